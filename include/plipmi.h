@@ -1,0 +1,185 @@
+/*
+ * plipmi.h -- C ABI of libplipmi.so, the MI355X (gfx950) PLIP embedding engine.
+ *
+ * This is the drop-in boundary for the one hot path of PathologyFoundation/plip:
+ * the batched encode_images / encode_text forward and the image x text
+ * cosine-similarity logits.  The reference has no FFI layer of its own -- the
+ * seam is "the object stored in self.model" (reference plip.py:18) -- so every
+ * entry point below names the reference call it replaces:
+ *
+ *   plipmi_create         <- CLIPModel.from_pretrained(...).to(device)        plip.py:26,18
+ *                            clip.load(arch) + load_state_dict(...)           reproducibility/embedders/factory.py:21-25
+ *   plipmi_encode_image   <- self.model.get_image_features(**batch)           plip.py:50
+ *                            self.model.encode_image(images)                  reproducibility/embedders/plip.py:48
+ *   plipmi_encode_text    <- self.model.get_text_features(**batch)            plip.py:68
+ *                            self.model.encode_text(clip.tokenize(...))       reproducibility/embedders/plip.py:65-66
+ *   plipmi_l2_normalize   <- x / np.linalg.norm(x, axis=-1, keepdims=True)    plip.py:75, embedders/plip.py:53,73
+ *   plipmi_logits         <- CLIPModel.forward -> logits_per_image/_text      README.md:45-50 (HF modeling_clip.py:810-817)
+ *                            image_embeddings.dot(text_embeddings.T); argmax  reproducibility/evaluation/zero_shot/zero_shot.py:12-13
+ *   plipmi_topk           <- cosine_sim.argsort()[:, -k:][:, ::-1]            plip.py:78-87, evaluation/retrieval/retrieval.py:13-18
+ *
+ * Conventions
+ *   - plain C, no torch / HIP types in the signatures: device buffers are raw
+ *     `void*` device addresses (tensor.data_ptr()), the stream is a
+ *     hipStream_t passed as `void*` (NULL = the legacy default stream).
+ *   - every call only ENQUEUES work on the given stream and returns; the
+ *     caller synchronises.  Inputs are never modified; outputs are caller-owned.
+ *   - one handle per GPU / process, not thread-safe per handle.
+ *   - return value: 0 = OK, anything else = error; the message is available
+ *     from plipmi_last_error() (thread local).
+ *   - fp32 tensors are row-major C-contiguous; pixel input is NCHW.
+ */
+#ifndef PLIPMI_H
+#define PLIPMI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PLIPMI_VERSION 100 /* 0.1.0 */
+
+/* arithmetic the towers' GEMMs and attention run in (accumulation, LayerNorm,
+ * softmax statistics, residual stream, projections and logits are always fp32) */
+enum { PLIPMI_F32 = 0, PLIPMI_BF16 = 1 };
+
+/* towers, for plipmi_debug_hidden */
+enum { PLIPMI_VISION = 0, PLIPMI_TEXT = 1 };
+
+/* status codes */
+enum {
+  PLIPMI_OK = 0,
+  PLIPMI_ERR_INVALID = 1,   /* bad argument / unsupported shape */
+  PLIPMI_ERR_HIP = 2,       /* a HIP runtime call failed */
+  PLIPMI_ERR_NODEVICE = 3,  /* no gfx950 device visible */
+  PLIPMI_ERR_NOMEM = 4
+};
+
+typedef struct plipmi_engine* plipmi_handle;
+
+/* Architecture = the numbers in HF CLIPConfig (configuration_clip.py:47-64,97-109). */
+typedef struct plipmi_config {
+  int32_t image_size;      /* 224 */
+  int32_t patch_size;      /* 32  */
+  int32_t v_width;         /* 768 */
+  int32_t v_layers;        /* 12  */
+  int32_t v_heads;         /* 12  (head_dim must be 64) */
+  int32_t v_mlp;           /* 3072 */
+  int32_t vocab_size;      /* 49408 */
+  int32_t context_length;  /* 77 */
+  int32_t t_width;         /* 512 */
+  int32_t t_layers;        /* 12 */
+  int32_t t_heads;         /* 8 */
+  int32_t t_mlp;           /* 2048 */
+  int32_t projection_dim;  /* 512 */
+  float   layer_norm_eps;  /* 1e-5 */
+  int32_t compute_dtype;   /* PLIPMI_F32 | PLIPMI_BF16 */
+  int32_t max_batch;       /* images (and captions) per encode call the workspace is sized for */
+} plipmi_config;
+
+/* One pre-LN transformer block, HF CLIPEncoderLayer naming; all DEVICE pointers
+ * to fp32, Linear weights stored [out, in] exactly as in the state dict. */
+typedef struct plipmi_layer_weights {
+  const float *ln1_w, *ln1_b;
+  const float *q_w, *q_b, *k_w, *k_b, *v_w, *v_b, *o_w, *o_b;
+  const float *ln2_w, *ln2_b;
+  const float *fc1_w, *fc1_b, *fc2_w, *fc2_b;
+} plipmi_layer_weights;
+
+/* The whole checkpoint (HF CLIPModel state-dict tensors).  `v_layers` / `t_layers`
+ * are HOST arrays of per-layer structs whose members are device pointers.  The
+ * engine re-packs everything into its own buffers during plipmi_create, so the
+ * caller may free these tensors as soon as the create stream has drained. */
+typedef struct plipmi_weights {
+  const float* v_class_embedding;   /* [Dv]            vision_model.embeddings.class_embedding */
+  const float* v_patch_weight;      /* [Dv,3,P,P]      ...patch_embedding.weight (no bias)      */
+  const float* v_pos_embedding;     /* [Np+1,Dv]       ...position_embedding.weight             */
+  const float *v_pre_ln_w, *v_pre_ln_b;    /* vision_model.pre_layrnorm */
+  const float *v_post_ln_w, *v_post_ln_b;  /* vision_model.post_layernorm */
+  const float* visual_projection;   /* [P,Dv]  no bias */
+  const plipmi_layer_weights* v_layers;
+  const float* t_token_embedding;   /* [V,Dt] */
+  const float* t_pos_embedding;     /* [ctx,Dt] */
+  const float *t_final_ln_w, *t_final_ln_b;
+  const float* text_projection;     /* [P,Dt]  no bias */
+  const plipmi_layer_weights* t_layers;
+} plipmi_weights;
+
+/* ---- lifetime ----------------------------------------------------------- */
+int  plipmi_create(const plipmi_config* cfg, const plipmi_weights* w, void* stream, plipmi_handle* out);
+void plipmi_destroy(plipmi_handle h);
+int  plipmi_version(void);
+const char* plipmi_last_error(void);
+/* name of the device the engine runs on ("gfx950:..."), for logs */
+const char* plipmi_device_name(plipmi_handle h);
+
+/* ---- the hot path ----------------------------------------------------------
+ * pixels  : fp32 [B,3,H,W] NCHW, already CLIP-normalised (what CLIPProcessor /
+ *           reproducibility/embedders/transform.py:45-52 produce)
+ * out     : fp32 [B, projection_dim]; un-normalised when normalize == 0 (what
+ *           PLIP.encode_images returns, plip.py:53), L2-normalised rows when 1
+ *           (what CLIPEmbedder returns, embedders/plip.py:53).
+ * B may be anything in [0, max_batch]. */
+int plipmi_encode_image(plipmi_handle h, const float* pixels, int B, float* out, int normalize, void* stream);
+
+/* ids            : int64 [B, context_length] token ids
+ * attention_mask : int64 [B, context_length] (1 = token, 0 = padding) or NULL;
+ *                  combined with the causal mask like HF create_causal_mask
+ * eos_token_id   : pooled row = first position whose id == eos_token_id (0 if
+ *                  none); eos_token_id < 0 or == 2 selects "first arg-max of the
+ *                  ids" (legacy HF configs and OpenAI-clip), modeling_clip.py:561-581 */
+int plipmi_encode_text(plipmi_handle h, const int64_t* ids, const int64_t* attention_mask, int B,
+                       int eos_token_id, float* out, int normalize, void* stream);
+
+/* in-place row-wise x / sqrt(sum x^2), no epsilon (modeling_clip.py:57-65) */
+int plipmi_l2_normalize(plipmi_handle h, float* x, int N, int D, void* stream);
+
+/* logits_per_image[i,j] = scale * <img_i, txt_j>  ([Ni,Nt], required)
+ * logits_per_text       = its transpose            ([Nt,Ni], optional, may be NULL)
+ * argmax_per_image[i]   = first arg-max_j          (int32 [Ni], optional, may be NULL)
+ * img [Ni,D], txt [Nt,D] fp32; pass scale = exp(logit_scale) for CLIPModel.forward,
+ * 1.0 for the plain dot product of the zero-shot / retrieval heads. */
+int plipmi_logits(plipmi_handle h, const float* img, int Ni, const float* txt, int Nt, int D, float scale,
+                  float* logits_per_image, float* logits_per_text, int32_t* argmax_per_image, void* stream);
+
+/* top-k columns of each row of scores [N,M], descending (ties: lower index first);
+ * idx int64 [N,k].  Replaces argsort()[:, -k:][:, ::-1] (plip.py:84). */
+int plipmi_topk(plipmi_handle h, const float* scores, int N, int M, int k, int64_t* idx, void* stream);
+
+/* ---- test / measurement hooks ---------------------------------------------- */
+/* Parity tests only: run `tower` on `input` (pixels or ids; mask = NULL) through its
+ * first `layer` blocks and copy the fp32 residual stream [B,S,D] to `out`
+ * (layer 0 = embeddings, after pre_layrnorm for the vision tower -- HF hidden_states[layer]). */
+int plipmi_debug_hidden(plipmi_handle h, int tower, int layer, const void* input, int B, float* out, void* stream);
+
+/* Kernel-level entry for unit tests and micro-benchmarks of the GEMM that carries
+ * >98 % of the path's FLOPs:  C = epilogue(A[M,K] * W[N,K]^T).
+ *   dtype    PLIPMI_F32 | PLIPMI_BF16 (A, W and non-fp32 outputs are that type; bf16 as raw uint16)
+ *   epilogue 0: C(dtype) = acc + bias        1: C(dtype) = quickgelu(acc + bias)
+ *            2: C(f32) += acc + bias         3: C(f32)   = alpha * acc
+ *   variant  -1 = the engine's own choice, >= 0 = a specific tile configuration
+ *            (plipmi_gemm_variant_name lists them; NULL past the end);
+ *            variant -2 = the naive one-thread-per-output checker kernel. */
+int plipmi_gemm_nt(int dtype, int epilogue, int variant, int M, int N, int K, const void* A, const void* W,
+                   const float* bias, float alpha, void* C, void* stream);
+const char* plipmi_gemm_variant_name(int variant);
+
+/* Per-kernel timing with HIP events recorded on the launch stream.  While
+ * enabled every kernel launch of the handle is bracketed by two events; the
+ * totals are read back (this call synchronises) as rows of `plipmi_kernel_stat`. */
+typedef struct plipmi_kernel_stat {
+  char   name[96];     /* kernel symbol family, e.g. "gemm_nt<bf16,128x128,bias_qgelu>" */
+  int64_t calls;
+  double total_ms;     /* sum of event-measured durations */
+  double flops;        /* algorithmic FLOPs of those calls (GEMM/attention), 0 for byte-bound kernels */
+  double bytes;        /* algorithmic bytes moved by those calls */
+} plipmi_kernel_stat;
+int plipmi_profile_enable(plipmi_handle h, int on);   /* on=1 starts (and clears), on=0 stops */
+int plipmi_profile_read(plipmi_handle h, plipmi_kernel_stat* rows, int max_rows, int* n_rows);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PLIPMI_H */

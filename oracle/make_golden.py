@@ -1,0 +1,86 @@
+"""Generate tests/golden/*.npz from the reference's arithmetic -- TEST INFRASTRUCTURE.
+
+Run in the build container (needs ``transformers``; no GPU):
+
+    python -m oracle.make_golden
+
+For every case the synthetic weights/inputs are re-derivable from seeds
+(plip_amd.weights.synthetic_*: numpy RandomState), so only the *outputs* of
+HuggingFace ``CLIPModel`` (CPU fp32, sdpa attention -- the HF default the
+reference gets, modeling_clip.py:394) are stored, plus weight/input
+fingerprints that prove a test regenerated the very same tensors.
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from oracle import hf_reference as H  # noqa: E402
+from plip_amd import weights as W  # noqa: E402
+from plip_amd.config import LN100, get_config  # noqa: E402
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+# name -> (arch, batch, weight seed, pixel seed, ids seed, pad style, logit_scale override)
+CASES = {
+    "tiny_b6": ("tiny", 6, 0, 1, 2, "eos", None),
+    "tiny_b5_zero_pad_ln100": ("tiny", 5, 3, 4, 5, "zero", LN100),
+    "vitb32_b4": ("ViT-B/32", 4, 0, 1, 2, "eos", None),
+    "vitb32_b3_zero_pad_ln100": ("ViT-B/32", 3, 7, 8, 9, "zero", LN100),
+}
+
+
+def fingerprint(sd) -> np.ndarray:
+    """Order-independent digest of a state dict: per-tensor (sum, sum of squares) in float64."""
+    keys = sorted(sd)
+    return np.array([[np.asarray(sd[k], dtype=np.float64).sum(),
+                      (np.asarray(sd[k], dtype=np.float64) ** 2).sum()] for k in keys])
+
+
+def case_inputs(name):
+    arch, B, ws, ps, is_, pad, ls = CASES[name]
+    cfg = get_config(arch)
+    if arch != "tiny" and pad == "zero":
+        cfg = cfg.replace(eos_token_id=2)       # OpenAI-clip / legacy-HF argmax pooling rule
+    sd = W.synthetic_state_dict(cfg, ws, logit_scale=ls)
+    px = W.synthetic_pixels(cfg, B, ps)
+    ids, mask = W.synthetic_ids(cfg.replace(eos_token_id=get_config(arch).eos_token_id), B, is_, pad=pad)
+    return cfg, sd, px, ids, mask
+
+
+def main():
+    os.makedirs(GOLDEN_DIR, exist_ok=True)
+    for name in CASES:
+        cfg, sd, px, ids, mask = case_inputs(name)
+        model = H.build_model(cfg, sd, "sdpa")
+        # the OpenAI tokenizer gives no attention_mask: zero-pad cases run without one
+        use_mask = None if "zero_pad" in name else mask
+        out = H.run(model, px, ids, use_mask, output_hidden_states=True)
+        save = {k: out[k] for k in ("image_features", "text_features", "image_embeds", "text_embeds",
+                                    "logits_per_image", "logits_per_text")}
+        # hidden states: all of them for tiny; CLS / first-EOS rows for the full model (small files)
+        vh, th = out["vision_hidden"], out["text_hidden"]
+        if cfg.v_width <= 128:
+            save["vision_hidden"] = np.stack(vh)
+            save["text_hidden"] = np.stack(th)
+        else:
+            save["vision_hidden_cls"] = np.stack([h[:, 0, :] for h in vh])
+            save["vision_hidden_last_token"] = np.stack([h[:, -1, :] for h in vh])
+            save["text_hidden_bos"] = np.stack([h[:, 0, :] for h in th])
+            save["text_hidden_tok1"] = np.stack([h[:, 1, :] for h in th])
+        save["weights_fingerprint"] = fingerprint(sd)
+        save["pixels_fingerprint"] = np.array([px.astype(np.float64).sum(), (px.astype(np.float64) ** 2).sum()])
+        save["ids"] = ids
+        save["mask"] = mask
+        path = os.path.join(GOLDEN_DIR, name + ".npz")
+        np.savez_compressed(path, **save)
+        print(f"{name}: wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB)  "
+              f"|logits|max={np.abs(out['logits_per_image']).max():.4f}")
+
+
+if __name__ == "__main__":
+    main()

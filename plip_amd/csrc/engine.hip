@@ -1,0 +1,467 @@
+// engine.hip -- the C ABI of libplipmi.so (include/plipmi.h): weight packing, the two
+// tower drivers, logits / top-k heads and the event-based per-kernel profile.
+//
+// Data layout in HBM (per handle)
+//   weights    one slab: per layer  Wqkv [3D,D] (q rows pre-scaled by 1/8 = 64^-1/2, exact),
+//              Wo [D,D], W1 [F,D], W2 [D,F] in the compute dtype, K contiguous (= the HF
+//              [out,in] layout, so no transposes); biases / LayerNorm / embeddings fp32;
+//              projection matrices transposed to [D,P] fp32 for the pooled head.
+//   workspace  per tower, sized for max_batch: residual stream x fp32 [M,D]; h [M,D],
+//              qkv [M,3D], attn [M,D], mlp [M,F] in the compute dtype (M = B * tokens).
+//              The two towers have separate workspaces so they can run on two streams.
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/plipmi.h"
+#include "gemm.h"
+#include "kernels.h"
+
+using namespace plipmi;
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+#define HIP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t e_ = (expr);                                                                        \
+    if (e_ != hipSuccess) return fail(PLIPMI_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+namespace {
+
+struct LayerW {
+  void *wqkv, *wo, *w1, *w2;
+  float *bqkv, *bo, *b1, *b2, *ln1w, *ln1b, *ln2w, *ln2b;
+};
+struct Tower {
+  int D = 0, F = 0, L = 0, H = 0, S = 0;
+  std::vector<LayerW> layers;
+  // workspace
+  float* x = nullptr;
+  void *h = nullptr, *qkv = nullptr, *att = nullptr, *mlp = nullptr;
+};
+struct ProfRec {
+  const char* name;
+  hipEvent_t t0, t1;
+  double flops, bytes;
+};
+
+}  // namespace
+
+struct plipmi_engine {
+  plipmi_config cfg;
+  int dtype = 0;
+  size_t esz = 4;
+  int np = 0, kpad = 0;
+  Tower vis, txt;
+  void* patch_w = nullptr;  // [Dv, kpad]
+  void* patches = nullptr;  // [max_batch*np, kpad]
+  float *cls = nullptr, *vpos = nullptr, *pre_w = nullptr, *pre_b = nullptr, *post_w = nullptr, *post_b = nullptr,
+        *vproj_t = nullptr;
+  float *tok = nullptr, *tpos = nullptr, *fin_w = nullptr, *fin_b = nullptr, *tproj_t = nullptr;
+  char* slab = nullptr;
+  size_t slab_bytes = 0;
+  int attn_impl = 0;
+  char devname[128] = "";
+  // profiling
+  bool prof = false;
+  std::vector<ProfRec> recs;
+  std::vector<hipEvent_t> pool;
+};
+
+namespace {
+
+struct Scope {  // brackets one kernel launch with events while profiling is on
+  plipmi_engine* e;
+  hipStream_t s;
+  bool on;
+  ProfRec r;
+  Scope(plipmi_engine* e_, hipStream_t s_, const char* name, double flops, double bytes) : e(e_), s(s_), on(e_->prof) {
+    if (!on) return;
+    r.name = name; r.flops = flops; r.bytes = bytes;
+    r.t0 = take(); r.t1 = take();
+    hipEventRecord(r.t0, s);
+  }
+  void rename(const char* name) { r.name = name; }
+  ~Scope() {
+    if (!on) return;
+    hipEventRecord(r.t1, s);
+    e->recs.push_back(r);
+  }
+  hipEvent_t take() {
+    if (!e->pool.empty()) { hipEvent_t ev = e->pool.back(); e->pool.pop_back(); return ev; }
+    hipEvent_t ev; hipEventCreate(&ev); return ev;
+  }
+};
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct Carver {  // two-pass slab carving: pass 1 sizes, pass 2 hands out pointers
+  char* base = nullptr;
+  size_t off = 0;
+  template <typename T> T* take(size_t count, size_t elem) {
+    off = align_up(off, 256);
+    T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+    off += count * elem;
+    return p;
+  }
+};
+
+void carve(plipmi_engine* e, Carver& c) {
+  const plipmi_config& g = e->cfg;
+  const size_t es = e->esz;
+  const size_t B = (size_t)g.max_batch;
+  e->patch_w = c.take<void>((size_t)g.v_width * e->kpad, es);
+  e->cls = c.take<float>(g.v_width, 4);
+  e->vpos = c.take<float>((size_t)(e->np + 1) * g.v_width, 4);
+  e->pre_w = c.take<float>(g.v_width, 4);  e->pre_b = c.take<float>(g.v_width, 4);
+  e->post_w = c.take<float>(g.v_width, 4); e->post_b = c.take<float>(g.v_width, 4);
+  e->vproj_t = c.take<float>((size_t)g.v_width * g.projection_dim, 4);
+  e->tok = c.take<float>((size_t)g.vocab_size * g.t_width, 4);
+  e->tpos = c.take<float>((size_t)g.context_length * g.t_width, 4);
+  e->fin_w = c.take<float>(g.t_width, 4);  e->fin_b = c.take<float>(g.t_width, 4);
+  e->tproj_t = c.take<float>((size_t)g.t_width * g.projection_dim, 4);
+  for (Tower* t : {&e->vis, &e->txt}) {
+    const size_t D = t->D, F = t->F;
+    t->layers.resize(t->L);
+    for (LayerW& w : t->layers) {
+      w.wqkv = c.take<void>(3 * D * D, es); w.wo = c.take<void>(D * D, es);
+      w.w1 = c.take<void>(F * D, es);       w.w2 = c.take<void>(D * F, es);
+      w.bqkv = c.take<float>(3 * D, 4); w.bo = c.take<float>(D, 4); w.b1 = c.take<float>(F, 4); w.b2 = c.take<float>(D, 4);
+      w.ln1w = c.take<float>(D, 4); w.ln1b = c.take<float>(D, 4); w.ln2w = c.take<float>(D, 4); w.ln2b = c.take<float>(D, 4);
+    }
+    const size_t M = B * t->S;
+    t->x = c.take<float>(M * D, 4);
+    t->h = c.take<void>(M * D, es);
+    t->qkv = c.take<void>(M * 3 * D, es);
+    t->att = c.take<void>(M * D, es);
+    t->mlp = c.take<void>(M * F, es);
+  }
+  e->patches = c.take<void>(B * e->np * e->kpad, es);
+}
+
+int pack_tower(plipmi_engine* e, Tower& t, const plipmi_layer_weights* src, hipStream_t s) {
+  const int D = t.D, F = t.F, dt = e->dtype;
+  const float qscale = 0.125f;  // head_dim 64 -> 64^-0.5, a power of two: folding it into Wq/bq is exact
+  for (int l = 0; l < t.L; ++l) {
+    const plipmi_layer_weights& w = src[l];
+    LayerW& d = t.layers[l];
+    char* wq = reinterpret_cast<char*>(d.wqkv);
+    HIP_TRY(launch_convert(w.q_w, wq, dt, D, D, D, qscale, s));
+    HIP_TRY(launch_convert(w.k_w, wq + (size_t)D * D * e->esz, dt, D, D, D, 1.f, s));
+    HIP_TRY(launch_convert(w.v_w, wq + (size_t)2 * D * D * e->esz, dt, D, D, D, 1.f, s));
+    HIP_TRY(launch_scale_copy(w.q_b, d.bqkv, D, qscale, s));
+    HIP_TRY(launch_scale_copy(w.k_b, d.bqkv + D, D, 1.f, s));
+    HIP_TRY(launch_scale_copy(w.v_b, d.bqkv + 2 * D, D, 1.f, s));
+    HIP_TRY(launch_convert(w.o_w, d.wo, dt, D, D, D, 1.f, s));
+    HIP_TRY(launch_convert(w.fc1_w, d.w1, dt, F, D, D, 1.f, s));
+    HIP_TRY(launch_convert(w.fc2_w, d.w2, dt, D, F, F, 1.f, s));
+    HIP_TRY(launch_scale_copy(w.o_b, d.bo, D, 1.f, s));
+    HIP_TRY(launch_scale_copy(w.fc1_b, d.b1, F, 1.f, s));
+    HIP_TRY(launch_scale_copy(w.fc2_b, d.b2, D, 1.f, s));
+    HIP_TRY(launch_scale_copy(w.ln1_w, d.ln1w, D, 1.f, s));
+    HIP_TRY(launch_scale_copy(w.ln1_b, d.ln1b, D, 1.f, s));
+    HIP_TRY(launch_scale_copy(w.ln2_w, d.ln2w, D, 1.f, s));
+    HIP_TRY(launch_scale_copy(w.ln2_b, d.ln2b, D, 1.f, s));
+  }
+  return PLIPMI_OK;
+}
+
+int run_gemm(plipmi_engine* e, int epi, const void* A, const void* W, void* C, const float* bias, int M, int N, int K,
+             int ldc, int np, hipStream_t s) {
+  GemmParams p;
+  p.A = A; p.W = W; p.C = C; p.bias = bias;
+  p.M = M; p.N = N; p.K = K; p.lda = K; p.ldw = K; p.ldc = ldc; p.alpha = 1.f; p.np = np;
+  const char* name = "gemm_nt";
+  Scope sc(e, s, name, 2.0 * M * N * (double)K, ((double)M * K + (double)N * K) * e->esz + (double)M * N * 4);
+  const int rc = gemm_launch(e->dtype, epi, -1, p, s, &name);
+  sc.rename(name);
+  if (rc != 0) return fail(PLIPMI_ERR_HIP, "gemm launch (%s, M=%d N=%d K=%d) failed: %s", name, M, N, K,
+                           hipGetErrorString((hipError_t)rc));
+  return PLIPMI_OK;
+}
+
+#define RUN(expr) do { int rc_ = (expr); if (rc_ != PLIPMI_OK) return rc_; } while (0)
+
+// n_layers pre-LN residual blocks over the tower's residual stream x (CLIPEncoderLayer, modeling_clip.py:362-383)
+int run_layers(plipmi_engine* e, Tower& t, int B, int n_layers, int causal, const int64_t* key_mask, hipStream_t s) {
+  const int M = B * t.S, D = t.D, F = t.F;
+  const float eps = e->cfg.layer_norm_eps;
+  for (int l = 0; l < n_layers; ++l) {
+    const LayerW& w = t.layers[l];
+    { Scope sc(e, s, "layernorm", 0, (double)M * D * (4 + e->esz));
+      HIP_TRY(launch_layernorm(t.x, D, w.ln1w, w.ln1b, t.h, e->dtype, M, D, eps, s)); }
+    RUN(run_gemm(e, EPI_BIAS, t.h, w.wqkv, t.qkv, w.bqkv, M, 3 * D, D, 3 * D, 0, s));
+    { Scope sc(e, s, e->attn_impl ? "attention_mfma" : "attention_valu", 4.0 * B * t.H * (double)t.S * t.S * 64,
+               (double)M * 4 * D * e->esz);
+      HIP_TRY(launch_attention(t.qkv, t.att, e->dtype, B, t.S, t.H, causal, key_mask, e->attn_impl, s)); }
+    RUN(run_gemm(e, EPI_BIAS_RESID, t.att, w.wo, t.x, w.bo, M, D, D, D, 0, s));
+    { Scope sc(e, s, "layernorm", 0, (double)M * D * (4 + e->esz));
+      HIP_TRY(launch_layernorm(t.x, D, w.ln2w, w.ln2b, t.h, e->dtype, M, D, eps, s)); }
+    RUN(run_gemm(e, EPI_BIAS_QGELU, t.h, w.w1, t.mlp, w.b1, M, F, D, F, 0, s));
+    RUN(run_gemm(e, EPI_BIAS_RESID, t.mlp, w.w2, t.x, w.b2, M, D, F, D, 0, s));
+  }
+  return PLIPMI_OK;
+}
+
+// CLIPVisionEmbeddings + pre_layrnorm (modeling_clip.py:202-218,642): x = LN(cat(cls, conv(pixels)) + pos)
+int vision_embed(plipmi_engine* e, const float* pixels, int B, hipStream_t s) {
+  const plipmi_config& g = e->cfg;
+  Tower& t = e->vis;
+  { Scope sc(e, s, "unfold_patches", 0, (double)B * 3 * g.image_size * g.image_size * 4 + (double)B * e->np * e->kpad * e->esz);
+    HIP_TRY(launch_unfold_patches(pixels, e->patches, e->dtype, B, g.image_size, g.patch_size, e->kpad, s)); }
+  { Scope sc(e, s, "cls_rows", 0, (double)B * t.D * 4);
+    HIP_TRY(launch_cls_rows(e->cls, e->vpos, t.x, B, t.S, t.D, s)); }
+  RUN(run_gemm(e, EPI_PATCH, e->patches, e->patch_w, t.x, e->vpos, B * e->np, t.D, e->kpad, t.D, e->np, s));
+  { Scope sc(e, s, "layernorm", 0, (double)B * t.S * t.D * 8);
+    HIP_TRY(launch_layernorm(t.x, t.D, e->pre_w, e->pre_b, t.x, 0, B * t.S, t.D, g.layer_norm_eps, s)); }
+  return PLIPMI_OK;
+}
+
+int text_embed(plipmi_engine* e, const int64_t* ids, int B, hipStream_t s) {
+  Tower& t = e->txt;
+  Scope sc(e, s, "text_embed", 0, (double)B * t.S * t.D * 8);
+  HIP_TRY(launch_text_embed(ids, e->tok, e->tpos, t.x, B, t.S, t.D, e->cfg.vocab_size, s));
+  return PLIPMI_OK;
+}
+
+int check_batch(plipmi_engine* e, int B) {
+  if (!e) return fail(PLIPMI_ERR_INVALID, "null handle");
+  if (B < 0 || B > e->cfg.max_batch)
+    return fail(PLIPMI_ERR_INVALID, "batch %d outside [0, max_batch=%d]", B, e->cfg.max_batch);
+  return PLIPMI_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int plipmi_version(void) { return PLIPMI_VERSION; }
+const char* plipmi_last_error(void) { return g_err; }
+const char* plipmi_device_name(plipmi_handle h) { return h ? h->devname : ""; }
+
+int plipmi_create(const plipmi_config* cfg, const plipmi_weights* w, void* stream, plipmi_handle* out) {
+  if (!cfg || !w || !out) return fail(PLIPMI_ERR_INVALID, "null argument");
+  *out = nullptr;
+  const plipmi_config& g = *cfg;
+  if (g.compute_dtype != PLIPMI_F32 && g.compute_dtype != PLIPMI_BF16)
+    return fail(PLIPMI_ERR_INVALID, "compute_dtype must be PLIPMI_F32 or PLIPMI_BF16");
+  if (g.v_heads <= 0 || g.t_heads <= 0 || g.v_width != g.v_heads * 64 || g.t_width != g.t_heads * 64)
+    return fail(PLIPMI_ERR_INVALID, "head_dim must be 64 (v_width=%d/%d heads, t_width=%d/%d heads)", g.v_width,
+                g.v_heads, g.t_width, g.t_heads);
+  if (g.patch_size <= 0 || g.image_size % g.patch_size) return fail(PLIPMI_ERR_INVALID, "image_size %% patch_size != 0");
+  if (g.v_width % 128 || g.v_mlp % 128 || g.t_width % 128 || g.t_mlp % 128)
+    return fail(PLIPMI_ERR_INVALID, "widths and MLP sizes must be multiples of 128 (GEMM tile)");
+  if (g.v_width > 2048 || g.t_width > 2048 || g.projection_dim > 1024 || g.projection_dim <= 0)
+    return fail(PLIPMI_ERR_INVALID, "width > 2048 or projection_dim > 1024 not supported");
+  if (g.max_batch <= 0 || g.v_layers <= 0 || g.t_layers <= 0 || g.context_length <= 0 || g.vocab_size <= 0)
+    return fail(PLIPMI_ERR_INVALID, "non-positive size in config");
+  const int tokens = (g.image_size / g.patch_size) * (g.image_size / g.patch_size) + 1;
+  if (tokens > 1024 || g.context_length > 1024) return fail(PLIPMI_ERR_INVALID, "more than 1024 tokens per sequence");
+
+  int dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
+    return fail(PLIPMI_ERR_NODEVICE, "no HIP device visible (libplipmi needs an MI355X / gfx950 GPU)");
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(PLIPMI_ERR_NODEVICE, "device %d is %s; libplipmi is built for gfx950 only", dev, prop.gcnArchName);
+
+  plipmi_engine* e = new plipmi_engine();
+  e->cfg = g;
+  e->dtype = g.compute_dtype;
+  e->esz = g.compute_dtype == PLIPMI_BF16 ? 2 : 4;
+  e->np = tokens - 1;
+  e->kpad = (int)align_up((size_t)3 * g.patch_size * g.patch_size, 64);
+  snprintf(e->devname, sizeof(e->devname), "%s:%s", prop.gcnArchName, prop.name);
+  e->vis.D = g.v_width; e->vis.F = g.v_mlp; e->vis.L = g.v_layers; e->vis.H = g.v_heads; e->vis.S = tokens;
+  e->txt.D = g.t_width; e->txt.F = g.t_mlp; e->txt.L = g.t_layers; e->txt.H = g.t_heads; e->txt.S = g.context_length;
+  const char* ai = getenv("PLIPMI_ATTENTION");
+  e->attn_impl = ai ? atoi(ai) : 0;
+  if (e->dtype != PLIPMI_BF16) e->attn_impl = 0;
+
+  Carver sizing;
+  carve(e, sizing);
+  e->slab_bytes = align_up(sizing.off, 256);
+  hipError_t me = hipMalloc(reinterpret_cast<void**>(&e->slab), e->slab_bytes);
+  if (me != hipSuccess) {
+    const size_t need = e->slab_bytes;
+    delete e;
+    return fail(PLIPMI_ERR_NOMEM, "hipMalloc(%zu bytes) failed: %s", need, hipGetErrorString(me));
+  }
+  Carver placing;
+  placing.base = e->slab;
+  carve(e, placing);
+
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  int rc = PLIPMI_OK;
+  auto body = [&]() -> int {
+    const int Dv = g.v_width, Dt = g.t_width, P = g.projection_dim;
+    HIP_TRY(launch_convert(w->v_patch_weight, e->patch_w, e->dtype, Dv, 3 * g.patch_size * g.patch_size, e->kpad, 1.f, s));
+    HIP_TRY(launch_scale_copy(w->v_class_embedding, e->cls, Dv, 1.f, s));
+    HIP_TRY(launch_scale_copy(w->v_pos_embedding, e->vpos, tokens * Dv, 1.f, s));
+    HIP_TRY(launch_scale_copy(w->v_pre_ln_w, e->pre_w, Dv, 1.f, s));
+    HIP_TRY(launch_scale_copy(w->v_pre_ln_b, e->pre_b, Dv, 1.f, s));
+    HIP_TRY(launch_scale_copy(w->v_post_ln_w, e->post_w, Dv, 1.f, s));
+    HIP_TRY(launch_scale_copy(w->v_post_ln_b, e->post_b, Dv, 1.f, s));
+    HIP_TRY(launch_transpose(w->visual_projection, e->vproj_t, P, Dv, s));
+    HIP_TRY(hipMemcpyAsync(e->tok, w->t_token_embedding, (size_t)g.vocab_size * Dt * 4, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(launch_scale_copy(w->t_pos_embedding, e->tpos, g.context_length * Dt, 1.f, s));
+    HIP_TRY(launch_scale_copy(w->t_final_ln_w, e->fin_w, Dt, 1.f, s));
+    HIP_TRY(launch_scale_copy(w->t_final_ln_b, e->fin_b, Dt, 1.f, s));
+    HIP_TRY(launch_transpose(w->text_projection, e->tproj_t, P, Dt, s));
+    RUN(pack_tower(e, e->vis, w->v_layers, s));
+    RUN(pack_tower(e, e->txt, w->t_layers, s));
+    return PLIPMI_OK;
+  };
+  rc = body();
+  if (rc != PLIPMI_OK) {
+    hipFree(e->slab);
+    delete e;
+    return rc;
+  }
+  *out = e;
+  return PLIPMI_OK;
+}
+
+void plipmi_destroy(plipmi_handle h) {
+  if (!h) return;
+  for (ProfRec& r : h->recs) { hipEventDestroy(r.t0); hipEventDestroy(r.t1); }
+  for (hipEvent_t ev : h->pool) hipEventDestroy(ev);
+  if (h->slab) hipFree(h->slab);
+  delete h;
+}
+
+int plipmi_encode_image(plipmi_handle h, const float* pixels, int B, float* out, int normalize, void* stream) {
+  RUN(check_batch(h, B));
+  if (B == 0) return PLIPMI_OK;
+  if (!pixels || !out) return fail(PLIPMI_ERR_INVALID, "null pixels/out");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  RUN(vision_embed(h, pixels, B, s));
+  RUN(run_layers(h, h->vis, B, h->vis.L, 0, nullptr, s));
+  Scope sc(h, s, "pool_head", 2.0 * B * h->vis.D * h->cfg.projection_dim, (double)h->vis.D * h->cfg.projection_dim * 4);
+  HIP_TRY(launch_pool_head(h->vis.x, h->vis.S, h->vis.D, nullptr, -1, h->post_w, h->post_b, h->cfg.layer_norm_eps,
+                           h->vproj_t, h->cfg.projection_dim, out, B, normalize, s));
+  return PLIPMI_OK;
+}
+
+int plipmi_encode_text(plipmi_handle h, const int64_t* ids, const int64_t* attention_mask, int B, int eos_token_id,
+                       float* out, int normalize, void* stream) {
+  RUN(check_batch(h, B));
+  if (B == 0) return PLIPMI_OK;
+  if (!ids || !out) return fail(PLIPMI_ERR_INVALID, "null ids/out");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  RUN(text_embed(h, ids, B, s));
+  RUN(run_layers(h, h->txt, B, h->txt.L, 1, attention_mask, s));
+  Scope sc(h, s, "pool_head", 2.0 * B * h->txt.D * h->cfg.projection_dim, (double)h->txt.D * h->cfg.projection_dim * 4);
+  HIP_TRY(launch_pool_head(h->txt.x, h->txt.S, h->txt.D, ids, eos_token_id, h->fin_w, h->fin_b, h->cfg.layer_norm_eps,
+                           h->tproj_t, h->cfg.projection_dim, out, B, normalize, s));
+  return PLIPMI_OK;
+}
+
+int plipmi_debug_hidden(plipmi_handle h, int tower, int layer, const void* input, int B, float* out, void* stream) {
+  RUN(check_batch(h, B));
+  if (B == 0) return PLIPMI_OK;
+  if (!input || !out) return fail(PLIPMI_ERR_INVALID, "null input/out");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  Tower& t = tower == PLIPMI_VISION ? h->vis : h->txt;
+  if (tower != PLIPMI_VISION && tower != PLIPMI_TEXT) return fail(PLIPMI_ERR_INVALID, "tower must be 0 or 1");
+  if (layer < 0 || layer > t.L) return fail(PLIPMI_ERR_INVALID, "layer %d outside [0,%d]", layer, t.L);
+  if (tower == PLIPMI_VISION) RUN(vision_embed(h, reinterpret_cast<const float*>(input), B, s));
+  else RUN(text_embed(h, reinterpret_cast<const int64_t*>(input), B, s));
+  RUN(run_layers(h, t, B, layer, tower == PLIPMI_TEXT, nullptr, s));
+  HIP_TRY(hipMemcpyAsync(out, t.x, (size_t)B * t.S * t.D * 4, hipMemcpyDeviceToDevice, s));
+  return PLIPMI_OK;
+}
+
+int plipmi_l2_normalize(plipmi_handle h, float* x, int N, int D, void* stream) {
+  if (!h || !x || N < 0 || D <= 0) return fail(PLIPMI_ERR_INVALID, "bad argument");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  Scope sc(h, s, "l2_normalize", 0, (double)N * D * 8);
+  HIP_TRY(launch_l2_normalize(x, N, D, s));
+  return PLIPMI_OK;
+}
+
+int plipmi_logits(plipmi_handle h, const float* img, int Ni, const float* txt, int Nt, int D, float scale,
+                  float* logits_per_image, float* logits_per_text, int32_t* argmax_per_image, void* stream) {
+  if (!h || !img || !txt || !logits_per_image || Ni < 0 || Nt < 0 || D <= 0) return fail(PLIPMI_ERR_INVALID, "bad argument");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  Scope sc(h, s, "logits", 2.0 * Ni * (double)Nt * D, ((double)Ni + Nt) * D * 4 + (double)Ni * Nt * 4);
+  HIP_TRY(launch_logits(img, Ni, txt, Nt, D, scale, logits_per_image, logits_per_text, argmax_per_image, s));
+  return PLIPMI_OK;
+}
+
+int plipmi_topk(plipmi_handle h, const float* scores, int N, int M, int k, int64_t* idx, void* stream) {
+  if (!h || !scores || !idx || N < 0 || M <= 0 || k <= 0 || k > M) return fail(PLIPMI_ERR_INVALID, "bad argument (need 0 < k <= M)");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  Scope sc(h, s, "topk", 0, (double)N * M * 4 * k);
+  HIP_TRY(launch_topk(scores, N, M, k, idx, s));
+  return PLIPMI_OK;
+}
+
+int plipmi_gemm_nt(int dtype, int epilogue, int variant, int M, int N, int K, const void* A, const void* W,
+                   const float* bias, float alpha, void* C, void* stream) {
+  if (dtype != PLIPMI_F32 && dtype != PLIPMI_BF16) return fail(PLIPMI_ERR_INVALID, "bad dtype");
+  if (epilogue < 0 || epilogue > EPI_SCALE) return fail(PLIPMI_ERR_INVALID, "epilogue must be 0..3");
+  if (M < 0 || N <= 0 || K <= 0 || !A || !W || !C) return fail(PLIPMI_ERR_INVALID, "bad shape / null pointer");
+  if (epilogue != EPI_SCALE && !bias) return fail(PLIPMI_ERR_INVALID, "bias required for this epilogue");
+  GemmParams p;
+  p.A = A; p.W = W; p.C = C; p.bias = bias; p.M = M; p.N = N; p.K = K; p.lda = K; p.ldw = K; p.ldc = N;
+  p.alpha = alpha; p.np = 1;
+  const int rc = gemm_launch(dtype, epilogue, variant, p, reinterpret_cast<hipStream_t>(stream), nullptr);
+  if (rc != 0) return fail(PLIPMI_ERR_HIP, "gemm launch failed (variant %d, M=%d N=%d K=%d): %s", variant, M, N, K,
+                           hipGetErrorString((hipError_t)rc));
+  return PLIPMI_OK;
+}
+
+const char* plipmi_gemm_variant_name(int variant) {
+  if (variant < 0 || variant >= gemm_num_variants()) return nullptr;
+  return gemm_variant(variant).name;
+}
+
+int plipmi_profile_enable(plipmi_handle h, int on) {
+  if (!h) return fail(PLIPMI_ERR_INVALID, "null handle");
+  if (on) {
+    for (ProfRec& r : h->recs) { h->pool.push_back(r.t0); h->pool.push_back(r.t1); }
+    h->recs.clear();
+  }
+  h->prof = on != 0;
+  return PLIPMI_OK;
+}
+
+int plipmi_profile_read(plipmi_handle h, plipmi_kernel_stat* rows, int max_rows, int* n_rows) {
+  if (!h || !rows || !n_rows || max_rows <= 0) return fail(PLIPMI_ERR_INVALID, "bad argument");
+  HIP_TRY(hipDeviceSynchronize());
+  int n = 0;
+  for (ProfRec& r : h->recs) {
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, r.t0, r.t1));
+    int k = 0;
+    for (; k < n; ++k)
+      if (strncmp(rows[k].name, r.name, sizeof(rows[k].name) - 1) == 0) break;
+    if (k == n) {
+      if (n == max_rows) continue;
+      memset(&rows[n], 0, sizeof(rows[n]));
+      strncpy(rows[n].name, r.name, sizeof(rows[n].name) - 1);
+      ++n;
+    }
+    rows[k].calls += 1;
+    rows[k].total_ms += ms;
+    rows[k].flops += r.flops;
+    rows[k].bytes += r.bytes;
+  }
+  *n_rows = n;
+  return PLIPMI_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,329 @@
+// gemm.h -- the NT GEMM that carries >98 % of the PLIP forward's FLOPs.
+//
+//   C = epilogue( A[M,K] * W[N,K]^T )         A, W row-major, K contiguous
+//
+// which is exactly nn.Linear (HF stores Linear weights [out,in]) -- q/k/v, out_proj,
+// fc1, fc2 (modeling_clip.py:293-296,343-344), the unfolded patch-embed conv
+// (:148-154) and, with A = image embeds / W = text embeds, the logits (:814).
+//
+// gfx950 design
+//   * MFMA 32x32 tiles: v_mfma_f32_32x32x16_bf16 (bf16) or v_mfma_f32_32x32x2_f32
+//     (exact fp32, fmaf-chain numerics).  Operands are SWAPPED -- the weight
+//     fragment is the MFMA "A" operand and the activation fragment the "B"
+//     operand -- so a lane ends up with 4 CONSECUTIVE output columns of one
+//     output row per accumulator quad: 16-byte fp32 / 8-byte bf16 epilogue stores
+//     and a float4 bias load instead of 2-byte scalar stores.
+//   * LDS tile rows are always 128 bytes (BK = 64 bf16 / 32 fp32) = eight 16-byte
+//     chunks; chunk c of row r lives at slot c ^ ((r>>1)&7).  With that XOR every
+//     ds_read_b128 lane group (MI355X_MICROARCH LDS table) touches 16 distinct
+//     16-byte slots of the 256-byte bank row: conflict-free fragment reads.
+//   * global -> LDS staging either through `global_load_lds_dwordx4` (LDS-DMA, the
+//     LDS image is lane-linear so the swizzle is applied to the per-lane SOURCE
+//     address) or through registers (global_load_dwordx4 + ds_write_b128 issued
+//     after the MFMA block, so HBM/L2 latency hides under compute).
+//   * double-buffered LDS, one barrier per K tile.
+//   * blockIdx -> tile map is XCD-aware: hardware round-robins blocks over the 8
+//     XCDs, so block b is given logical tile (b%8)*ceil(n/8)+b/8 (bijective form)
+//     and each XCD's private L2 sees a contiguous strip of M tiles sweeping N.
+#pragma once
+#include "common.h"
+
+namespace plipmi {
+
+// first-class vector (HIP's uint4 struct keeps staging arrays in scratch)
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+enum Epilogue : int {
+  EPI_BIAS = 0,        // C(T)   = acc + bias[n]
+  EPI_BIAS_QGELU = 1,  // C(T)   = quickgelu(acc + bias[n])
+  EPI_BIAS_RESID = 2,  // C(f32) += acc + bias[n]            (in-place residual stream)
+  EPI_SCALE = 3,       // C(f32) = alpha * acc
+  EPI_PATCH = 4,       // C(f32)[img*(np+1)+1+p, n] = acc + pos[(1+p), n]   (m = img*np + p)
+  EPI_COUNT = 5
+};
+
+struct GemmParams {
+  const void* A;
+  const void* W;
+  void* C;
+  const float* bias;  // [N] (EPI_BIAS*) or position embedding [(np+1), N] (EPI_PATCH)
+  int M, N, K;
+  int lda, ldw, ldc;  // in elements
+  float alpha;
+  int np;             // patches per image (EPI_PATCH)
+};
+
+// LDS-DMA (global_load_lds_dwordx4): each lane's 16 bytes at `gsrc` land at
+// `lds_wave_base + lane*16` (wave-uniform base in M0).  Issued through inline asm
+// on purpose: with the builtin, hipcc cannot tell that the DMA fills the OTHER
+// LDS buffer and drains it (s_waitcnt vmcnt(0)) in front of the first ds_read of
+// the current one, which serialises load and compute.  The asm form is invisible
+// to its wait-count pass; the kernel waits vmcnt(0) itself right before the barrier
+// that publishes the buffer (cdna_hip_programming.md 5.7 item 1).  M0 is saved and
+// restored inside the statement because the compiler owns it.
+__device__ __forceinline__ void glds16(const char* gsrc, unsigned lds_wave_base) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_wave_base)
+      : "memory");
+}
+__device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// One 16-byte chunk of K per lane -> one (bf16) or four (fp32) MFMAs.
+template <typename T>
+__device__ __forceinline__ void mma16(f32x16& acc, const u32x4& wfrag, const u32x4& xfrag);
+
+template <>
+__device__ __forceinline__ void mma16<bf16_t>(f32x16& acc, const u32x4& wfrag, const u32x4& xfrag) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wfrag), __builtin_bit_cast(bf16x8, xfrag),
+                                                acc, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ void mma16<float>(f32x16& acc, const u32x4& wfrag, const u32x4& xfrag) {
+  // lane group g = lane>>5 holds k = 4*(2*kq+g)+j, j=0..3, for BOTH operands, so
+  // MFMA j multiplies matching k's (any k permutation shared by A and B is valid).
+  f32x4 w = __builtin_bit_cast(f32x4, wfrag), x = __builtin_bit_cast(f32x4, xfrag);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[j], x[j], acc, 0, 0, 0);
+}
+
+// Epilogue split in a LOAD half (bias / residual / position rows; issued back to
+// back for a whole 32x32 tile so the loads overlap) and a STORE half.
+template <typename T, int EPI>
+struct EpilogueOp {
+  static constexpr bool kAccurate = sizeof(T) == 4;
+  __device__ __forceinline__ static float4 load(const GemmParams& p, int m, int n0) {
+    if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_QGELU) {
+      return *reinterpret_cast<const float4*>(p.bias + n0);
+    } else if constexpr (EPI == EPI_BIAS_RESID) {
+      const float4 b = *reinterpret_cast<const float4*>(p.bias + n0);
+      const float4 r = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.C) + (size_t)m * p.ldc + n0);
+      return make_float4(r.x + b.x, r.y + b.y, r.z + b.z, r.w + b.w);
+    } else if constexpr (EPI == EPI_PATCH) {
+      const int img = m / p.np, pp = m - img * p.np;
+      return *reinterpret_cast<const float4*>(p.bias + (size_t)(1 + pp) * p.N + n0);
+    } else {
+      return make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  // 4 consecutive columns n0..n0+3 of output row m
+  __device__ __forceinline__ static void store(const GemmParams& p, int m, int n0, float v0, float v1, float v2,
+                                               float v3, const float4 add) {
+    if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_QGELU) {
+      v0 += add.x; v1 += add.y; v2 += add.z; v3 += add.w;
+      if constexpr (EPI == EPI_BIAS_QGELU) {
+        v0 = quick_gelu<kAccurate>(v0); v1 = quick_gelu<kAccurate>(v1);
+        v2 = quick_gelu<kAccurate>(v2); v3 = quick_gelu<kAccurate>(v3);
+      }
+      store4(reinterpret_cast<T*>(p.C) + (size_t)m * p.ldc + n0, v0, v1, v2, v3);
+    } else if constexpr (EPI == EPI_BIAS_RESID) {
+      store4(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n0, add.x + v0, add.y + v1, add.z + v2, add.w + v3);
+    } else if constexpr (EPI == EPI_SCALE) {
+      store4(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n0, p.alpha * v0, p.alpha * v1, p.alpha * v2,
+             p.alpha * v3);
+    } else {  // EPI_PATCH: patch row m = img*np + pp goes to token row img*(np+1) + 1 + pp
+      const int img = m / p.np, pp = m - img * p.np;
+      float* c = reinterpret_cast<float*>(p.C) + ((size_t)img * (p.np + 1) + 1 + pp) * p.ldc + n0;
+      store4(c, v0 + add.x, v1 + add.y, v2 + add.z, v3 + add.w);
+    }
+  }
+};
+
+// BM x BN block tile, WM x WN waves, each wave a (BM/WM) x (BN/WN) sub-tile of 32x32 MFMA tiles.
+template <typename T, int BM, int BN, int WM, int WN, int EPI, bool GLDS>
+__global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))  // LDS caps residency at 2 waves/SIMD:
+void gemm_nt_kernel(const GemmParams p) {                                            // let the allocator use 256 VGPRs
+  constexpr int NT = WM * WN * 64;
+  constexpr int TM = BM / WM, TN = BN / WN;
+  constexpr int MI = TM / 32, NI = TN / 32;
+  constexpr int ELEMS16 = 16 / sizeof(T);  // elements per 16-byte chunk
+  constexpr int BK = 8 * ELEMS16;          // 128-byte rows
+  constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, STAGE = A_BYTES + W_BYTES;
+  constexpr int PA = BM * 8 / NT, PW = BN * 8 / NT;  // 16-byte chunks per thread per tile
+  static_assert(TM % 32 == 0 && TN % 32 == 0, "wave tile must be a multiple of the 32x32 MFMA tile");
+  static_assert((BM * 8) % NT == 0 && (BN * 8) % NT == 0, "staging passes must be whole");
+  static_assert((NT / 8) % 16 == 0, "swizzle term must not depend on the staging pass");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+
+  // ---- XCD-aware tile assignment (bijective for any block count) -------------
+  const int nbn = p.N / BN;
+  const int nbm = (p.M + BM - 1) / BM;
+  const int nblk = nbm * nbn;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, xi = bid >> 3, xq = nblk >> 3, xr = nblk & 7;
+  const int lid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + xi;
+  const int m0 = (lid / nbn) * BM, n0 = (lid % nbn) * BN;
+
+  // ---- staging addresses --------------------------------------------------
+  // thread -> LDS chunk position q = pass*NT + tid: row = q>>3, slot = q&7, and the
+  // K chunk that belongs in that slot is slot ^ ((row>>1)&7) (pass-independent).
+  const int srow = tid >> 3;
+  const int schunk = (tid & 7) ^ ((srow >> 1) & 7);
+  const char* a_src[PA];
+  const char* w_src[PW];
+#pragma unroll
+  for (int i = 0; i < PA; ++i) {
+    int r = m0 + i * (NT / 8) + srow;
+    r = r < p.M ? r : p.M - 1;  // M edge: re-read the last row, stores are masked
+    a_src[i] = reinterpret_cast<const char*>(p.A) + ((size_t)r * p.lda + schunk * ELEMS16) * sizeof(T);
+  }
+#pragma unroll
+  for (int i = 0; i < PW; ++i) {
+    const int r = n0 + i * (NT / 8) + srow;
+    w_src[i] = reinterpret_cast<const char*>(p.W) + ((size_t)r * p.ldw + schunk * ELEMS16) * sizeof(T);
+  }
+  const unsigned lds0 =
+      __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem);
+
+  u32x4 ra[GLDS ? 1 : PA], rw[GLDS ? 1 : PW];
+
+  auto stage_issue = [&](int buf) {  // reads a_src/w_src, then advances them by one K tile
+    if constexpr (GLDS) {
+      const unsigned base = lds0 + buf * STAGE + wave * 1024;
+#pragma unroll
+      for (int i = 0; i < PA; ++i) glds16(a_src[i], base + i * NT * 16);
+#pragma unroll
+      for (int i = 0; i < PW; ++i) glds16(w_src[i], base + A_BYTES + i * NT * 16);
+    } else {
+#pragma unroll
+      for (int i = 0; i < PA; ++i) ra[i] = *reinterpret_cast<const u32x4*>(a_src[i]);
+#pragma unroll
+      for (int i = 0; i < PW; ++i) rw[i] = *reinterpret_cast<const u32x4*>(w_src[i]);
+      // keep the loads HERE (ahead of the MFMA block); left alone, the scheduler sinks them next to
+      // the ds_writes that consume them and the prefetch distance collapses.
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int i = 0; i < PA; ++i) a_src[i] += 128;
+#pragma unroll
+    for (int i = 0; i < PW; ++i) w_src[i] += 128;
+  };
+  auto stage_commit = [&](int buf) {  // make the staged tile visible in LDS buffer `buf`
+    if constexpr (GLDS) {
+      wait_vm0();
+    } else {
+      char* base = smem + buf * STAGE;
+#pragma unroll
+      for (int i = 0; i < PA; ++i) *reinterpret_cast<u32x4*>(base + (i * NT + tid) * 16) = ra[i];
+#pragma unroll
+      for (int i = 0; i < PW; ++i) *reinterpret_cast<u32x4*>(base + A_BYTES + (i * NT + tid) * 16) = rw[i];
+    }
+  };
+
+  // ---- fragment read offsets (lane-constant) -----------------------------------
+  const int lrow = lane & 31, lgrp = lane >> 5;
+  const int lsw = (lrow >> 1) & 7;
+  int foff[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) foff[ks] = lrow * 128 + (((ks * 2 + lgrp) ^ lsw) << 4);
+  const int a_tile = wm * TM * 128;
+  const int w_tile = A_BYTES + wn * TN * 128;
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  auto compute = [&](int buf) {
+    const char* sb = smem + buf * STAGE;
+    // fragments of K-step ks+1 are fetched from LDS before the MFMAs of step ks issue
+    u32x4 xf[2][MI], wf[2][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) xf[0][i] = *reinterpret_cast<const u32x4*>(sb + a_tile + i * 32 * 128 + foff[0]);
+#pragma unroll
+    for (int j = 0; j < NI; ++j) wf[0][j] = *reinterpret_cast<const u32x4*>(sb + w_tile + j * 32 * 128 + foff[0]);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      if (ks < 3) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+          xf[(ks + 1) & 1][i] = *reinterpret_cast<const u32x4*>(sb + a_tile + i * 32 * 128 + foff[ks + 1]);
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+          wf[(ks + 1) & 1][j] = *reinterpret_cast<const u32x4*>(sb + w_tile + j * 32 * 128 + foff[ks + 1]);
+      }
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) mma16<T>(acc[i][j], wf[ks & 1][j], xf[ks & 1][i]);
+    }
+  };
+
+  // ---- main loop: tile kt+1 streams in while tile kt is multiplied; one barrier per tile.
+  const int KT = p.K / BK;
+  stage_issue(0);
+  stage_commit(0);
+  __syncthreads();
+  for (int kt = 0; kt < KT - 1; ++kt) {
+    const int cur = kt & 1;
+    stage_issue(cur ^ 1);
+    compute(cur);
+    stage_commit(cur ^ 1);
+    __syncthreads();
+  }
+  compute((KT - 1) & 1);
+
+  // ---- epilogue: acc[i][j][4q+e] = C[m = .. + lrow][n = .. + 8q + 4*lgrp + e] ----
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int m = m0 + wm * TM + i * 32 + lrow;
+    if (m < p.M) {
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int nb = n0 + wn * TN + j * 32 + 4 * lgrp;
+        float4 add[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) add[q] = EpilogueOp<T, EPI>::load(p, m, nb + 8 * q);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          EpilogueOp<T, EPI>::store(p, m, nb + 8 * q, acc[i][j][4 * q + 0], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2],
+                                    acc[i][j][4 * q + 3], add[q]);
+      }
+    }
+  }
+}
+
+// One thread per output element; the on-device checker for the MFMA kernels
+// (tests and PLIPMI_NAIVE_GEMM=1), never used on the product path by default.
+template <typename T, int EPI>
+__global__ void gemm_nt_naive_kernel(const GemmParams p) {
+  const int n4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  const int m = blockIdx.y;
+  if (n4 >= p.N || m >= p.M) return;
+  const T* a = reinterpret_cast<const T*>(p.A) + (size_t)m * p.lda;
+  float v[4];
+  for (int e = 0; e < 4; ++e) {
+    const T* w = reinterpret_cast<const T*>(p.W) + (size_t)(n4 + e) * p.ldw;
+    float s = 0.f;
+    for (int k = 0; k < p.K; ++k) s = fmaf(to_f32(a[k]), to_f32(w[k]), s);
+    v[e] = s;
+  }
+  EpilogueOp<T, EPI>::store(p, m, n4, v[0], v[1], v[2], v[3], EpilogueOp<T, EPI>::load(p, m, n4));
+}
+
+// ---- host side ----------------------------------------------------------------
+struct GemmVariant {
+  const char* name;
+  int bm, bn, threads;
+  bool glds;
+};
+int gemm_num_variants();
+const GemmVariant& gemm_variant(int v);
+// dtype: 0 fp32, 1 bf16.  variant -1 = auto, -2 = naive.  Returns hipError_t as int; *kernel_name (optional)
+// receives a static string naming the kernel that ran.
+int gemm_launch(int dtype, int epi, int variant, const GemmParams& p, hipStream_t stream, const char** kernel_name);
+int gemm_default_variant(int dtype, int M, int N, int K);
+void gemm_set_default_override(int variant);  // PLIPMI_GEMM_VARIANT / tests
+
+}  // namespace plipmi

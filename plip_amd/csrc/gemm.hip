@@ -1,0 +1,60 @@
+// gemm.hip -- variant registry and dispatch for the NT GEMM (kernels live in gemm.h).
+#include <stdlib.h>
+
+#include "gemm_inst.h"
+
+namespace plipmi {
+
+static const GemmVariant kVariants[kNumVariants] = {
+    {"128x128_w2x2_regstage", 128, 128, 256, false}, {"128x128_w2x2_glds", 128, 128, 256, true},
+    {"256x128_w4x2_regstage", 256, 128, 512, false}, {"256x128_w4x2_glds", 256, 128, 512, true},
+    {"256x256_w4x2_regstage", 256, 256, 512, false}, {"256x256_w4x2_glds", 256, 256, 512, true},
+};
+
+int gemm_num_variants() { return kNumVariants; }
+const GemmVariant& gemm_variant(int v) { return kVariants[v]; }
+
+static int g_override = -100;  // -100 = not yet read
+void gemm_set_default_override(int variant) { g_override = variant; }
+
+int gemm_default_variant(int dtype, int M, int N, int K) {
+  if (g_override == -100) {
+    const char* e = getenv("PLIPMI_GEMM_VARIANT");
+    g_override = e ? atoi(e) : -1;
+  }
+  if (g_override >= 0 || g_override == -2) {
+    if (g_override >= 0 && N % kVariants[g_override].bn != 0) return 1;
+    return g_override;
+  }
+  (void)dtype; (void)M; (void)K;
+  // Round-1 default: the 128x128 LDS-DMA tile (2 blocks/CU); re-tuned from bench data.
+  return 1;
+}
+
+static const char* kEpiNames[EPI_COUNT] = {"bias", "bias_qgelu", "bias_resid", "scale", "patch"};
+
+int gemm_launch(int dtype, int epi, int variant, const GemmParams& p, hipStream_t stream, const char** kernel_name) {
+  if (variant == -1) variant = gemm_default_variant(dtype, p.M, p.N, p.K);
+  if (p.M <= 0) return 0;
+  const int bk = dtype == 1 ? 64 : 32;
+  if (variant >= 0) {
+    if (variant >= kNumVariants) return (int)hipErrorInvalidValue;
+    if (p.N % kVariants[variant].bn != 0 || p.K % bk != 0) return (int)hipErrorInvalidValue;
+  } else if (p.N % 4 != 0) {
+    return (int)hipErrorInvalidValue;
+  }
+  GemmLaunchFn fn = dtype == 1 ? gemm_get_bf16(variant, epi) : gemm_get_f32(variant, epi);
+  if (!fn) return (int)hipErrorInvalidValue;
+  if (kernel_name) {
+    // static table of names: "gemm_nt<dtype,tile,epi>"
+    static char names[2][kNumVariants + 1][EPI_COUNT][64];
+    char* nm = names[dtype][variant < 0 ? kNumVariants : variant][epi];
+    if (!nm[0])
+      snprintf(nm, 64, "gemm_nt<%s,%s,%s>", dtype == 1 ? "bf16" : "f32", variant < 0 ? "naive" : kVariants[variant].name,
+               kEpiNames[epi]);
+    *kernel_name = nm;
+  }
+  return fn(p, stream);
+}
+
+}  // namespace plipmi

@@ -1,0 +1,66 @@
+// gemm_inst.h -- per-dtype instantiation table of gemm_nt_kernel (included by gemm_f32.hip / gemm_bf16.hip
+// so the two halves compile in parallel).
+#pragma once
+#include "gemm.h"
+
+namespace plipmi {
+
+typedef int (*GemmLaunchFn)(const GemmParams&, hipStream_t);
+
+template <typename T, int BM, int BN, int WM, int WN, int EPI, bool GLDS>
+int launch_tiled(const GemmParams& p, hipStream_t stream) {
+  constexpr int NT = WM * WN * 64;
+  constexpr int LDS = 2 * (BM + BN) * 128;
+  auto kern = gemm_nt_kernel<T, BM, BN, WM, WN, EPI, GLDS>;
+  static bool attr_set = false;  // one handle per process; set once per instantiation
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  const int nblk = ((p.M + BM - 1) / BM) * (p.N / BN);
+  hipLaunchKernelGGL(kern, dim3(nblk), dim3(NT), LDS, stream, p);
+  return (int)hipGetLastError();
+}
+
+template <typename T, int EPI>
+int launch_naive(const GemmParams& p, hipStream_t stream) {
+  dim3 grid((p.N / 4 + 63) / 64, p.M);
+  hipLaunchKernelGGL((gemm_nt_naive_kernel<T, EPI>), grid, dim3(64), 0, stream, p);
+  return (int)hipGetLastError();
+}
+
+constexpr int kNumVariants = 6;
+
+// table[variant][epilogue]
+template <typename T>
+struct GemmTable {
+  template <int EPI>
+  static GemmLaunchFn pick(int variant) {
+    switch (variant) {
+      case 0: return launch_tiled<T, 128, 128, 2, 2, EPI, false>;
+      case 1: return launch_tiled<T, 128, 128, 2, 2, EPI, true>;
+      case 2: return launch_tiled<T, 256, 128, 4, 2, EPI, false>;
+      case 3: return launch_tiled<T, 256, 128, 4, 2, EPI, true>;
+      case 4: return launch_tiled<T, 256, 256, 4, 2, EPI, false>;
+      case 5: return launch_tiled<T, 256, 256, 4, 2, EPI, true>;
+      case -2: return launch_naive<T, EPI>;
+      default: return nullptr;
+    }
+  }
+  static GemmLaunchFn get(int variant, int epi) {
+    switch (epi) {
+      case EPI_BIAS: return pick<EPI_BIAS>(variant);
+      case EPI_BIAS_QGELU: return pick<EPI_BIAS_QGELU>(variant);
+      case EPI_BIAS_RESID: return pick<EPI_BIAS_RESID>(variant);
+      case EPI_SCALE: return pick<EPI_SCALE>(variant);
+      case EPI_PATCH: return pick<EPI_PATCH>(variant);
+      default: return nullptr;
+    }
+  }
+};
+
+GemmLaunchFn gemm_get_f32(int variant, int epi);
+GemmLaunchFn gemm_get_bf16(int variant, int epi);
+
+}  // namespace plipmi

@@ -1,0 +1,52 @@
+// kernels.h -- launchers of the HBM-bound kernels around the GEMMs (definitions in kernels.hip / attention.hip).
+#pragma once
+#include "common.h"
+
+namespace plipmi {
+
+// dtype codes used by the launchers: 0 = fp32, 1 = bf16 (same as PLIPMI_F32 / PLIPMI_BF16)
+
+// y[r,:] = LayerNorm(x[r*x_row_stride : +D]) * g + b ; y is fp32 or bf16, contiguous [rows, D].
+// One wavefront per row, statistics in fp32 (two-pass, values held in registers).
+hipError_t launch_layernorm(const float* x, size_t x_row_stride, const float* g, const float* b, void* y, int y_dtype,
+                            int rows, int D, float eps, hipStream_t s);
+
+// pixels fp32 [B,3,H,W] -> patch rows [B*np, Kpad] (dtype), column (c,u,v), zero padded to Kpad.
+hipError_t launch_unfold_patches(const float* pixels, void* out, int out_dtype, int B, int image, int patch, int Kpad,
+                                 hipStream_t s);
+
+// x[b,0,:] = class_embedding + pos[0,:]   (token rows 1.. are written by the patch GEMM epilogue)
+hipError_t launch_cls_rows(const float* cls, const float* pos, float* x, int B, int tokens, int D, hipStream_t s);
+
+// x[b,s,:] = tok[ids[b,s],:] + pos[s,:]   (ids clamped to [0,vocab) -- the host validates them)
+hipError_t launch_text_embed(const int64_t* ids, const float* tok, const float* pos, float* x, int B, int S, int D,
+                             int vocab, hipStream_t s);
+
+// Pooled head: row = CLS (ids == nullptr) or the EOS row of each caption, then
+// LayerNorm -> bias-free projection (Wt is the projection TRANSPOSED: [D, P]) -> optional L2 normalise.
+hipError_t launch_pool_head(const float* x, int S, int D, const int64_t* ids, int eos_id, const float* ln_w,
+                            const float* ln_b, float eps, const float* Wt, int P, float* out, int B, int normalize,
+                            hipStream_t s);
+
+hipError_t launch_l2_normalize(float* x, int N, int D, hipStream_t s);
+
+// logits_per_image[i,j] = scale*<img_i,txt_j>; optional transpose output and per-row first arg-max.
+hipError_t launch_logits(const float* img, int Ni, const float* txt, int Nt, int D, float scale, float* lpi,
+                         float* lpt, int32_t* argmax, hipStream_t s);
+
+hipError_t launch_topk(const float* scores, int N, int M, int k, int64_t* idx, hipStream_t s);
+
+// dst[r, 0:cols] = (T)(scale * src[r, 0:cols]), dst[r, cols:dst_ld] = 0   (weight packing)
+hipError_t launch_convert(const float* src, void* dst, int dst_dtype, int rows, int cols, int dst_ld, float scale,
+                          hipStream_t s);
+// dst[c, r] = src[r, c]   fp32 (projection weights -> [D, P])
+hipError_t launch_transpose(const float* src, float* dst, int rows, int cols, hipStream_t s);
+hipError_t launch_scale_copy(const float* src, float* dst, int n, float scale, hipStream_t s);
+
+// Multi-head attention over the fused qkv buffer [B*S, 3*D] (q | k | v, head h at columns h*64..), the 1/sqrt(64)
+// scale already folded into q.  out [B*S, D].  causal: key j <= query i.  key_mask: int64 [B,S] or nullptr.
+//   impl 0 = exact fp32 VALU kernel (any dtype), 1 = bf16 MFMA kernel (dtype must be bf16)
+hipError_t launch_attention(const void* qkv, void* out, int dtype, int B, int S, int H, int causal,
+                            const int64_t* key_mask, int impl, hipStream_t s);
+
+}  // namespace plipmi

@@ -1,0 +1,454 @@
+// kernels.hip -- the HBM-bound kernels around the GEMMs: LayerNorm, patch unfold,
+// embeddings, pooled projection head, L2 normalise, logits, top-k, weight packing.
+// All are wavefront(64)-shaped: one wave per row for row reductions (shuffle/DPP
+// reductions, no LDS), 16-byte accesses per lane, fp32 statistics.
+#include <limits.h>
+
+#include "kernels.h"
+
+namespace plipmi {
+
+// ---------------------------------------------------------------------------------
+// LayerNorm (nn.LayerNorm, biased variance; modeling_clip.py:358,360,559,605,608)
+// ---------------------------------------------------------------------------------
+constexpr int kLnMaxVec = 8;  // float4 per lane -> D <= 2048
+
+template <typename TOut>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, size_t xs,
+                                                        const float* __restrict__ g, const float* __restrict__ b,
+                                                        TOut* __restrict__ y, int rows, int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + (size_t)row * xs;
+  float4 v[kLnMaxVec];
+  float s = 0.f;
+#pragma unroll
+  for (int it = 0; it < kLnMaxVec; ++it) {
+    const int idx = it * 256 + lane * 4;
+    if (idx < D) {
+      v[it] = *reinterpret_cast<const float4*>(xr + idx);
+      s += (v[it].x + v[it].y) + (v[it].z + v[it].w);
+    }
+  }
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int it = 0; it < kLnMaxVec; ++it) {
+    const int idx = it * 256 + lane * 4;
+    if (idx < D) {
+      const float a = v[it].x - mean, c = v[it].y - mean, d = v[it].z - mean, e = v[it].w - mean;
+      q += (a * a + c * c) + (d * d + e * e);
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+  TOut* yr = y + (size_t)row * D;
+#pragma unroll
+  for (int it = 0; it < kLnMaxVec; ++it) {
+    const int idx = it * 256 + lane * 4;
+    if (idx < D) {
+      const float4 gg = *reinterpret_cast<const float4*>(g + idx);
+      const float4 bb = *reinterpret_cast<const float4*>(b + idx);
+      store4(yr + idx, (v[it].x - mean) * rstd * gg.x + bb.x, (v[it].y - mean) * rstd * gg.y + bb.y,
+             (v[it].z - mean) * rstd * gg.z + bb.z, (v[it].w - mean) * rstd * gg.w + bb.w);
+    }
+  }
+}
+
+hipError_t launch_layernorm(const float* x, size_t xs, const float* g, const float* b, void* y, int y_dtype, int rows,
+                            int D, float eps, hipStream_t s) {
+  if (rows <= 0) return hipSuccess;
+  if (D % 4 || D > kLnMaxVec * 256) return hipErrorInvalidValue;
+  const dim3 grid((rows + 3) / 4), block(256);
+  if (y_dtype == 1)
+    hipLaunchKernelGGL(layernorm_kernel<bf16_t>, grid, block, 0, s, x, xs, g, b, (bf16_t*)y, rows, D, eps);
+  else
+    hipLaunchKernelGGL(layernorm_kernel<float>, grid, block, 0, s, x, xs, g, b, (float*)y, rows, D, eps);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------
+// Patch unfold: Conv2d(kernel = stride = P) is a pure re-index (modeling_clip.py:148-154,
+// 209-210): row (img, gi, gj), column (c, u, v) -- the order of conv.weight.reshape(out,-1).
+// ---------------------------------------------------------------------------------
+template <typename TOut, bool kVec>
+__global__ __launch_bounds__(256) void unfold_kernel(const float* __restrict__ px, TOut* __restrict__ out, int image,
+                                                     int P, int K, int Kpad) {
+  const int g = image / P;
+  const int row = blockIdx.x;  // img*g*g + gi*g + gj
+  const int img = row / (g * g), cell = row - img * g * g, gi = cell / g, gj = cell - gi * g;
+  const float* base = px + (size_t)img * 3 * image * image + (size_t)(gi * P) * image + gj * P;
+  TOut* orow = out + (size_t)row * Kpad;
+  for (int k = threadIdx.x * 4; k < Kpad; k += 256 * 4) {
+    float r[4];
+    if constexpr (kVec) {  // P % 4 == 0: the 4 columns are 4 consecutive pixels of one image row
+      if (k < K) {
+        const int c = k / (P * P), rem = k - c * P * P, u = rem / P, v = rem - u * P;
+        const float4 t = *reinterpret_cast<const float4*>(base + (size_t)c * image * image + (size_t)u * image + v);
+        r[0] = t.x; r[1] = t.y; r[2] = t.z; r[3] = t.w;
+      } else {
+        r[0] = r[1] = r[2] = r[3] = 0.f;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int kk = k + e;
+        if (kk < K) {
+          const int c = kk / (P * P), rem = kk - c * P * P, u = rem / P, v = rem - u * P;
+          r[e] = base[(size_t)c * image * image + (size_t)u * image + v];
+        } else {
+          r[e] = 0.f;
+        }
+      }
+    }
+    store4(orow + k, r[0], r[1], r[2], r[3]);
+  }
+}
+
+hipError_t launch_unfold_patches(const float* pixels, void* out, int out_dtype, int B, int image, int patch, int Kpad,
+                                 hipStream_t s) {
+  if (B <= 0) return hipSuccess;
+  const int g = image / patch, K = 3 * patch * patch;
+  const dim3 grid(B * g * g), block(256);
+  const bool vec = (patch % 4 == 0) && (image % 4 == 0);
+#define PLIPMI_UNFOLD(T, V) \
+  hipLaunchKernelGGL((unfold_kernel<T, V>), grid, block, 0, s, pixels, (T*)out, image, patch, K, Kpad)
+  if (out_dtype == 1) { if (vec) PLIPMI_UNFOLD(bf16_t, true); else PLIPMI_UNFOLD(bf16_t, false); }
+  else                { if (vec) PLIPMI_UNFOLD(float, true);  else PLIPMI_UNFOLD(float, false); }
+#undef PLIPMI_UNFOLD
+  return hipGetLastError();
+}
+
+// x[b,0,:] = class_embedding + position_embedding[0]   (modeling_clip.py:212-217)
+__global__ void cls_rows_kernel(const float* __restrict__ cls, const float* __restrict__ pos, float* __restrict__ x,
+                                int tokens, int D) {
+  float* xr = x + (size_t)blockIdx.x * tokens * D;
+  for (int i = threadIdx.x * 4; i < D; i += blockDim.x * 4) {
+    const float4 a = *reinterpret_cast<const float4*>(cls + i), p = *reinterpret_cast<const float4*>(pos + i);
+    store4(xr + i, a.x + p.x, a.y + p.y, a.z + p.z, a.w + p.w);
+  }
+}
+hipError_t launch_cls_rows(const float* cls, const float* pos, float* x, int B, int tokens, int D, hipStream_t s) {
+  if (B <= 0) return hipSuccess;
+  hipLaunchKernelGGL(cls_rows_kernel, dim3(B), dim3(256), 0, s, cls, pos, x, tokens, D);
+  return hipGetLastError();
+}
+
+// x[b,s,:] = token_embedding[ids[b,s]] + position_embedding[s]   (modeling_clip.py:251-254)
+__global__ void text_embed_kernel(const int64_t* __restrict__ ids, const float* __restrict__ tok,
+                                  const float* __restrict__ pos, float* __restrict__ x, int S, int D, int vocab) {
+  const int row = blockIdx.x;
+  long long id = ids[row];
+  id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+  const float* t = tok + (size_t)id * D;
+  const float* p = pos + (size_t)(row % S) * D;
+  float* xr = x + (size_t)row * D;
+  for (int i = threadIdx.x * 4; i < D; i += blockDim.x * 4) {
+    const float4 a = *reinterpret_cast<const float4*>(t + i), b = *reinterpret_cast<const float4*>(p + i);
+    store4(xr + i, a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+  }
+}
+hipError_t launch_text_embed(const int64_t* ids, const float* tok, const float* pos, float* x, int B, int S, int D,
+                             int vocab, hipStream_t s) {
+  if (B <= 0) return hipSuccess;
+  hipLaunchKernelGGL(text_embed_kernel, dim3(B * S), dim3(128), 0, s, ids, tok, pos, x, S, D, vocab);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------
+// Pooled head.  Vision: CLS row -> post_layernorm -> visual_projection (modeling_clip.py:650-651,751).
+// Text: the reference applies final_layer_norm to all S rows and then picks the EOS
+// row (:559-581); LayerNorm is row-wise, so picking first is exact and 77x cheaper.
+// ---------------------------------------------------------------------------------
+constexpr int kHeadMaxD = 2048, kHeadMaxOut = 4;  // P <= 1024
+
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void pool_head_kernel(const float* __restrict__ x, int S, int D,
+                                                        const int64_t* __restrict__ ids, int eos_id,
+                                                        const float* __restrict__ ln_w, const float* __restrict__ ln_b,
+                                                        float eps, const float* __restrict__ Wt, int P,
+                                                        float* __restrict__ out, int normalize) {
+  __shared__ float xn[kHeadMaxD];
+  __shared__ float red[4];
+  __shared__ int pos_s;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (tid < 64) {
+    int pos = 0;
+    if (ids != nullptr) {
+      const int64_t* row = ids + (size_t)b * S;
+      if (eos_id >= 0 && eos_id != 2) {  // first position holding eos_token_id, 0 if absent
+        int best = INT_MAX;
+        for (int s = tid; s < S; s += 64)
+          if ((int)row[s] == eos_id) best = min(best, s);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) best = min(best, __shfl_xor(best, o, 64));
+        pos = best == INT_MAX ? 0 : best;
+      } else {  // legacy rule: first arg-max of the ids (ids.to(int).argmax)
+        int mx = INT_MIN;
+        for (int s = tid; s < S; s += 64) mx = max(mx, (int)row[s]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o, 64));
+        int best = INT_MAX;
+        for (int s = tid; s < S; s += 64)
+          if ((int)row[s] == mx) best = min(best, s);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) best = min(best, __shfl_xor(best, o, 64));
+        pos = best;
+      }
+    }
+    if (tid == 0) pos_s = pos;
+  }
+  __syncthreads();
+  const float* xr = x + ((size_t)b * S + pos_s) * D;
+  float s = 0.f;
+  for (int i = tid; i < D; i += 256) { const float v = xr[i]; xn[i] = v; s += v; }
+  const float mean = block_sum_256(s, red) / (float)D;
+  float q = 0.f;
+  for (int i = tid; i < D; i += 256) { const float d = xn[i] - mean; q += d * d; }
+  const float rstd = 1.0f / sqrtf(block_sum_256(q, red) / (float)D + eps);
+  for (int i = tid; i < D; i += 256) xn[i] = (xn[i] - mean) * rstd * ln_w[i] + ln_b[i];
+  __syncthreads();
+  float o[kHeadMaxOut];
+#pragma unroll
+  for (int r = 0; r < kHeadMaxOut; ++r) o[r] = 0.f;
+  for (int k = 0; k < D; ++k) {
+    const float xv = xn[k];
+    const float* wr = Wt + (size_t)k * P;
+#pragma unroll
+    for (int r = 0; r < kHeadMaxOut; ++r) {
+      const int j = tid + r * 256;
+      if (j < P) o[r] = fmaf(xv, wr[j], o[r]);
+    }
+  }
+  float scale = 1.f;
+  if (normalize) {
+    float ss = 0.f;
+#pragma unroll
+    for (int r = 0; r < kHeadMaxOut; ++r) ss += (tid + r * 256 < P) ? o[r] * o[r] : 0.f;
+    scale = 1.0f / sqrtf(block_sum_256(ss, red));
+  }
+#pragma unroll
+  for (int r = 0; r < kHeadMaxOut; ++r) {
+    const int j = tid + r * 256;
+    if (j < P) out[(size_t)b * P + j] = normalize ? o[r] * scale : o[r];
+  }
+}
+
+hipError_t launch_pool_head(const float* x, int S, int D, const int64_t* ids, int eos_id, const float* ln_w,
+                            const float* ln_b, float eps, const float* Wt, int P, float* out, int B, int normalize,
+                            hipStream_t s) {
+  if (B <= 0) return hipSuccess;
+  if (D > kHeadMaxD || P > kHeadMaxOut * 256) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(pool_head_kernel, dim3(B), dim3(256), 0, s, x, S, D, ids, eos_id, ln_w, ln_b, eps, Wt, P, out,
+                     normalize);
+  return hipGetLastError();
+}
+
+// x / sqrt(sum x^2), no epsilon (modeling_clip.py:57-65; plip.py:75)
+__global__ __launch_bounds__(256) void l2_normalize_kernel(float* __restrict__ x, int N, int D) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= N) return;
+  float* xr = x + (size_t)row * D;
+  float ss = 0.f;
+  for (int i = lane; i < D; i += 64) ss += xr[i] * xr[i];
+  const float scale = 1.0f / sqrtf(wave_sum(ss));
+  for (int i = lane; i < D; i += 64) xr[i] *= scale;
+}
+hipError_t launch_l2_normalize(float* x, int N, int D, hipStream_t s) {
+  if (N <= 0) return hipSuccess;
+  hipLaunchKernelGGL(l2_normalize_kernel, dim3((N + 3) / 4), dim3(256), 0, s, x, N, D);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------
+// Logits: logits_per_image = scale * img @ txt^T (modeling_clip.py:814-817), fp32 FMA.
+// 64x64 tile per 256-thread block, 4x4 outputs per thread, K staged through LDS in
+// chunks of 16.  Any Ni / Nt (zero-shot uses Nt = number of class prompts).
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void logits_kernel(const float* __restrict__ A, int Ni, const float* __restrict__ Bm,
+                                                     int Nt, int D, float scale, float* __restrict__ lpi,
+                                                     float* __restrict__ lpt) {
+  __shared__ float As[16][68];
+  __shared__ float Bs[16][68];
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  const int i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
+  float acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[a][c] = 0.f;
+  const int lr = tid >> 2, lk = (tid & 3) * 4;  // each thread stages 4 consecutive k of one row
+  for (int k0 = 0; k0 < D; k0 += 16) {
+    float av[4] = {0.f, 0.f, 0.f, 0.f}, bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (i0 + lr < Ni)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) if (k0 + lk + e < D) av[e] = A[(size_t)(i0 + lr) * D + k0 + lk + e];
+    if (j0 + lr < Nt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) if (k0 + lk + e < D) bv[e] = Bm[(size_t)(j0 + lr) * D + k0 + lk + e];
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { As[lk + e][lr] = av[e]; Bs[lk + e][lr] = bv[e]; }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      float a[4], b[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { a[e] = As[k][ty * 4 + e]; b[e] = Bs[k][tx * 4 + e]; }
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[r][c] = fmaf(a[r], b[c], acc[r][c]);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = i0 + ty * 4 + r;
+    if (i >= Ni) continue;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int j = j0 + tx * 4 + c;
+      if (j >= Nt) continue;
+      const float v = acc[r][c] * scale;
+      lpi[(size_t)i * Nt + j] = v;
+      if (lpt) lpt[(size_t)j * Ni + i] = v;
+    }
+  }
+}
+
+// first arg-max of each row (np.argmax / torch.argmax semantics for ties)
+__global__ __launch_bounds__(256) void row_argmax_kernel(const float* __restrict__ x, int N, int M,
+                                                         int32_t* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= N) return;
+  const float* xr = x + (size_t)row * M;
+  float best = -INFINITY;
+  int bi = INT_MAX;
+  for (int j = lane; j < M; j += 64) {
+    const float v = xr[j];
+    if (v > best || bi == INT_MAX) { best = v; bi = j; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (oi != INT_MAX && (bi == INT_MAX || ov > best || (ov == best && oi < bi))) { best = ov; bi = oi; }
+  }
+  if (lane == 0) out[row] = bi == INT_MAX ? 0 : bi;
+}
+
+hipError_t launch_logits(const float* img, int Ni, const float* txt, int Nt, int D, float scale, float* lpi,
+                         float* lpt, int32_t* argmax, hipStream_t s) {
+  if (Ni <= 0 || Nt <= 0) return hipSuccess;
+  hipLaunchKernelGGL(logits_kernel, dim3((Nt + 63) / 64, (Ni + 63) / 64), dim3(256), 0, s, img, Ni, txt, Nt, D, scale,
+                     lpi, lpt);
+  if (argmax) hipLaunchKernelGGL(row_argmax_kernel, dim3((Ni + 3) / 4), dim3(256), 0, s, lpi, Ni, Nt, argmax);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------
+// top-k per row, descending, ties -> lower index (replaces argsort()[:, -k:][:, ::-1],
+// plip.py:84; retrieval.py:17).  k selection passes, each a block-wide arg-max over
+// the keys strictly after the previous pick in (value desc, index asc) order.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ x, int M, int k, int64_t* __restrict__ out) {
+  __shared__ float rv[4];
+  __shared__ int ri[4];
+  const float* xr = x + (size_t)blockIdx.x * M;
+  float pv = INFINITY;
+  int pi = -1;
+  for (int t = 0; t < k; ++t) {
+    float best = -INFINITY;
+    int bi = INT_MAX;
+    for (int j = threadIdx.x; j < M; j += 256) {
+      float v = xr[j];
+      if (!(v == v)) v = -INFINITY;  // NaN sorts last
+      const bool after = (v < pv) || (v == pv && j > pi);
+      if (after && (v > best || (v == best && j < bi))) { best = v; bi = j; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(best, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { rv[threadIdx.x >> 6] = best; ri[threadIdx.x >> 6] = bi; }
+    __syncthreads();
+    best = rv[0]; bi = ri[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w)
+      if (rv[w] > best || (rv[w] == best && ri[w] < bi)) { best = rv[w]; bi = ri[w]; }
+    if (threadIdx.x == 0) out[(size_t)blockIdx.x * k + t] = bi == INT_MAX ? -1 : bi;
+    pv = best; pi = bi;
+  }
+}
+hipError_t launch_topk(const float* scores, int N, int M, int k, int64_t* idx, hipStream_t s) {
+  if (N <= 0 || k <= 0) return hipSuccess;
+  if (k > M) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(topk_kernel, dim3(N), dim3(256), 0, s, scores, M, k, idx);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------
+// weight packing (plipmi_create)
+// ---------------------------------------------------------------------------------
+template <typename T>
+__global__ void convert_kernel(const float* __restrict__ src, T* __restrict__ dst, int rows, int cols, int dst_ld,
+                               float scale) {
+  const size_t n = (size_t)rows * dst_ld;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / dst_ld), c = (int)(i - (size_t)r * dst_ld);
+    dst[i] = from_f32<T>(c < cols ? src[(size_t)r * cols + c] * scale : 0.f);
+  }
+}
+hipError_t launch_convert(const float* src, void* dst, int dst_dtype, int rows, int cols, int dst_ld, float scale,
+                          hipStream_t s) {
+  const size_t n = (size_t)rows * dst_ld;
+  if (n == 0) return hipSuccess;
+  const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  if (dst_dtype == 1)
+    hipLaunchKernelGGL(convert_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, src, (bf16_t*)dst, rows, cols, dst_ld, scale);
+  else
+    hipLaunchKernelGGL(convert_kernel<float>, dim3(grid), dim3(256), 0, s, src, (float*)dst, rows, cols, dst_ld, scale);
+  return hipGetLastError();
+}
+
+__global__ void transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows, int cols) {
+  __shared__ float t[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  for (int i = threadIdx.y; i < 32; i += 8) {
+    const int r = r0 + i, c = c0 + threadIdx.x;
+    t[i][threadIdx.x] = (r < rows && c < cols) ? src[(size_t)r * cols + c] : 0.f;
+  }
+  __syncthreads();
+  for (int i = threadIdx.y; i < 32; i += 8) {
+    const int c = c0 + i, r = r0 + threadIdx.x;
+    if (r < rows && c < cols) dst[(size_t)c * rows + r] = t[threadIdx.x][i];
+  }
+}
+hipError_t launch_transpose(const float* src, float* dst, int rows, int cols, hipStream_t s) {
+  hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(32, 8), 0, s, src, dst, rows, cols);
+  return hipGetLastError();
+}
+
+__global__ void scale_copy_kernel(const float* __restrict__ src, float* __restrict__ dst, int n, float scale) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) dst[i] = src[i] * scale;
+}
+hipError_t launch_scale_copy(const float* src, float* dst, int n, float scale, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(scale_copy_kernel, dim3((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024), dim3(256), 0, s, src, dst,
+                     n, scale);
+  return hipGetLastError();
+}
+
+}  // namespace plipmi

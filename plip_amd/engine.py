@@ -1,0 +1,239 @@
+"""Thin host-side owner of one plipmi handle.  PyTorch-ROCm is used for device
+memory, streams and tensors only -- all arithmetic happens inside libplipmi.so."""
+from __future__ import annotations
+
+import contextlib
+import ctypes as C
+import math
+from typing import Mapping, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from .config import PlipConfig
+
+_DTYPES = {"fp32": _lib.F32, "f32": _lib.F32, "float32": _lib.F32, torch.float32: _lib.F32,
+           "bf16": _lib.BF16, "bfloat16": _lib.BF16, torch.bfloat16: _lib.BF16}
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class Engine:
+    """One MI355X engine = packed weights + workspace for ``max_batch`` images/captions."""
+
+    def __init__(self, cfg: PlipConfig, state_dict: Mapping[str, object], device="cuda:0", dtype="bf16",
+                 max_batch: int = 256):
+        cfg.validate()
+        if not torch.cuda.is_available():
+            raise RuntimeError("plip_amd needs a ROCm GPU (MI355X / gfx950): torch.cuda.is_available() is False "
+                               "and there is no CPU fallback")
+        self.cfg = cfg
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError(f"device must be a cuda(ROCm) device, got {device}")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self.dtype_code = _DTYPES[dtype]
+        self.dtype_name = "bf16" if self.dtype_code == _lib.BF16 else "f32"
+        self.max_batch = int(max_batch)
+        self.lib = _lib.load()
+        self._h = C.c_void_p()
+        self.logit_scale = float(np.asarray(state_dict["logit_scale"], dtype=np.float64)) \
+            if not torch.is_tensor(state_dict["logit_scale"]) else float(state_dict["logit_scale"])
+        with torch.cuda.device(self.device):
+            dev = {}
+            for k, v in state_dict.items():
+                if k == "logit_scale":
+                    continue
+                t = v if torch.is_tensor(v) else torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32))
+                dev[k] = t.detach().to(device=self.device, dtype=torch.float32).contiguous()
+            c = _lib.Config(cfg.image_size, cfg.patch_size, cfg.v_width, cfg.v_layers, cfg.v_heads, cfg.v_mlp,
+                            cfg.vocab_size, cfg.context_length, cfg.t_width, cfg.t_layers, cfg.t_heads, cfg.t_mlp,
+                            cfg.projection_dim, cfg.layer_norm_eps, self.dtype_code, self.max_batch)
+            w = _lib.Weights()
+
+            def layers(prefix, n):
+                arr = (_lib.LayerWeights * n)()
+                names = {"ln1": "layer_norm1", "ln2": "layer_norm2", "q": "self_attn.q_proj", "k": "self_attn.k_proj",
+                         "v": "self_attn.v_proj", "o": "self_attn.out_proj", "fc1": "mlp.fc1", "fc2": "mlp.fc2"}
+                for i in range(n):
+                    for short, long in names.items():
+                        for suf, key in (("w", "weight"), ("b", "bias")):
+                            setattr(arr[i], f"{short}_{suf}", dev[f"{prefix}.encoder.layers.{i}.{long}.{key}"].data_ptr())
+                return arr
+
+            vl, tl = layers("vision_model", cfg.v_layers), layers("text_model", cfg.t_layers)
+            w.v_class_embedding = dev["vision_model.embeddings.class_embedding"].data_ptr()
+            w.v_patch_weight = dev["vision_model.embeddings.patch_embedding.weight"].data_ptr()
+            w.v_pos_embedding = dev["vision_model.embeddings.position_embedding.weight"].data_ptr()
+            w.v_pre_ln_w = dev["vision_model.pre_layrnorm.weight"].data_ptr()
+            w.v_pre_ln_b = dev["vision_model.pre_layrnorm.bias"].data_ptr()
+            w.v_post_ln_w = dev["vision_model.post_layernorm.weight"].data_ptr()
+            w.v_post_ln_b = dev["vision_model.post_layernorm.bias"].data_ptr()
+            w.visual_projection = dev["visual_projection.weight"].data_ptr()
+            w.v_layers = vl
+            w.t_token_embedding = dev["text_model.embeddings.token_embedding.weight"].data_ptr()
+            w.t_pos_embedding = dev["text_model.embeddings.position_embedding.weight"].data_ptr()
+            w.t_final_ln_w = dev["text_model.final_layer_norm.weight"].data_ptr()
+            w.t_final_ln_b = dev["text_model.final_layer_norm.bias"].data_ptr()
+            w.text_projection = dev["text_projection.weight"].data_ptr()
+            w.t_layers = tl
+            stream = torch.cuda.current_stream(self.device)
+            _lib.check(self.lib.plipmi_create(C.byref(c), C.byref(w), C.c_void_p(stream.cuda_stream),
+                                              C.byref(self._h)), "plipmi_create")
+            stream.synchronize()  # packing done -> the fp32 upload copies can go
+            del dev
+        self.device_name = self.lib.plipmi_device_name(self._h).decode()
+
+    # ------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.lib.plipmi_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _chunks(self, n):
+        for s in range(0, n, self.max_batch):
+            yield s, min(n, s + self.max_batch)
+
+    # ------------------------------------------------------------------
+    def encode_image(self, pixels: torch.Tensor, normalize: bool = False) -> torch.Tensor:
+        """fp32 [B,3,H,W] (any device) -> fp32 [B,P] on the GPU."""
+        cfg = self.cfg
+        if pixels.dim() != 4 or pixels.shape[1] != 3 or pixels.shape[2] != cfg.image_size or pixels.shape[3] != cfg.image_size:
+            raise ValueError(f"Input image size ({tuple(pixels.shape)}) doesn't match model "
+                             f"([B,3,{cfg.image_size},{cfg.image_size}]).")
+        with torch.cuda.device(self.device):
+            px = pixels.to(device=self.device, dtype=torch.float32).contiguous()
+            out = torch.empty((px.shape[0], cfg.projection_dim), dtype=torch.float32, device=self.device)
+            for a, b in self._chunks(px.shape[0]):
+                _lib.check(self.lib.plipmi_encode_image(self._h, _ptr(px[a:b]), b - a, _ptr(out[a:b]), int(normalize),
+                                                        self._stream()), "plipmi_encode_image")
+        return out
+
+    def encode_text(self, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
+                    normalize: bool = False, eos_token_id: Optional[int] = None) -> torch.Tensor:
+        """int [B,ctx] token ids -> fp32 [B,P] on the GPU."""
+        cfg = self.cfg
+        if input_ids.dim() != 2 or input_ids.shape[1] != cfg.context_length:
+            raise ValueError(f"input_ids must be [B,{cfg.context_length}], got {tuple(input_ids.shape)} "
+                             "(pad/truncate to the context length like the reference, plip.py:58)")
+        if input_ids.device.type == "cpu" and input_ids.numel():
+            lo, hi = int(input_ids.min()), int(input_ids.max())
+            if lo < 0 or hi >= cfg.vocab_size:
+                raise IndexError(f"token id out of range [0,{cfg.vocab_size}): min {lo}, max {hi}")
+        eos = cfg.eos_token_id if eos_token_id is None else int(eos_token_id)
+        with torch.cuda.device(self.device):
+            ids = input_ids.to(device=self.device, dtype=torch.int64).contiguous()
+            mask = None if attention_mask is None else attention_mask.to(device=self.device, dtype=torch.int64).contiguous()
+            out = torch.empty((ids.shape[0], cfg.projection_dim), dtype=torch.float32, device=self.device)
+            for a, b in self._chunks(ids.shape[0]):
+                _lib.check(self.lib.plipmi_encode_text(self._h, _ptr(ids[a:b]), _ptr(None if mask is None else mask[a:b]),
+                                                       b - a, eos, _ptr(out[a:b]), int(normalize), self._stream()),
+                           "plipmi_encode_text")
+        return out
+
+    def l2_normalize_(self, x: torch.Tensor) -> torch.Tensor:
+        assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 2
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.plipmi_l2_normalize(self._h, _ptr(x), x.shape[0], x.shape[1], self._stream()),
+                       "plipmi_l2_normalize")
+        return x
+
+    def logits(self, image_embeds: torch.Tensor, text_embeds: torch.Tensor, scale: float = 1.0,
+               want_text: bool = True, want_argmax: bool = False):
+        """scale * image_embeds @ text_embeds.T -> (logits_per_image, logits_per_text|None, argmax|None)."""
+        with torch.cuda.device(self.device):
+            img = image_embeds.to(device=self.device, dtype=torch.float32).contiguous()
+            txt = text_embeds.to(device=self.device, dtype=torch.float32).contiguous()
+            ni, nt, d = img.shape[0], txt.shape[0], img.shape[1]
+            if txt.shape[1] != d:
+                raise ValueError("embedding widths differ")
+            lpi = torch.empty((ni, nt), dtype=torch.float32, device=self.device)
+            lpt = torch.empty((nt, ni), dtype=torch.float32, device=self.device) if want_text else None
+            am = torch.empty((ni,), dtype=torch.int32, device=self.device) if want_argmax else None
+            _lib.check(self.lib.plipmi_logits(self._h, _ptr(img), ni, _ptr(txt), nt, d, float(scale), _ptr(lpi), _ptr(lpt),
+                                              _ptr(am), self._stream()), "plipmi_logits")
+        return lpi, lpt, am
+
+    def topk(self, scores: torch.Tensor, k: int) -> torch.Tensor:
+        with torch.cuda.device(self.device):
+            sc = scores.to(device=self.device, dtype=torch.float32).contiguous()
+            idx = torch.empty((sc.shape[0], k), dtype=torch.int64, device=self.device)
+            _lib.check(self.lib.plipmi_topk(self._h, _ptr(sc), sc.shape[0], sc.shape[1], int(k), _ptr(idx),
+                                            self._stream()), "plipmi_topk")
+        return idx
+
+    def hidden(self, tower: str, layer: int, inp: torch.Tensor) -> torch.Tensor:
+        """HF ``hidden_states[layer]`` of a tower (parity tests)."""
+        cfg = self.cfg
+        vision = tower == "vision"
+        S, D = (cfg.v_tokens, cfg.v_width) if vision else (cfg.context_length, cfg.t_width)
+        with torch.cuda.device(self.device):
+            x = inp.to(device=self.device, dtype=torch.float32 if vision else torch.int64).contiguous()
+            if x.shape[0] > self.max_batch:
+                raise ValueError("batch larger than max_batch")
+            out = torch.empty((x.shape[0], S, D), dtype=torch.float32, device=self.device)
+            _lib.check(self.lib.plipmi_debug_hidden(self._h, _lib.VISION if vision else _lib.TEXT, int(layer), _ptr(x),
+                                                    x.shape[0], _ptr(out), self._stream()), "plipmi_debug_hidden")
+        return out
+
+    # ------------------------------------------------------------------
+    @contextlib.contextmanager
+    def profile(self, result: list):
+        """Per-kernel HIP-event timing of everything launched inside the block; rows are appended to ``result``."""
+        _lib.check(self.lib.plipmi_profile_enable(self._h, 1), "plipmi_profile_enable")
+        try:
+            yield
+        finally:
+            _lib.check(self.lib.plipmi_profile_enable(self._h, 0), "plipmi_profile_enable")
+            rows = (_lib.KernelStat * 128)()
+            n = C.c_int(0)
+            _lib.check(self.lib.plipmi_profile_read(self._h, rows, 128, C.byref(n)), "plipmi_profile_read")
+            for r in rows[: n.value]:
+                result.append({"name": r.name.decode(), "calls": int(r.calls), "total_ms": float(r.total_ms),
+                               "flops": float(r.flops), "bytes": float(r.bytes)})
+
+    @property
+    def logit_scale_exp(self) -> float:
+        return math.exp(self.logit_scale)
+
+
+def gemm_nt(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, epilogue: int = 0,
+            variant: int = -1, alpha: float = 1.0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Kernel-level entry (tests / micro-bench): epilogue(A[M,K] @ W[N,K]^T); a, w fp32 or bf16 CUDA tensors."""
+    lib = _lib.load()
+    assert a.is_cuda and w.is_cuda and a.dtype == w.dtype and a.is_contiguous() and w.is_contiguous()
+    code = _lib.BF16 if a.dtype == torch.bfloat16 else _lib.F32
+    M, K = a.shape
+    N = w.shape[0]
+    if out is None:
+        odt = a.dtype if epilogue in (0, 1) else torch.float32
+        out = torch.zeros((M, N), dtype=odt, device=a.device)
+    with torch.cuda.device(a.device):
+        _lib.check(lib.plipmi_gemm_nt(code, epilogue, variant, M, N, K, _ptr(a), _ptr(w), _ptr(bias), float(alpha),
+                                      _ptr(out), C.c_void_p(torch.cuda.current_stream(a.device).cuda_stream)),
+                   "plipmi_gemm_nt")
+    return out
+
+
+def gemm_variants():
+    lib = _lib.load()
+    names, i = [], 0
+    while True:
+        n = lib.plipmi_gemm_variant_name(i)
+        if not n:
+            return names
+        names.append(n.decode())
+        i += 1

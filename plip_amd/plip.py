@@ -1,0 +1,118 @@
+"""Drop-in for the reference's top-level ``PLIP`` class (/root/reference/plip.py).
+
+Same constructor and methods -- ``encode_images``, ``encode_text``,
+``_cosine_similarity``, ``_nearest_neighbours``, ``zero_shot_classification``,
+``retrieval`` -- with the model forward running in the MI355X engine.  Reference
+quirks that are part of its observable behaviour are kept:
+``encode_*`` return UN-normalised float32 [N,512] numpy arrays (plip.py:53,71) and
+``_cosine_similarity`` normalises only the key side (plip.py:73-76).  Two latent bugs
+are not reproduced: ``retrieval`` read a never-assigned ``self.image_vectors``
+(plip.py:114) -- here ``index_images`` sets it -- and the batch loop no longer syncs
+and copies to the host once per batch (plip.py:50): batches are enqueued back to back
+and copied once.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Sequence, Union
+
+import numpy as np
+import torch
+
+from .model import PlipModel
+from .preprocess import load_tokenizer, preprocess_images
+
+
+class PLIP:
+    def __init__(self, model_name: str = None, auth_token=None, *, model: Optional[PlipModel] = None,
+                 tokenizer: Optional[Callable] = None, dtype: str = "bf16", max_batch: int = 256,
+                 device: str = "cuda:0"):
+        if not torch.cuda.is_available():
+            raise RuntimeError("plip_amd.PLIP needs an MI355X (ROCm) GPU; there is no CPU path")
+        self.device = device
+        self.model_name = model_name
+        if model is None:
+            if model_name is None:
+                raise ValueError("give a local checkpoint path (HF dir or OpenAI .pt) or a PlipModel")
+            model = PlipModel.from_pretrained(model_name, device=device, dtype=dtype, max_batch=max_batch)
+            if tokenizer is None:
+                tokenizer = load_tokenizer(model_name)
+        self.model = model.to(self.device)
+        self.tokenizer = tokenizer
+        self.model_hash = hash            # the reference returns the builtin too (plip.py:29)
+        self.image_vectors = None
+
+    # -- plip.py:31-53 -------------------------------------------------------
+    def encode_images(self, images: Union[List[str], list, np.ndarray, torch.Tensor], batch_size: int):
+        n_px = self.model.config.image_size
+        outs = []
+        with torch.no_grad():
+            for s in range(0, len(images), batch_size):
+                chunk = images[s:s + batch_size]
+                if torch.is_tensor(chunk):
+                    px = chunk
+                elif isinstance(chunk, np.ndarray) and chunk.dtype != np.uint8:
+                    px = torch.from_numpy(chunk)
+                else:
+                    px = torch.from_numpy(preprocess_images(list(chunk), n_px))
+                outs.append(self.model.get_image_features(pixel_values=px))
+        if not outs:
+            return np.zeros((0, self.model.config.projection_dim), np.float32)
+        return torch.cat(outs).detach().cpu().numpy()
+
+    # -- plip.py:55-71 ---------------------------------------------------------
+    def encode_text(self, text: Union[List[str], np.ndarray, torch.Tensor], batch_size: int):
+        ctx = self.model.config.context_length
+        if torch.is_tensor(text) or isinstance(text, np.ndarray):
+            ids, mask = torch.as_tensor(text), None      # already tokenised
+        else:
+            if self.tokenizer is None:
+                raise RuntimeError("no tokenizer: pass tokenizer=... or token ids")
+            ids, mask = self.tokenizer(list(text), ctx)
+            ids, mask = torch.as_tensor(ids), (None if mask is None else torch.as_tensor(mask))
+        outs = []
+        with torch.no_grad():
+            for s in range(0, len(ids), batch_size):
+                m = None if mask is None else mask[s:s + batch_size]
+                outs.append(self.model.get_text_features(input_ids=ids[s:s + batch_size], attention_mask=m))
+        if not outs:
+            return np.zeros((0, self.model.config.projection_dim), np.float32)
+        return torch.cat(outs).detach().cpu().numpy()
+
+    # -- plip.py:73-76 -----------------------------------------------------------
+    def _cosine_similarity(self, key_vectors: np.ndarray, space_vectors: np.ndarray, normalize=True):
+        eng = self.model.engine
+        k = torch.as_tensor(np.ascontiguousarray(key_vectors, dtype=np.float32)).to(eng.device)
+        s = torch.as_tensor(np.ascontiguousarray(space_vectors, dtype=np.float32)).to(eng.device)
+        if normalize:
+            k = eng.l2_normalize_(k.clone())            # only the key side, as the reference does
+        lpi, _, _ = eng.logits(k, s, scale=1.0, want_text=False)
+        return lpi.cpu().numpy()
+
+    # -- plip.py:78-87 -----------------------------------------------------------
+    def _nearest_neighbours(self, k, key_vectors, space_vectors, normalize=True, debug=False):
+        key_vectors, space_vectors = np.asarray(key_vectors), np.asarray(space_vectors)
+        eng = self.model.engine
+        sim = torch.as_tensor(self._cosine_similarity(key_vectors, space_vectors, normalize=normalize))
+        return eng.topk(sim, k).cpu().numpy()
+
+    # -- plip.py:89-103 ----------------------------------------------------------
+    def zero_shot_classification(self, images, text_labels: List[str], debug=False):
+        text_vectors = self.encode_text(text_labels, batch_size=8)
+        image_vectors = self.encode_images(images, batch_size=8)
+        cosine_sim = self._cosine_similarity(image_vectors, text_vectors)
+        if debug:
+            print(cosine_sim)
+        preds = np.argmax(cosine_sim, axis=-1)
+        return [text_labels[idx] for idx in preds]
+
+    def index_images(self, images, batch_size: int = 256):
+        """Embed the retrieval corpus (the reference forgot to: plip.py:114 reads self.image_vectors)."""
+        self.image_vectors = self.encode_images(images, batch_size=batch_size)
+        return self.image_vectors
+
+    # -- plip.py:105-114 -----------------------------------------------------------
+    def retrieval(self, queries: List[str], top_k: int = 10):
+        if self.image_vectors is None:
+            raise RuntimeError("call index_images(images) before retrieval()")
+        text_vectors = self.encode_text(queries, batch_size=8)
+        return self._nearest_neighbours(k=top_k, key_vectors=text_vectors, space_vectors=self.image_vectors)
