@@ -1,0 +1,219 @@
+#!/usr/bin/env python
+"""bench.py -- the PLIP embedding hot path on N MI355X GPUs of one node.
+
+One "step" = one pass of the path over one synthetic batch per GPU:
+    pixels [B,3,224,224] fp32 + token ids [B,77]  (already resident in HBM)
+      -> image tower, text tower (libplipmi.so), L2-normalise
+      -> all-gather of the embeddings across ranks (RCCL, only when N > 1)
+      -> this rank's rows of logits_per_image against every caption of the global batch.
+Workload at every N: BASELINE.json config "Full dual-encoder (image+text) bs=256 bf16"
+per GPU (weak scaling: the global batch is 256*N pairs).
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+        --master-port 29500 bench.py --gpus 8 --steps 20 --warmup 3
+
+Rank 0 prints ONE JSON line (see README / DESIGN.md for the fields).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}   # dense MFMA peaks, MI355X_MICROARCH.md "Chip-level parameters"
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="pairs per GPU per step")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--arch", default="ViT-B/32")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="lower bound of CPU work for the baseline sample")
+    ap.add_argument("--no-profile", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(cfg, sd, seconds):
+    """The reference's own forward (HF CLIPModel, what plip.py:50,68 call) on the host cores of
+    THIS box, same synthetic weights, bounded sample.  Falls back to the numpy oracle ("port")."""
+    from plip_amd import weights as W
+    cores = os.cpu_count() or 1
+    B = 32
+    px = W.synthetic_pixels(cfg, B, seed=1)
+    ids, mask = W.synthetic_ids(cfg, B, seed=2)
+    try:
+        from oracle import hf_reference as H
+        torch.set_num_threads(cores)
+        model = H.build_model(cfg, sd, "sdpa")
+        tp, ti, tm = torch.from_numpy(px), torch.from_numpy(ids), torch.from_numpy(mask)
+
+        def run():
+            with torch.no_grad():
+                return model(input_ids=ti, pixel_values=tp, attention_mask=tm).logits_per_image
+        kind, what = "reference", "HF transformers CLIPModel.forward, torch CPU fp32 sdpa"
+    except Exception as e:  # transformers missing -> time the oracle restatement instead
+        from oracle import clip_oracle as O
+
+        def run():
+            return O.clip_forward(px, ids, sd, cfg, mask)["logits_per_image"]
+        kind, what = "port", f"numpy oracle (HF unavailable: {type(e).__name__})"
+    run()                                   # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        run()
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= seconds and n >= 2:
+            break
+    cpu_name = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu_name = next((l.split(":", 1)[1].strip() for l in f if l.startswith("model name")), "")
+    except OSError:
+        pass
+    return {"value": round(n * B / el, 2), "unit": "pairs/s", "cores": cores, "kind": kind,
+            "sample": f"{n} x {B} synthetic pairs ({el:.1f} s): {what}; {cpu_name}"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit(f"--gpus {args.gpus} needs one process per GPU: launch with\n  python -m torch.distributed.run "
+                             f"--nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 --master-port 29500 "
+                             f"bench.py --gpus {args.gpus} ...")
+        raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (ROCm) GPU: torch.cuda.is_available() is False; there is no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)       # "nccl" is RCCL on ROCm
+
+    from plip_amd import weights as W
+    from plip_amd.config import get_config
+    from plip_amd.dist import sharded_pair_logits
+    from plip_amd.model import PlipModel
+
+    cfg = get_config(args.arch)
+    B = args.batch
+    sd = W.synthetic_state_dict(cfg, seed=0)                   # same weights on every rank
+    model = PlipModel(cfg, sd, device=dev, dtype=args.dtype, max_batch=B)
+    px = torch.from_numpy(W.synthetic_pixels(cfg, B, seed=1000 + rank)).to(dev)
+    ids_np, mask_np = W.synthetic_ids(cfg, B, seed=2000 + rank)
+    ids, mask = torch.from_numpy(ids_np).to(dev), torch.from_numpy(mask_np).to(dev)
+
+    def step():
+        return sharded_pair_logits(model, px, ids, mask)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    logits = out[0]
+    assert logits.shape == (B, B * world) and bool(torch.isfinite(logits).all())
+
+    # ---- roofline of the dominant kernel: HIP events on the launch stream, same K steps ----------
+    roofline = None
+    kernels = []
+    if not args.no_profile:
+        rows = []
+        with model.engine.profile(rows):
+            for _ in range(args.steps):
+                step()
+        rows.sort(key=lambda r: -r["total_ms"])
+        total = sum(r["total_ms"] for r in rows) or 1.0
+        kernels = [{"name": r["name"], "calls_per_step": r["calls"] / args.steps,
+                    "ms_per_step": round(r["total_ms"] / args.steps, 4), "share": round(r["total_ms"] / total, 4),
+                    "tflops": round(r["flops"] / (r["total_ms"] * 1e9), 1) if r["flops"] else None}
+                   for r in rows[:8]]
+        dom = next((r for r in rows if r["flops"] > 0), None)
+        if dom:
+            ach = dom["flops"] / (dom["total_ms"] * 1e-3) / 1e12
+            peak = PEAK_TFLOPS[args.dtype]
+            roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                        "frac": round(ach / peak, 4), "traffic": None, "kernel": dom["name"],
+                        "avg_launch_us": round(dom["total_ms"] * 1e3 / dom["calls"], 2),
+                        "flops_per_launch": round(dom["flops"] / dom["calls"]),
+                        "all_gemm_tflops": round(sum(r["flops"] for r in rows if r["name"].startswith("gemm")) /
+                                                 (sum(r["total_ms"] for r in rows if r["name"].startswith("gemm")) * 1e9), 1)}
+
+    if rank != 0:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    pairs = B * world * args.steps
+    value = pairs / elapsed
+    res = {
+        "metric": "image+text pairs embedded/sec at 224px bs=256",
+        "value": round(value, 1), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": args.dtype if args.dtype != "f32" else "f32", "data": "synthetic",
+        "config": {"workload": f"full dual encoder (image tower + text tower + L2 normalise + logits_per_image), "
+                               f"{args.arch}, bs={B} pairs per GPU, {cfg.image_size}px, {cfg.context_length} tokens, "
+                               f"{args.dtype} MFMA / fp32 accumulate (BASELINE.json configs[2])",
+                   "arch": args.arch, "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
+                   "collective": "none" if world == 1 else "RCCL all-gather of [B,512] fp32 image+text embeddings",
+                   "device": model.engine.device_name},
+        "algorithmic_tflops": round(value * cfg.pair_flops() / 1e12, 2),
+        "roofline": roofline,
+        "kernels": kernels,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        # parity on a small sample, then the timed CPU baseline (rank 0, N=1 only)
+        try:
+            from oracle import clip_oracle as O
+            n = 8
+            o = O.clip_forward(px[:n].cpu().numpy(), ids_np[:n], sd, cfg, mask_np[:n])
+            got = model(input_ids=ids[:n], pixel_values=px[:n], attention_mask=mask[:n])
+            scale = float(np.exp(np.float64(sd["logit_scale"])))
+            res["logits_max_abs_err"] = {
+                "cosine": float(np.abs(got.logits_per_image.cpu().numpy() / scale - o["logits_per_image"] / scale).max()),
+                "vs": "CPU oracle (numpy fp32 restatement of HF CLIPModel, pinned to HF golden vectors)", "pairs": n}
+        except Exception as e:  # pragma: no cover
+            res["logits_max_abs_err"] = {"error": repr(e)}
+        res["cpu_baseline"] = cpu_baseline(cfg, sd, args.cpu_seconds)
+    else:
+        res["cpu_baseline"] = None
+    print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

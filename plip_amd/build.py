@@ -21,7 +21,7 @@ LIB = os.path.join(CSRC, "libplipmi.so")
 SOURCES = ["engine.hip", "gemm.hip", "gemm_f32.hip", "gemm_bf16.hip", "kernels.hip", "attention.hip",
            "attention_mfma.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
-         "-Wno-unused-result"]
+         "-Wno-unused-result", "-Wno-unused-value"]
 
 
 def _hipcc() -> str:

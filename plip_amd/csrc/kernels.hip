@@ -14,9 +14,9 @@ namespace plipmi {
 constexpr int kLnMaxVec = 8;  // float4 per lane -> D <= 2048
 
 template <typename TOut>
-__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, size_t xs,
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* x, size_t xs,  // x may alias y (in-place pre-LN)
                                                         const float* __restrict__ g, const float* __restrict__ b,
-                                                        TOut* __restrict__ y, int rows, int D, float eps) {
+                                                        TOut* y, int rows, int D, float eps) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;

@@ -280,6 +280,7 @@ def normalize_state_dict(sd: Mapping[str, object], cfg: PlipConfig | None = None
                if not k.endswith("position_ids")}  # non-persistent buffer in old HF checkpoints
         if cfg is None:
             cfg = get_config("ViT-B/32")
+    out["logit_scale"] = np.float32(np.asarray(out["logit_scale"], dtype=np.float32).reshape(-1)[0])
     check_state_dict(out, cfg)
     return out, cfg
 

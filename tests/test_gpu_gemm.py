@@ -1,0 +1,70 @@
+"""Kernel-level parity of the MFMA NT GEMM (plipmi_gemm_nt) on the MI355X: every tile
+variant x dtype x epilogue against an fp64 product of the same (already rounded) operands,
+and against the naive one-thread-per-output checker kernel of the library."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(1, 256, 64), (37, 256, 128), (128, 256, 192), (300, 512, 768), (515, 256, 3072)]
+
+
+def _ref(a, w, bias, epi, alpha, c0):
+    y = a.double() @ w.double().T
+    if epi in (0, 1, 2):
+        y = y + bias.double()
+    if epi == 1:
+        y = y * torch.sigmoid(1.702 * y)
+    if epi == 2:
+        y = y + c0.double()
+    if epi == 3:
+        y = alpha * y
+    return y
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, -2])
+@pytest.mark.parametrize("epi", [0, 1, 2, 3])
+def test_gemm_variants(dtype, variant, epi):
+    from plip_amd.engine import gemm_nt
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(1234 + 10 * epi + variant)
+    for (M, N, K) in SHAPES:
+        a = torch.randn(M, K, generator=g).to(dev).to(dtype)
+        w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev).to(dtype)      # asymmetric operands
+        bias = torch.randn(N, generator=g).to(dev)
+        c0 = torch.randn(M, N, generator=g).to(dev)
+        out = c0.clone() if epi == 2 else None
+        y = gemm_nt(a, w, bias, epilogue=epi, variant=variant, alpha=0.37, out=out)
+        torch.cuda.synchronize()
+        ref = _ref(a, w, bias, epi, 0.37, c0)
+        err = (y.double() - ref).abs().max().item()
+        # fp32 outputs: fp32 accumulation noise only; bf16 outputs: one RNE rounding (2^-9 relative)
+        tol = 2e-4 if y.dtype == torch.float32 else 4e-3 * max(1.0, ref.abs().max().item())
+        assert err < tol, f"variant {variant} epi {epi} {M}x{N}x{K}: max err {err:.3e} (tol {tol:.1e})"
+
+
+def test_gemm_matches_naive_checker_bitwise_fp32():
+    """fp32 MFMA is an fmaf chain: tiled and naive kernels only differ in summation order."""
+    from plip_amd.engine import gemm_nt
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(7)
+    a = torch.randn(200, 256, generator=g).to(dev)
+    w = (torch.randn(384, 256, generator=g) / 16).to(dev)
+    b = torch.randn(384, generator=g).to(dev)
+    y1 = gemm_nt(a, w, b, epilogue=0, variant=1)
+    y0 = gemm_nt(a, w, b, epilogue=0, variant=0)
+    yn = gemm_nt(a, w, b, epilogue=0, variant=-2)
+    assert torch.equal(y0, y1)                      # same tile shape, LDS-DMA vs register staging
+    assert (y1 - yn).abs().max().item() < 1e-5
+
+
+def test_gemm_rejects_bad_shapes():
+    from plip_amd._lib import PlipmiError
+    from plip_amd.engine import gemm_nt
+    dev = torch.device("cuda:0")
+    a = torch.zeros(8, 48, device=dev)
+    w = torch.zeros(128, 48, device=dev)
+    with pytest.raises(PlipmiError):
+        gemm_nt(a, w, torch.zeros(128, device=dev), variant=1)      # K % 32 != 0

@@ -1,0 +1,138 @@
+"""Parity of the HIP path against the golden vectors of the reference's arithmetic
+(HF CLIPModel, tests/golden/*.npz) and against the CPU oracle, through the C ABI."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import clip_oracle as O
+from oracle.make_golden import CASES, case_inputs
+
+pytestmark = pytest.mark.gpu
+
+# Tolerances (max-abs).  fp32 engine: fp32-roundoff class (HF sdpa-vs-eager is 2e-6 on cosines).
+# bf16 engine: BASELINE.json north_star -- cosine-similarity logits within 1e-3 of the reference.
+TOL = {
+    "f32": dict(feat=2e-4, cos=1e-5, hidden=5e-4),
+    "bf16": dict(feat=6e-2, cos=1e-3, hidden=1.5e-1),
+}
+
+
+def _cos_logits(d, sd):
+    return d / np.exp(np.float64(sd["logit_scale"]))
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("name", list(CASES))
+def test_golden_features_and_logits(name, dtype, engines, golden):
+    g = golden(name)
+    model, cfg, sd, px, ids, mask = engines(name, dtype)
+    use_mask = None if "zero_pad" in name else torch.from_numpy(mask)
+    t = TOL[dtype]
+    img = model.get_image_features(pixel_values=torch.from_numpy(px)).cpu().numpy()
+    txt = model.get_text_features(input_ids=torch.from_numpy(ids), attention_mask=use_mask).cpu().numpy()
+    assert np.abs(img - g["image_features"]).max() < t["feat"]
+    assert np.abs(txt - g["text_features"]).max() < t["feat"]
+    out = model(input_ids=torch.from_numpy(ids), pixel_values=torch.from_numpy(px), attention_mask=use_mask)
+    assert np.abs(out.image_embeds.cpu().numpy() - g["image_embeds"]).max() < t["cos"]
+    assert np.abs(out.text_embeds.cpu().numpy() - g["text_embeds"]).max() < t["cos"]
+    lpi = out.logits_per_image.cpu().numpy()
+    assert np.abs(_cos_logits(lpi, sd) - _cos_logits(g["logits_per_image"], sd)).max() < t["cos"]
+    assert torch.equal(out.logits_per_image, out.logits_per_text.T.contiguous())
+    if dtype == "f32":
+        np.testing.assert_array_equal(lpi.argmax(1), g["logits_per_image"].argmax(1))
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_hidden_states_layer_by_layer_tiny(dtype, engines, golden):
+    """HF hidden_states[l] of both towers after every block (modeling_clip.py:398-401)."""
+    g = golden("tiny_b6")
+    model, cfg, sd, px, ids, mask = engines("tiny_b6", dtype)
+    t = TOL[dtype]
+    for layer in range(cfg.v_layers + 1):
+        h = model.engine.hidden("vision", layer, torch.from_numpy(px)).cpu().numpy()
+        assert np.abs(h - g["vision_hidden"][layer]).max() < t["hidden"], f"vision layer {layer}"
+    m = mask[:, :, None].astype(np.float32)
+    for layer in range(cfg.t_layers + 1):
+        h = model.engine.hidden("text", layer, torch.from_numpy(ids)).cpu().numpy()
+        assert np.abs((h - g["text_hidden"][layer]) * m).max() < t["hidden"], f"text layer {layer}"
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_hidden_states_vitb32(dtype, engines, golden):
+    g = golden("vitb32_b4")
+    model, cfg, sd, px, ids, mask = engines("vitb32_b4", dtype)
+    t = TOL[dtype]
+    for layer in (0, 1, 6, 12):
+        h = model.engine.hidden("vision", layer, torch.from_numpy(px)).cpu().numpy()
+        assert np.abs(h[:, 0] - g["vision_hidden_cls"][layer]).max() < t["hidden"] * 4, f"vision layer {layer}"
+        assert np.abs(h[:, -1] - g["vision_hidden_last_token"][layer]).max() < t["hidden"] * 4
+        h = model.engine.hidden("text", layer, torch.from_numpy(ids)).cpu().numpy()
+        assert np.abs(h[:, 0] - g["text_hidden_bos"][layer]).max() < t["hidden"] * 4, f"text layer {layer}"
+        assert np.abs(h[:, 1] - g["text_hidden_tok1"][layer]).max() < t["hidden"] * 4
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_full_batch_properties_bs256(dtype, engines):
+    """BASELINE size (bs=256, 224 px, 77 tokens): size-independent properties + oracle spot rows."""
+    from plip_amd import weights as W
+    from plip_amd.model import PlipModel
+    model, cfg, sd, *_ = engines("vitb32_b4", dtype, 256)
+    B = 256
+    px = torch.from_numpy(W.synthetic_pixels(cfg, B, seed=11))
+    ids_np, mask_np = W.synthetic_ids(cfg, B, seed=12)
+    ids, mask = torch.from_numpy(ids_np), torch.from_numpy(mask_np)
+    out = model(input_ids=ids, pixel_values=px, attention_mask=mask)
+    img, txt = out.image_embeds, out.text_embeds
+    assert img.shape == (B, 512) and txt.shape == (B, 512) and out.logits_per_image.shape == (B, B)
+    assert torch.isfinite(out.logits_per_image).all()
+    # unit rows
+    assert (img.norm(dim=-1) - 1).abs().max().item() < 2e-6 and (txt.norm(dim=-1) - 1).abs().max().item() < 2e-6
+    # transpose relation is exact, logits = scale * img @ txt.T
+    assert torch.equal(out.logits_per_image, out.logits_per_text.T.contiguous())
+    ref = (img.double() @ txt.double().T) * float(np.exp(np.float64(sd["logit_scale"])))
+    assert (out.logits_per_image.double() - ref).abs().max().item() < 1e-4
+    # batch invariance: a row's embedding does not depend on what else is in the batch (bit-exact)
+    sub = model.get_image_features(pixel_values=px[40:48])
+    full = model.get_image_features(pixel_values=px)
+    assert torch.equal(sub, full[40:48])
+    subt = model.get_text_features(input_ids=ids[100:103], attention_mask=mask[100:103])
+    fullt = model.get_text_features(input_ids=ids, attention_mask=mask)
+    assert torch.equal(subt, fullt[100:103])
+    # chunking over max_batch (B > max_batch goes through several engine calls)
+    small = engines("vitb32_b4", dtype)[0]          # max_batch = 32
+    assert torch.equal(small.get_image_features(pixel_values=px[:70]), full[:70])
+    # oracle on three rows of the big batch
+    rows = [0, 100, 255]
+    o = O.clip_forward(px[rows].numpy(), ids_np[rows], sd, cfg, mask_np[rows])
+    t = TOL[dtype]
+    assert np.abs(img[rows].cpu().numpy() - o["image_embeds"]).max() < t["cos"]
+    assert np.abs(txt[rows].cpu().numpy() - o["text_embeds"]).max() < t["cos"]
+
+
+def test_bf16_argmax_agreement_with_fp32(engines):
+    """Zero-shot style decision: bf16 engine picks the same caption as the fp32 engine."""
+    from plip_amd import weights as W
+    m32, cfg, sd, *_ = engines("vitb32_b3_zero_pad_ln100", "f32")
+    m16 = engines("vitb32_b3_zero_pad_ln100", "bf16")[0]
+    px = torch.from_numpy(W.synthetic_pixels(cfg, 24, seed=21))
+    ids = torch.from_numpy(W.synthetic_ids(cfg.replace(eos_token_id=49407), 10, seed=22, pad="zero")[0])
+    a = m32(input_ids=ids, pixel_values=px).logits_per_image
+    b = m16(input_ids=ids, pixel_values=px).logits_per_image
+    top2 = a.topk(2, dim=1).values
+    decided = (top2[:, 0] - top2[:, 1]) > 2e-2 * float(np.exp(np.float64(sd["logit_scale"])))
+    assert torch.equal(a.argmax(1)[decided], b.argmax(1)[decided])
+
+
+def test_eos_pooling_rules(engines):
+    """first-eos rule vs legacy arg-max rule (modeling_clip.py:561-581) on ids where they differ."""
+    model, cfg, sd, px, ids, mask = engines("tiny_b6", "f32")
+    ids2 = ids.copy()
+    # put a LARGER id than eos nowhere (eos is the max id): both rules agree
+    a = model.engine.encode_text(torch.from_numpy(ids2), None, eos_token_id=cfg.eos_token_id)
+    b = model.engine.encode_text(torch.from_numpy(ids2), None, eos_token_id=-1)
+    assert torch.equal(a, b)
+    # make them differ: eos id := a mid-range token that appears at position 2 of row 0
+    tok = int(ids2[0, 2])
+    o = O.text_tower(ids2, sd, cfg.replace(eos_token_id=tok), None)
+    c = model.engine.encode_text(torch.from_numpy(ids2), None, eos_token_id=tok).cpu().numpy()
+    assert np.abs(c - o).max() < 2e-4

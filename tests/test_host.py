@@ -1,0 +1,156 @@
+"""CPU-side checks: the C-ABI library builds/loads and exports every symbol the header
+declares, checkpoint ingestion (HF and OpenAI-clip formats), preprocessing, config maths.
+No kernel is launched here (no GPU in this container)."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from plip_amd import weights as W
+from plip_amd.config import PRESETS, get_config
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from plip_amd import _lib
+    from plip_amd.build import build
+    build(verbose=False)
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, "include", "plipmi.h")).read()
+    declared = set(re.findall(r"\b(plipmi_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.plipmi_version() == 100
+    names = []
+    i = 0
+    while lib.plipmi_gemm_variant_name(i):
+        names.append(lib.plipmi_gemm_variant_name(i).decode())
+        i += 1
+    assert len(names) >= 2 and lib.plipmi_gemm_variant_name(-1) is None
+
+
+def test_struct_layouts_match_header():
+    """ctypes mirrors of the C structs: field order/sizes as in include/plipmi.h."""
+    import ctypes as C
+
+    from plip_amd import _lib
+    assert C.sizeof(_lib.Config) == 16 * 4
+    assert C.sizeof(_lib.LayerWeights) == 16 * 8
+    assert C.sizeof(_lib.Weights) == 15 * 8
+    assert C.sizeof(_lib.KernelStat) == 96 + 8 + 3 * 8
+    header = open(os.path.join(ROOT, "include", "plipmi.h")).read()
+    cfg_block = header[header.index("typedef struct plipmi_config {"):header.index("} plipmi_config;")]
+    fields = re.findall(r"^\s*(?:int32_t|float)\s+(\w+);", cfg_block, flags=re.M)
+    assert fields == [f[0] for f in _lib.Config._fields_]
+
+
+def test_engine_creation_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from plip_amd.model import PlipModel
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        PlipModel.from_synthetic("tiny")
+
+
+def test_flop_model_matches_survey():
+    c = get_config("ViT-B/32")
+    assert abs(c.image_flops() / 1e9 - 8.8176) < 1e-3
+    assert abs(c.text_flops() / 1e9 - 5.9595) < 1e-3
+    assert abs(c.pair_flops() / 1e9 - 14.7772) < 1e-3
+    assert abs(get_config("ViT-L/14@336px").image_flops() / 1e9 - 381.92) < 1e-1
+    for name, cfg in PRESETS.items():
+        cfg.validate()
+
+
+def test_openai_checkpoint_round_trip():
+    cfg = get_config("tiny")
+    sd = W.synthetic_state_dict(cfg, 3)
+    oa = W.to_openai_state_dict(sd, cfg)
+    assert W.is_openai_state_dict(oa) and not W.is_openai_state_dict(sd)
+    rcfg = W.config_from_openai_state_dict(oa)
+    for f in ("image_size", "patch_size", "v_width", "v_layers", "v_heads", "v_mlp", "vocab_size",
+              "context_length", "t_width", "t_layers", "t_heads", "t_mlp", "projection_dim"):
+        assert getattr(rcfg, f) == getattr(cfg, f), f
+    assert rcfg.eos_token_id == 2          # OpenAI pools at argmax(ids)
+    back, _ = W.normalize_state_dict(oa)
+    assert set(back) == set(sd)
+    for k in sd:
+        np.testing.assert_array_equal(back[k], sd[k])
+
+
+def test_state_dict_validation():
+    cfg = get_config("tiny")
+    sd = W.synthetic_state_dict(cfg, 0)
+    W.check_state_dict(sd, cfg)
+    bad = dict(sd)
+    bad.pop("visual_projection.weight")
+    with pytest.raises(KeyError):
+        W.check_state_dict(bad, cfg)
+    bad = dict(sd)
+    bad["text_projection.weight"] = bad["text_projection.weight"].T
+    with pytest.raises(ValueError):
+        W.check_state_dict(bad, cfg.replace(projection_dim=32))
+
+
+def test_hf_checkpoint_dir_round_trip(tmp_path):
+    """load_checkpoint on an HF-layout directory (config.json + model.safetensors)."""
+    pytest.importorskip("safetensors")
+    import json
+
+    from safetensors.numpy import save_file
+    cfg = get_config("tiny")
+    sd = W.synthetic_state_dict(cfg, 1)
+    save_file({k: np.ascontiguousarray(np.asarray(v, dtype=np.float32)) for k, v in sd.items()},
+              str(tmp_path / "model.safetensors"))
+    hf_cfg = {"projection_dim": cfg.projection_dim, "logit_scale_init_value": 2.6592,
+              "text_config": {"vocab_size": cfg.vocab_size, "hidden_size": cfg.t_width, "intermediate_size": cfg.t_mlp,
+                              "num_hidden_layers": cfg.t_layers, "num_attention_heads": cfg.t_heads,
+                              "max_position_embeddings": cfg.context_length, "eos_token_id": cfg.eos_token_id,
+                              "bos_token_id": cfg.bos_token_id},
+              "vision_config": {"hidden_size": cfg.v_width, "intermediate_size": cfg.v_mlp,
+                                "num_hidden_layers": cfg.v_layers, "num_attention_heads": cfg.v_heads,
+                                "image_size": cfg.image_size, "patch_size": cfg.patch_size, "layer_norm_eps": 1e-5}}
+    (tmp_path / "config.json").write_text(json.dumps(hf_cfg))
+    got, gcfg = W.load_checkpoint(str(tmp_path))
+    assert gcfg == cfg
+    for k in sd:
+        np.testing.assert_array_equal(got[k], sd[k])
+
+
+def test_synthetic_ids_are_tokenizer_shaped():
+    cfg = get_config("ViT-B/32")
+    ids, mask = W.synthetic_ids(cfg, 64, seed=5)
+    assert ids.shape == (64, 77) and ids.dtype == np.int64
+    assert (ids[:, 0] == 49406).all() and ids.max() == 49407 and ids.min() >= 1
+    first_eos = (ids == 49407).argmax(1)
+    np.testing.assert_array_equal(mask.sum(1), first_eos + 1)
+    idz, _ = W.synthetic_ids(cfg, 8, seed=5, pad="zero")
+    assert ((idz == 0).sum(1) > 0).all() and ((idz == 49407).sum(1) == 1).all()
+
+
+def test_preprocess_reduces_to_affine_on_native_tiles():
+    """transform.py:45-52 / CLIPImageProcessor on a tile that is already n_px x n_px."""
+    from plip_amd.preprocess import CLIP_MEAN, CLIP_STD, preprocess_image
+    rs = np.random.RandomState(0)
+    tile = rs.randint(0, 256, size=(224, 224, 3), dtype=np.uint8)
+    got = preprocess_image(tile, 224)
+    want = ((tile.astype(np.float32) / 255.0 - np.float32(CLIP_MEAN)) / np.float32(CLIP_STD)).transpose(2, 0, 1)
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-6)
+    big = rs.randint(0, 256, size=(300, 260, 3), dtype=np.uint8)
+    assert preprocess_image(big, 224).shape == (3, 224, 224)
+
+
+def test_preprocess_matches_hf_image_processor():
+    tr = pytest.importorskip("transformers")
+    from PIL import Image
+
+    from plip_amd.preprocess import preprocess_image
+    rs = np.random.RandomState(1)
+    tile = rs.randint(0, 256, size=(224, 224, 3), dtype=np.uint8)
+    proc = tr.CLIPImageProcessor()
+    want = proc(images=Image.fromarray(tile), return_tensors="np")["pixel_values"][0]
+    np.testing.assert_allclose(preprocess_image(tile), want, rtol=0, atol=1e-6)

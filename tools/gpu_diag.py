@@ -1,0 +1,174 @@
+"""GPU-side diagnostics (run on the MI355X box through gpurun; never part of the product path).
+
+    python tools/gpu_diag.py gemm | tiny | vitb32 | gemmbench | e2e
+
+Unlike the pytest suite nothing here stops at the first mismatch: every section prints a
+table of errors / timings so one gpurun call localises a wrong kernel.
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from oracle import clip_oracle as O  # noqa: E402
+from oracle.make_golden import case_inputs  # noqa: E402
+from plip_amd import weights as W  # noqa: E402
+from plip_amd.config import get_config  # noqa: E402
+from plip_amd.engine import gemm_nt, gemm_variants  # noqa: E402
+from plip_amd.model import PlipModel  # noqa: E402
+
+dev = torch.device("cuda:0")
+
+
+def sec_gemm():
+    print("device", torch.cuda.get_device_name(0), "variants", gemm_variants())
+    g = torch.Generator().manual_seed(0)
+    for dtype in (torch.float32, torch.bfloat16):
+        for (M, N, K) in ((300, 512, 768), (77, 256, 64)):
+            a = torch.randn(M, K, generator=g).to(dev).to(dtype)
+            w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev).to(dtype)
+            bias = torch.randn(N, generator=g).to(dev)
+            c0 = torch.randn(M, N, generator=g).to(dev)
+            base = a.double() @ w.double().T
+            for variant in (-2, 0, 1, 2, 3, 4, 5):
+                for epi in (0, 1, 2, 3):
+                    ref = base + (bias.double() if epi < 3 else 0)
+                    if epi == 1:
+                        ref = ref * torch.sigmoid(1.702 * ref)
+                    if epi == 2:
+                        ref = ref + c0.double()
+                    if epi == 3:
+                        ref = 0.5 * ref
+                    try:
+                        y = gemm_nt(a, w, bias, epilogue=epi, variant=variant, alpha=0.5, out=c0.clone() if epi == 2 else None)
+                        torch.cuda.synchronize()
+                        err = (y.double() - ref).abs()
+                        bad = (err > 0.05).sum().item()
+                        print(f"{str(dtype):16s} {M}x{N}x{K} variant {variant:2d} epi {epi}: max err {err.max().item():.3e} "
+                              f"bad {bad}/{err.numel()}" + ("" if bad == 0 else f"  first bad idx {torch.nonzero(err > 0.05)[0].tolist()}"))
+                    except Exception as e:
+                        print(f"{dtype} {M}x{N}x{K} variant {variant} epi {epi}: EXC {e}")
+
+
+def _report(model, cfg, sd, px, ids, mask, name):
+    eng = model.engine
+    _, vh = O.vision_tower(px, sd, cfg, return_hidden=True)
+    _, th = O.text_tower(ids, sd, cfg, mask, return_hidden=True)
+    tpx, tids = torch.from_numpy(px), torch.from_numpy(ids)
+    vl = sorted(set([0, 1, 2, cfg.v_layers // 2, cfg.v_layers]))
+    for l in [x for x in vl if x <= cfg.v_layers]:
+        h = eng.hidden("vision", l, tpx).cpu().numpy()
+        print(f"{name} vision hidden[{l}] max err {np.abs(h - vh[l]).max():.3e}  (|h| max {np.abs(vh[l]).max():.2f})")
+    m = mask[:, :, None].astype(np.float32)
+    for l in [x for x in vl if x <= cfg.t_layers]:
+        h = eng.hidden("text", l, tids).cpu().numpy()
+        print(f"{name} text   hidden[{l}] max err {np.abs((h - th[l]) * m).max():.3e}  (|h| max {np.abs(th[l]).max():.2f})")
+    ref = O.clip_forward(px, ids, sd, cfg, mask)
+    out = model(input_ids=tids, pixel_values=tpx, attention_mask=torch.from_numpy(mask))
+    img = model.get_image_features(pixel_values=tpx).cpu().numpy()
+    txt = model.get_text_features(input_ids=tids, attention_mask=torch.from_numpy(mask)).cpu().numpy()
+    scale = np.exp(np.float64(sd["logit_scale"]))
+    print(f"{name} image_features err {np.abs(img - ref['image_features']).max():.3e}  text_features err "
+          f"{np.abs(txt - ref['text_features']).max():.3e}")
+    print(f"{name} image_embeds err {np.abs(out.image_embeds.cpu().numpy() - ref['image_embeds']).max():.3e}  text_embeds err "
+          f"{np.abs(out.text_embeds.cpu().numpy() - ref['text_embeds']).max():.3e}  cosine-logits err "
+          f"{np.abs(out.logits_per_image.cpu().numpy() - ref['logits_per_image']).max() / scale:.3e}")
+
+
+def sec_tiny():
+    for dtype in ("f32", "bf16"):
+        cfg, sd, px, ids, mask = case_inputs("tiny_b6")
+        model = PlipModel(cfg, sd, dtype=dtype, max_batch=8)
+        _report(model, cfg, sd, px, ids, mask, f"tiny/{dtype}")
+
+
+def sec_vitb32():
+    for dtype in ("f32", "bf16"):
+        cfg, sd, px, ids, mask = case_inputs("vitb32_b4")
+        model = PlipModel(cfg, sd, dtype=dtype, max_batch=8)
+        _report(model, cfg, sd, px, ids, mask, f"vitb32/{dtype}")
+        # a second weight seed / bigger batch for the bf16 cosine bar
+        cfg2 = cfg
+        sd2 = W.synthetic_state_dict(cfg2, 5)
+        px2 = W.synthetic_pixels(cfg2, 16, 6)
+        ids2, mask2 = W.synthetic_ids(cfg2, 16, 7)
+        m2 = PlipModel(cfg2, sd2, dtype=dtype, max_batch=16)
+        ref = O.clip_forward(px2, ids2, sd2, cfg2, mask2)
+        out = m2(input_ids=torch.from_numpy(ids2), pixel_values=torch.from_numpy(px2), attention_mask=torch.from_numpy(mask2))
+        scale = np.exp(np.float64(sd2["logit_scale"]))
+        print(f"vitb32/{dtype} seed5 b16: cosine-logits err {np.abs(out.logits_per_image.cpu().numpy() - ref['logits_per_image']).max() / scale:.3e} "
+              f"argmax agree {(out.logits_per_image.cpu().numpy().argmax(1) == ref['logits_per_image'].argmax(1)).mean():.3f}")
+
+
+def _time(fn, iters=30, warm=5):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def sec_gemmbench():
+    """Every tile variant on the eight production GEMM shapes of the bs=256 step (random data)."""
+    shapes = [("v.qkv", 12800, 2304, 768, 0), ("v.out", 12800, 768, 768, 2), ("v.fc1", 12800, 3072, 768, 1),
+              ("v.fc2", 12800, 768, 3072, 2), ("v.patch", 12544, 768, 3072, 3),
+              ("t.qkv", 19712, 1536, 512, 0), ("t.out", 19712, 512, 512, 2), ("t.fc1", 19712, 2048, 512, 1),
+              ("t.fc2", 19712, 512, 2048, 2)]
+    g = torch.Generator().manual_seed(0)
+    for dtype in (torch.bfloat16, torch.float32):
+        print(f"== {dtype}: TFLOP/s per variant {gemm_variants()}")
+        for name, M, N, K, epi in shapes:
+            a = torch.randn(M, K, generator=g).to(dev).to(dtype)
+            w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev).to(dtype)
+            bias = torch.randn(N, generator=g).to(dev)
+            out = torch.zeros(M, N, device=dev, dtype=dtype if epi in (0, 1) else torch.float32)
+            row = []
+            for v in range(len(gemm_variants())):
+                try:
+                    ms = _time(lambda: gemm_nt(a, w, bias, epilogue=epi, variant=v, out=out), iters=20 if dtype == torch.bfloat16 else 5)
+                    row.append(f"{2.0 * M * N * K / ms / 1e9:7.1f}")
+                except Exception as e:
+                    row.append("   n/a ")
+            print(f"{name:8s} {M:6d}x{N:5d}x{K:5d} epi{epi}: " + " ".join(row))
+
+
+def sec_e2e():
+    cfg = get_config("ViT-B/32")
+    sd = W.synthetic_state_dict(cfg, 0)
+    B = 256
+    px = torch.from_numpy(W.synthetic_pixels(cfg, B, 1)).to(dev)
+    ids_np, mask_np = W.synthetic_ids(cfg, B, 2)
+    ids, mask = torch.from_numpy(ids_np).to(dev), torch.from_numpy(mask_np).to(dev)
+    for dtype in ("bf16", "f32"):
+        model = PlipModel(cfg, sd, dtype=dtype, max_batch=B)
+        eng = model.engine
+        ti = _time(lambda: eng.encode_image(px, True), iters=10, warm=2)
+        tt = _time(lambda: eng.encode_text(ids, mask, True), iters=10, warm=2)
+        print(f"{dtype}: image tower {ti:.3f} ms ({B / ti * 1e3:.0f} img/s, {B * cfg.image_flops() / ti / 1e9:.1f} TFLOP/s)  "
+              f"text tower {tt:.3f} ms ({B / tt * 1e3:.0f} cap/s, {B * cfg.text_flops() / tt / 1e9:.1f} TFLOP/s)  "
+              f"pairs/s {B / (ti + tt) * 1e3:.0f}")
+        rows = []
+        with eng.profile(rows):
+            eng.encode_image(px, True)
+            eng.encode_text(ids, mask, True)
+        rows.sort(key=lambda r: -r["total_ms"])
+        tot = sum(r["total_ms"] for r in rows)
+        for r in rows:
+            tf = f"{r['flops'] / r['total_ms'] / 1e9:8.1f} TF/s" if r["flops"] else f"{r['bytes'] / r['total_ms'] / 1e6:8.1f} GB/s"
+            print(f"   {r['name']:48s} calls {r['calls']:4d}  {r['total_ms']:8.3f} ms  {100 * r['total_ms'] / tot:5.1f}%  {tf}")
+        model.engine.close()
+
+
+if __name__ == "__main__":
+    t0 = time.time()
+    {"gemm": sec_gemm, "tiny": sec_tiny, "vitb32": sec_vitb32, "gemmbench": sec_gemmbench, "e2e": sec_e2e}[sys.argv[1]]()
+    print(f"[{sys.argv[1]} done in {time.time() - t0:.1f} s]")

@@ -1,0 +1,21 @@
+#!/bin/bash
+# One gpurun call: diagnostics, the gpu test suite, the bench line and a rocprofv3 kernel trace.
+# usage: gpurun --timeout 1500 -- 'bash tools/gpu_round.sh [sections...]'
+cd "${GRAFT_REPO_ROOT:-.}"
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+SECTIONS="${@:-gemm tiny vitb32 gemmbench e2e pytest bench rocprof}"
+echo "sections: $SECTIONS" > gpurun_out/status.log
+for s in $SECTIONS; do
+  t0=$(date +%s)
+  case $s in
+    pytest)  timeout 1200 python -m pytest tests -m gpu -q -x > gpurun_out/pytest_gpu.log 2>&1 ;;
+    pytestall) timeout 1500 python -m pytest tests -m gpu -q > gpurun_out/pytest_gpu.log 2>&1 ;;
+    bench)   timeout 600 python bench.py --steps 20 --warmup 3 > gpurun_out/bench.json 2> gpurun_out/bench.err ;;
+    rocprof) (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/prof" -o plip -- python "$OLDPWD/bench.py" --steps 10 --warmup 2 --no-cpu-baseline --no-profile > "$OLDPWD/gpurun_out/rocprof_bench.json" 2> "$OLDPWD/gpurun_out/rocprof.err") ;;
+    smoke)   timeout 600 python __graft_entry__.py --smoke > gpurun_out/smoke.log 2>&1 ;;
+    *)       timeout 600 python tools/gpu_diag.py $s > gpurun_out/diag_$s.log 2>&1 ;;
+  esac
+  echo "$s exit $? ($(( $(date +%s) - t0 )) s)" >> gpurun_out/status.log
+done
+cat gpurun_out/status.log
