@@ -166,6 +166,12 @@ int plipmi_gemm_nt(int dtype, int epilogue, int variant, int M, int N, int K, co
                    const float* bias, float alpha, void* C, void* stream);
 const char* plipmi_gemm_variant_name(int variant);
 
+/* Kernel-level entry for the attention kernels: out[B*S, H*64] = softmax(q k^T + masks) v over the fused
+ * activation qkv [B*S, 3*H*64] (q | k | v, 1/sqrt(64) already folded into q).
+ *   impl 0 = exact-fp32 VALU kernel (dtype f32 or bf16), impl 1 = bf16 MFMA kernel (S <= 128). */
+int plipmi_attention(int dtype, int impl, const void* qkv, void* out, int B, int S, int H, int causal,
+                     const int64_t* key_mask, void* stream);
+
 /* Per-kernel timing with HIP events recorded on the launch stream.  While
  * enabled every kernel launch of the handle is bracketed by two events; the
  * totals are read back (this call synchronises) as rows of `plipmi_kernel_stat`. */

@@ -1,8 +1,163 @@
-// attention_mfma.hip -- bf16 MFMA attention (placeholder until the kernel lands; the engine uses the
-// exact VALU kernel and this entry reports "not supported" so nothing can silently fall back).
+// attention_mfma.hip -- bf16 MFMA attention for the short CLIP sequences (S <= 128:
+// 50 vision tokens, 77 text tokens), one workgroup per (image|caption, head), one
+// wavefront per block of 32 queries, v_mfma_f32_32x32x16_bf16 for both products.
+//
+//   scores^T = K Q^T   (operands swapped): a lane owns ONE query column (lane&31) and
+//                      16 keys per 32-key tile, so the softmax row reductions are a
+//                      register max/sum plus one exchange with lane^32 -- no LDS.
+//   O^T = V^T P^T      the contraction index (key) may be permuted freely as long as
+//                      both MFMA operands use the same permutation.  Choosing the
+//                      permutation that the QK^T accumulator layout already has
+//                      (slot jj of lane group g  <->  key (jj&3) + 4g + 8(jj>>2) + 16s)
+//                      makes the P operand a plain register pack: no cross-lane shuffle.
+//                      V^T comes from an LDS copy of V transposed at staging time
+//                      (row stride S_pad+4 bf16 -> conflict-free ds_read_b64).
+//   Softmax statistics, the running sum and the 1/l normalisation are fp32
+//   (modeling_clip.py:271); P is rounded to bf16 only as the MFMA operand.
 #include "kernels.h"
+
 namespace plipmi {
-hipError_t launch_attention_mfma(const void*, void*, int, int, int, int, const int64_t*, hipStream_t) {
-  return hipErrorNotSupported;
+
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+
+template <int KT>  // 32-key tiles: S <= 32*KT
+__global__ __launch_bounds__(64 * KT) void attention_mfma_kernel(const bf16_t* __restrict__ qkv,
+                                                                 bf16_t* __restrict__ out, int S, int H, int causal,
+                                                                 const int64_t* __restrict__ key_mask) {
+  constexpr int SP = 32 * KT;   // padded sequence
+  constexpr int VLD = SP + 4;   // Vt row stride (bf16): (SP/2 + 2) dwords, odd multiple of 2 -> all 64 banks
+  __shared__ __attribute__((aligned(16))) bf16_t Vt[64 * VLD];
+  __shared__ unsigned long long mk[4];
+
+  const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
+  const int D = H * 64, ld = 3 * D;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bf16_t* base = qkv + (size_t)b * S * ld + h * 64;
+
+  // key validity bits (sequence padding and the tokenizer's attention_mask): key = tid
+  {
+    const bool ok = tid < S && (key_mask == nullptr || key_mask[(size_t)b * S + tid] != 0);
+    const unsigned long long bits = __ballot(ok);
+    if (lane == 0) mk[wave] = bits;
+    if (KT < 4 && tid < 4 - KT) mk[KT + tid] = 0ull;
+  }
+  // V^T into LDS: thread -> (key, 4 consecutive d)
+  for (int e = tid; e < SP * 16; e += 64 * KT) {
+    const int key = e >> 4, dc = (e & 15) * 4;
+    const int kg = key < S ? key : S - 1;
+    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+    const bf16x4 v = *reinterpret_cast<const bf16x4*>(base + (size_t)kg * ld + 2 * D + dc);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) Vt[(dc + i) * VLD + key] = v[i];
+  }
+  __syncthreads();
+
+  const int q0 = wave * 32;
+  if (q0 >= S) return;
+  const int lrow = lane & 31, hi = lane >> 5;
+  const int qidx = q0 + lrow;
+
+  // Q fragments (B operand): Q[query = lrow][d = 16ks + 8hi .. +7]
+  u32x4 qf[4];
+  {
+    const bf16_t* qr = base + (size_t)(qidx < S ? qidx : S - 1) * ld + 8 * hi;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const u32x4*>(qr + 16 * ks);
+  }
+
+  // scores^T tiles
+  f32x16 sc[KT];
+  const unsigned long long m0 = mk[0], m1 = mk[1];
+  float rmax = -INFINITY;
+#pragma unroll
+  for (int t = 0; t < KT; ++t) {
+    const bool live = !(causal && 32 * t > q0 + 31);  // wave-uniform: tile entirely above the diagonal
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sc[t][r] = 0.f;
+    if (live) {
+      const int krow = 32 * t + lrow;
+      const bf16_t* kr = base + (size_t)(krow < S ? krow : S - 1) * ld + D + 8 * hi;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const u32x4 kf = *reinterpret_cast<const u32x4*>(kr + 16 * ks);
+        sc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf), __builtin_bit_cast(bf16x8, qf[ks]),
+                                                        sc[t], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      const unsigned long long word = key < 64 ? m0 : m1;
+      const bool ok = live && ((word >> (key & 63)) & 1ull) && (!causal || key <= qidx);
+      sc[t][r] = ok ? sc[t][r] : -INFINITY;
+      rmax = fmaxf(rmax, sc[t][r]);
+    }
+  }
+  rmax = fmaxf(rmax, __shfl_xor(rmax, 32, 64));
+  const float m_use = (rmax == -INFINITY) ? 0.f : rmax;
+  float rsum = 0.f;
+#pragma unroll
+  for (int t = 0; t < KT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      sc[t][r] = __expf(sc[t][r] - m_use);
+      rsum += sc[t][r];
+    }
+  rsum += __shfl_xor(rsum, 32, 64);
+
+  // O^T = V^T P^T
+  f32x16 acc[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[dt][r] = 0.f;
+#pragma unroll
+  for (int t = 0; t < KT; ++t) {
+    if (causal && 32 * t > q0 + 31) continue;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      bf16x8 pf;
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) pf[jj] = (bf16_t)sc[t][8 * s2 + jj];
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const bf16_t* vr = Vt + (dt * 32 + lrow) * VLD + 32 * t + 16 * s2 + 4 * hi;
+        const u32x2 v0 = *reinterpret_cast<const u32x2*>(vr);
+        const u32x2 v1 = *reinterpret_cast<const u32x2*>(vr + 8);
+        const u32x4 vf = {v0[0], v0[1], v1[0], v1[1]};
+        acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf), pf, acc[dt], 0, 0, 0);
+      }
+    }
+  }
+  if (qidx < S) {
+    const float inv = 1.0f / rsum;
+    bf16_t* orow = out + ((size_t)b * S + qidx) * D + h * 64;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4)
+        store4(orow + dt * 32 + 8 * q4 + 4 * hi, acc[dt][4 * q4 + 0] * inv, acc[dt][4 * q4 + 1] * inv,
+               acc[dt][4 * q4 + 2] * inv, acc[dt][4 * q4 + 3] * inv);
+  }
 }
+
+hipError_t launch_attention_mfma(const void* qkv, void* out, int B, int S, int H, int causal, const int64_t* key_mask,
+                                 hipStream_t s) {
+  if (S > 128 || S <= 0) return hipErrorNotSupported;
+  const int KT = (S + 31) / 32;
+  const dim3 grid(B * H), block(64 * KT);
+#define PLIPMI_ATT(K) \
+  hipLaunchKernelGGL(attention_mfma_kernel<K>, grid, block, 0, s, (const bf16_t*)qkv, (bf16_t*)out, S, H, causal, key_mask)
+  switch (KT) {
+    case 1: PLIPMI_ATT(1); break;
+    case 2: PLIPMI_ATT(2); break;
+    case 3: PLIPMI_ATT(3); break;
+    default: PLIPMI_ATT(4); break;
+  }
+#undef PLIPMI_ATT
+  return hipGetLastError();
+}
+
 }  // namespace plipmi

@@ -21,6 +21,10 @@
 #include "gemm.h"
 #include "kernels.h"
 
+#ifndef PLIPMI_DEFAULT_ATTENTION
+#define PLIPMI_DEFAULT_ATTENTION 0
+#endif
+
 using namespace plipmi;
 
 static thread_local char g_err[512] = "";
@@ -72,7 +76,7 @@ struct plipmi_engine {
   float *tok = nullptr, *tpos = nullptr, *fin_w = nullptr, *fin_b = nullptr, *tproj_t = nullptr;
   char* slab = nullptr;
   size_t slab_bytes = 0;
-  int attn_impl = 0;
+  int attn_impl = 0, attn_impl_vis = 0, attn_impl_txt = 0;
   char devname[128] = "";
   // profiling
   bool prof = false;
@@ -203,9 +207,10 @@ int run_layers(plipmi_engine* e, Tower& t, int B, int n_layers, int causal, cons
     { Scope sc(e, s, "layernorm", 0, (double)M * D * (4 + e->esz));
       HIP_TRY(launch_layernorm(t.x, D, w.ln1w, w.ln1b, t.h, e->dtype, M, D, eps, s)); }
     RUN(run_gemm(e, EPI_BIAS, t.h, w.wqkv, t.qkv, w.bqkv, M, 3 * D, D, 3 * D, 0, s));
-    { Scope sc(e, s, e->attn_impl ? "attention_mfma" : "attention_valu", 4.0 * B * t.H * (double)t.S * t.S * 64,
+    { const int impl = (&t == &e->vis) ? e->attn_impl_vis : e->attn_impl_txt;
+      Scope sc(e, s, impl ? "attention_mfma" : "attention_valu", 4.0 * B * t.H * (double)t.S * t.S * 64,
                (double)M * 4 * D * e->esz);
-      HIP_TRY(launch_attention(t.qkv, t.att, e->dtype, B, t.S, t.H, causal, key_mask, e->attn_impl, s)); }
+      HIP_TRY(launch_attention(t.qkv, t.att, e->dtype, B, t.S, t.H, causal, key_mask, impl, s)); }
     RUN(run_gemm(e, EPI_BIAS_RESID, t.att, w.wo, t.x, w.bo, M, D, D, D, 0, s));
     { Scope sc(e, s, "layernorm", 0, (double)M * D * (4 + e->esz));
       HIP_TRY(launch_layernorm(t.x, D, w.ln2w, w.ln2b, t.h, e->dtype, M, D, eps, s)); }
@@ -286,9 +291,13 @@ int plipmi_create(const plipmi_config* cfg, const plipmi_weights* w, void* strea
   snprintf(e->devname, sizeof(e->devname), "%s:%s", prop.gcnArchName, prop.name);
   e->vis.D = g.v_width; e->vis.F = g.v_mlp; e->vis.L = g.v_layers; e->vis.H = g.v_heads; e->vis.S = tokens;
   e->txt.D = g.t_width; e->txt.F = g.t_mlp; e->txt.L = g.t_layers; e->txt.H = g.t_heads; e->txt.S = g.context_length;
+  // attention kernel: exact-fp32 VALU kernel for the fp32 engine and for sequences > 128 tokens,
+  // bf16 MFMA kernel otherwise (PLIPMI_ATTENTION=0/1 forces one for A/B runs)
   const char* ai = getenv("PLIPMI_ATTENTION");
-  e->attn_impl = ai ? atoi(ai) : 0;
+  e->attn_impl = ai ? atoi(ai) : PLIPMI_DEFAULT_ATTENTION;
   if (e->dtype != PLIPMI_BF16) e->attn_impl = 0;
+  e->attn_impl_txt = (e->attn_impl && g.context_length <= 128) ? 1 : 0;
+  e->attn_impl_vis = (e->attn_impl && tokens <= 128) ? 1 : 0;
 
   Carver sizing;
   carve(e, sizing);
@@ -421,6 +430,15 @@ int plipmi_gemm_nt(int dtype, int epilogue, int variant, int M, int N, int K, co
   const int rc = gemm_launch(dtype, epilogue, variant, p, reinterpret_cast<hipStream_t>(stream), nullptr);
   if (rc != 0) return fail(PLIPMI_ERR_HIP, "gemm launch failed (variant %d, M=%d N=%d K=%d): %s", variant, M, N, K,
                            hipGetErrorString((hipError_t)rc));
+  return PLIPMI_OK;
+}
+
+int plipmi_attention(int dtype, int impl, const void* qkv, void* out, int B, int S, int H, int causal,
+                     const int64_t* key_mask, void* stream) {
+  if ((dtype != PLIPMI_F32 && dtype != PLIPMI_BF16) || !qkv || !out || B < 0 || S <= 0 || H <= 0)
+    return fail(PLIPMI_ERR_INVALID, "bad argument");
+  hipError_t e = launch_attention(qkv, out, dtype, B, S, H, causal, key_mask, impl, reinterpret_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return fail(PLIPMI_ERR_HIP, "attention launch (impl %d, S=%d) failed: %s", impl, S, hipGetErrorString(e));
   return PLIPMI_OK;
 }
 

@@ -228,6 +228,19 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = Non
     return out
 
 
+def attention(qkv: torch.Tensor, B: int, S: int, H: int, causal: bool = False, key_mask: Optional[torch.Tensor] = None,
+              impl: int = 0) -> torch.Tensor:
+    """Kernel-level entry (tests): qkv [B*S, 3*H*64] (scale folded into q) -> [B*S, H*64]."""
+    lib = _lib.load()
+    assert qkv.is_cuda and qkv.is_contiguous() and qkv.shape == (B * S, 3 * H * 64)
+    code = _lib.BF16 if qkv.dtype == torch.bfloat16 else _lib.F32
+    out = torch.empty((B * S, H * 64), dtype=qkv.dtype, device=qkv.device)
+    with torch.cuda.device(qkv.device):
+        _lib.check(lib.plipmi_attention(code, impl, _ptr(qkv), _ptr(out), B, S, H, int(causal), _ptr(key_mask),
+                                        C.c_void_p(torch.cuda.current_stream(qkv.device).cuda_stream)), "plipmi_attention")
+    return out
+
+
 def gemm_variants():
     lib = _lib.load()
     names, i = [], 0

@@ -104,6 +104,44 @@ def sec_vitb32():
               f"argmax agree {(out.logits_per_image.cpu().numpy().argmax(1) == ref['logits_per_image'].argmax(1)).mean():.3f}")
 
 
+def sec_attn():
+    from plip_amd.engine import attention
+    g = torch.Generator().manual_seed(0)
+    for (B, S, H, causal) in ((3, 50, 12, False), (3, 77, 8, True), (2, 33, 2, True), (1, 128, 2, False)):
+        qkv = torch.randn(B * S, 3 * H * 64, generator=g)
+        qkv[:, : H * 64] *= 0.125 * 3
+        x = qkv.double().reshape(B, S, 3, H, 64)
+        q, k, v = (x[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+        lens = torch.randint(1, S + 1, (B,), generator=g)
+        mask = (torch.arange(S)[None, :] < lens[:, None]).long()
+        for use_mask in (False, True):
+            for mode, dt, impl in (("valu_f32", torch.float32, 0), ("valu_bf16", torch.bfloat16, 0), ("mfma_bf16", torch.bfloat16, 1)):
+                qd = qkv.to(dev).to(dt)
+                xr = qd.double().cpu().reshape(B, S, 3, H, 64)
+                q, k, v = (xr[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+                sc = q @ k.transpose(-1, -2)
+                if causal:
+                    sc = sc.masked_fill(~torch.tril(torch.ones(S, S, dtype=torch.bool)), float("-inf"))
+                if use_mask:
+                    sc = sc.masked_fill(~mask.bool()[:, None, None, :], float("-inf"))
+                ref = (torch.softmax(sc, -1) @ v).permute(0, 2, 1, 3).reshape(B * S, H * 64)
+                try:
+                    out = attention(qd, B, S, H, causal, mask.to(dev) if use_mask else None, impl=impl)
+                    torch.cuda.synchronize()
+                    err = (out.double().cpu() - ref).abs()
+                    print(f"attn {mode:10s} B{B} S{S} H{H} causal={causal} mask={use_mask}: max err {err.max().item():.3e} "
+                          f"nan {int(torch.isnan(out).sum())} bad(>0.05) {int((err > 0.05).sum())}/{err.numel()}")
+                except Exception as e:
+                    print(f"attn {mode} B{B} S{S}: EXC {e}")
+    # timing at production shapes
+    for (B, S, H, causal) in ((256, 50, 12, False), (256, 77, 8, True)):
+        qd = torch.randn(B * S, 3 * H * 64, generator=g).to(dev).to(torch.bfloat16)
+        for impl in (0, 1):
+            ms = _time(lambda: attention(qd, B, S, H, causal, None, impl=impl), iters=20)
+            print(f"attn timing B{B} S{S} H{H} impl {impl}: {ms * 1e3:.1f} us  ({4.0 * B * H * S * S * 64 / ms / 1e9:.1f} TFLOP/s dense-count, "
+                  f"{B * S * 4 * H * 64 * 2 / ms / 1e6:.0f} GB/s)")
+
+
 def _time(fn, iters=30, warm=5):
     for _ in range(warm):
         fn()
@@ -170,5 +208,5 @@ def sec_e2e():
 
 if __name__ == "__main__":
     t0 = time.time()
-    {"gemm": sec_gemm, "tiny": sec_tiny, "vitb32": sec_vitb32, "gemmbench": sec_gemmbench, "e2e": sec_e2e}[sys.argv[1]]()
+    {"gemm": sec_gemm, "attn": sec_attn, "tiny": sec_tiny, "vitb32": sec_vitb32, "gemmbench": sec_gemmbench, "e2e": sec_e2e}[sys.argv[1]]()
     print(f"[{sys.argv[1]} done in {time.time() - t0:.1f} s]")
