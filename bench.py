@@ -43,14 +43,36 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="lower bound of CPU work for the baseline sample")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--overlap", type=int, default=1, help="1: text tower on a second HIP stream (default), 0: one stream")
     return ap.parse_args()
+
+
+def usable_cores() -> int:
+    """Host cores this process may actually run on: affinity mask, capped by the cgroup CPU quota.
+    (os.cpu_count() reports every core of the node; asking torch for 256 threads inside a container
+    that is throttled to a few CPUs makes the CPU baseline 100x slower than it should be.)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                q, per = int(f.read()), int(g.read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return max(1, min(n, 64))      # torch CPU GEMMs stop scaling (and oversubscribe) far below a full 2-socket node
 
 
 def cpu_baseline(cfg, sd, seconds):
     """The reference's own forward (HF CLIPModel, what plip.py:50,68 call) on the host cores of
     THIS box, same synthetic weights, bounded sample.  Falls back to the numpy oracle ("port")."""
     from plip_amd import weights as W
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     B = 32
     px = W.synthetic_pixels(cfg, B, seed=1)
     ids, mask = W.synthetic_ids(cfg, B, seed=2)
@@ -76,7 +98,7 @@ def cpu_baseline(cfg, sd, seconds):
         run()
         n += 1
         el = time.perf_counter() - t0
-        if el >= seconds and n >= 2:
+        if (el >= seconds and n >= 2) or el >= 3 * seconds:
             break
     cpu_name = ""
     try:
@@ -122,7 +144,7 @@ def main():
     ids, mask = torch.from_numpy(ids_np).to(dev), torch.from_numpy(mask_np).to(dev)
 
     def step():
-        return sharded_pair_logits(model, px, ids, mask)
+        return sharded_pair_logits(model, px, ids, mask, overlap=bool(args.overlap))
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -188,7 +210,7 @@ def main():
                                f"{args.dtype} MFMA / fp32 accumulate (BASELINE.json configs[2])",
                    "arch": args.arch, "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
                    "collective": "none" if world == 1 else "RCCL all-gather of [B,512] fp32 image+text embeddings",
-                   "device": model.engine.device_name},
+                   "streams": 2 if args.overlap else 1, "device": model.engine.device_name},
         "algorithmic_tflops": round(value * cfg.pair_flops() / 1e12, 2),
         "roofline": roofline,
         "kernels": kernels,

@@ -22,7 +22,7 @@
 #include "kernels.h"
 
 #ifndef PLIPMI_DEFAULT_ATTENTION
-#define PLIPMI_DEFAULT_ATTENTION 0
+#define PLIPMI_DEFAULT_ATTENTION 1
 #endif
 
 using namespace plipmi;
@@ -74,6 +74,8 @@ struct plipmi_engine {
   float *cls = nullptr, *vpos = nullptr, *pre_w = nullptr, *pre_b = nullptr, *post_w = nullptr, *post_b = nullptr,
         *vproj_t = nullptr;
   float *tok = nullptr, *tpos = nullptr, *fin_w = nullptr, *fin_b = nullptr, *tproj_t = nullptr;
+  float *vproj = nullptr, *tproj = nullptr;        // [P, D] fp32, the HF layout (NT GEMM operand)
+  float *vpooled = nullptr, *tpooled = nullptr;    // [max_batch, D] fp32 LayerNorm'd pooled rows
   char* slab = nullptr;
   size_t slab_bytes = 0;
   int attn_impl = 0, attn_impl_vis = 0, attn_impl_txt = 0;
@@ -136,6 +138,10 @@ void carve(plipmi_engine* e, Carver& c) {
   e->tpos = c.take<float>((size_t)g.context_length * g.t_width, 4);
   e->fin_w = c.take<float>(g.t_width, 4);  e->fin_b = c.take<float>(g.t_width, 4);
   e->tproj_t = c.take<float>((size_t)g.t_width * g.projection_dim, 4);
+  e->vproj = c.take<float>((size_t)g.v_width * g.projection_dim, 4);
+  e->tproj = c.take<float>((size_t)g.t_width * g.projection_dim, 4);
+  e->vpooled = c.take<float>(B * g.v_width, 4);
+  e->tpooled = c.take<float>(B * g.t_width, 4);
   for (Tower* t : {&e->vis, &e->txt}) {
     const size_t D = t->D, F = t->F;
     t->layers.resize(t->L);
@@ -241,6 +247,30 @@ int text_embed(plipmi_engine* e, const int64_t* ids, int B, hipStream_t s) {
   return PLIPMI_OK;
 }
 
+// pooled row -> LayerNorm -> bias-free projection (-> L2 normalise).  Real heads (P % 128 == 0) run the
+// projection on the exact-fp32 MFMA GEMM; other widths use the fused one-block-per-sample kernel.
+int run_head(plipmi_engine* e, Tower& t, const int64_t* ids, int eos_id, const float* ln_w, const float* ln_b,
+             const float* W, const float* Wt, float* pooled, float* out, int B, int normalize, hipStream_t s) {
+  const int P = e->cfg.projection_dim, D = t.D;
+  if (P % 128 == 0) {
+    { Scope sc(e, s, "pool_layernorm", 0, (double)B * D * 8);
+      HIP_TRY(launch_pool_layernorm(t.x, t.S, D, ids, eos_id, ln_w, ln_b, e->cfg.layer_norm_eps, pooled, B, s)); }
+    GemmParams p;
+    p.A = pooled; p.W = W; p.C = out; p.bias = nullptr; p.M = B; p.N = P; p.K = D; p.lda = D; p.ldw = D; p.ldc = P;
+    p.alpha = 1.f; p.np = 1;
+    const char* name = "gemm_nt";
+    { Scope sc(e, s, name, 2.0 * B * P * (double)D, ((double)B * D + (double)P * D + (double)B * P) * 4);
+      const int rc = gemm_launch(PLIPMI_F32, EPI_SCALE, 1, p, s, &name);
+      sc.rename(name);
+      if (rc != 0) return fail(PLIPMI_ERR_HIP, "projection gemm failed: %s", hipGetErrorString((hipError_t)rc)); }
+    if (normalize) { Scope sc(e, s, "l2_normalize", 0, (double)B * P * 8); HIP_TRY(launch_l2_normalize(out, B, P, s)); }
+    return PLIPMI_OK;
+  }
+  Scope sc(e, s, "pool_head", 2.0 * B * D * P, (double)D * P * 4);
+  HIP_TRY(launch_pool_head(t.x, t.S, D, ids, eos_id, ln_w, ln_b, e->cfg.layer_norm_eps, Wt, P, out, B, normalize, s));
+  return PLIPMI_OK;
+}
+
 int check_batch(plipmi_engine* e, int B) {
   if (!e) return fail(PLIPMI_ERR_INVALID, "null handle");
   if (B < 0 || B > e->cfg.max_batch)
@@ -324,6 +354,8 @@ int plipmi_create(const plipmi_config* cfg, const plipmi_weights* w, void* strea
     HIP_TRY(launch_scale_copy(w->v_post_ln_w, e->post_w, Dv, 1.f, s));
     HIP_TRY(launch_scale_copy(w->v_post_ln_b, e->post_b, Dv, 1.f, s));
     HIP_TRY(launch_transpose(w->visual_projection, e->vproj_t, P, Dv, s));
+    HIP_TRY(launch_scale_copy(w->visual_projection, e->vproj, P * Dv, 1.f, s));
+    HIP_TRY(launch_scale_copy(w->text_projection, e->tproj, P * Dt, 1.f, s));
     HIP_TRY(hipMemcpyAsync(e->tok, w->t_token_embedding, (size_t)g.vocab_size * Dt * 4, hipMemcpyDeviceToDevice, s));
     HIP_TRY(launch_scale_copy(w->t_pos_embedding, e->tpos, g.context_length * Dt, 1.f, s));
     HIP_TRY(launch_scale_copy(w->t_final_ln_w, e->fin_w, Dt, 1.f, s));
@@ -358,10 +390,7 @@ int plipmi_encode_image(plipmi_handle h, const float* pixels, int B, float* out,
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   RUN(vision_embed(h, pixels, B, s));
   RUN(run_layers(h, h->vis, B, h->vis.L, 0, nullptr, s));
-  Scope sc(h, s, "pool_head", 2.0 * B * h->vis.D * h->cfg.projection_dim, (double)h->vis.D * h->cfg.projection_dim * 4);
-  HIP_TRY(launch_pool_head(h->vis.x, h->vis.S, h->vis.D, nullptr, -1, h->post_w, h->post_b, h->cfg.layer_norm_eps,
-                           h->vproj_t, h->cfg.projection_dim, out, B, normalize, s));
-  return PLIPMI_OK;
+  return run_head(h, h->vis, nullptr, -1, h->post_w, h->post_b, h->vproj, h->vproj_t, h->vpooled, out, B, normalize, s);
 }
 
 int plipmi_encode_text(plipmi_handle h, const int64_t* ids, const int64_t* attention_mask, int B, int eos_token_id,
@@ -372,10 +401,7 @@ int plipmi_encode_text(plipmi_handle h, const int64_t* ids, const int64_t* atten
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   RUN(text_embed(h, ids, B, s));
   RUN(run_layers(h, h->txt, B, h->txt.L, 1, attention_mask, s));
-  Scope sc(h, s, "pool_head", 2.0 * B * h->txt.D * h->cfg.projection_dim, (double)h->txt.D * h->cfg.projection_dim * 4);
-  HIP_TRY(launch_pool_head(h->txt.x, h->txt.S, h->txt.D, ids, eos_token_id, h->fin_w, h->fin_b, h->cfg.layer_norm_eps,
-                           h->tproj_t, h->cfg.projection_dim, out, B, normalize, s));
-  return PLIPMI_OK;
+  return run_head(h, h->txt, ids, eos_token_id, h->fin_w, h->fin_b, h->tproj, h->tproj_t, h->tpooled, out, B, normalize, s);
 }
 
 int plipmi_debug_hidden(plipmi_handle h, int tower, int layer, const void* input, int B, float* out, void* stream) {

@@ -26,8 +26,15 @@ int gemm_default_variant(int dtype, int M, int N, int K) {
     if (g_override >= 0 && N % kVariants[g_override].bn != 0) return 1;
     return g_override;
   }
-  (void)dtype; (void)M; (void)K;
-  // Round-1 default: the 128x128 LDS-DMA tile (2 blocks/CU); re-tuned from bench data.
+  // Tuned on MI355X (profiles/r01_run1_gemm_variants_tflops.txt): the 256x256 LDS-DMA tile wins whenever N is
+  // wide or K is long (fewer L2->LDS bytes per FLOP); the short-K, narrow-N out-projections and small M
+  // prefer the 128x128 tile at two workgroups per CU.
+  if (M <= 1024) return 1;
+  if (dtype == 1) {
+    if (N % 256 == 0 && (N >= 1536 || K >= 1536)) return 5;
+    return 1;
+  }
+  if (N % 256 == 0 && N >= 1536 && K <= 1024) return 5;
   return 1;
 }
 

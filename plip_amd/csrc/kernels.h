@@ -28,6 +28,11 @@ hipError_t launch_pool_head(const float* x, int S, int D, const int64_t* ids, in
                             const float* ln_b, float eps, const float* Wt, int P, float* out, int B, int normalize,
                             hipStream_t s);
 
+// Pooled row (CLS, or the EOS row of each caption) -> LayerNorm -> fp32 [B, D]; the projection itself then
+// runs on the fp32 MFMA GEMM (used when P % 128 == 0, i.e. every real CLIP/PLIP head).
+hipError_t launch_pool_layernorm(const float* x, int S, int D, const int64_t* ids, int eos_id, const float* ln_w,
+                                 const float* ln_b, float eps, float* out, int B, hipStream_t s);
+
 hipError_t launch_l2_normalize(float* x, int N, int D, hipStream_t s);
 
 // logits_per_image[i,j] = scale*<img_i,txt_j>; optional transpose output and per-row first arg-max.

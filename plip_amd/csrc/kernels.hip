@@ -251,6 +251,75 @@ hipError_t launch_pool_head(const float* x, int S, int D, const int64_t* ids, in
   return hipGetLastError();
 }
 
+// EOS row of a caption (modeling_clip.py:561-581), evaluated by one wavefront
+__device__ __forceinline__ int eos_position(const int64_t* row, int S, int eos_id, int lane) {
+  if (eos_id >= 0 && eos_id != 2) {  // first position holding eos_token_id, 0 if absent
+    int best = INT_MAX;
+    for (int s = lane; s < S; s += 64)
+      if ((int)row[s] == eos_id) best = min(best, s);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) best = min(best, __shfl_xor(best, o, 64));
+    return best == INT_MAX ? 0 : best;
+  }
+  int mx = INT_MIN;  // legacy rule: first arg-max of the ids
+  for (int s = lane; s < S; s += 64) mx = max(mx, (int)row[s]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o, 64));
+  int best = INT_MAX;
+  for (int s = lane; s < S; s += 64)
+    if ((int)row[s] == mx) best = min(best, s);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) best = min(best, __shfl_xor(best, o, 64));
+  return best;
+}
+
+// one wavefront per sample: pick the pooled row, LayerNorm it, write fp32 [B, D]
+__global__ __launch_bounds__(256) void pool_layernorm_kernel(const float* __restrict__ x, int S, int D,
+                                                             const int64_t* __restrict__ ids, int eos_id,
+                                                             const float* __restrict__ g, const float* __restrict__ b,
+                                                             float eps, float* __restrict__ out, int B) {
+  const int lane = threadIdx.x & 63;
+  const int smp = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (smp >= B) return;
+  const int pos = ids ? eos_position(ids + (size_t)smp * S, S, eos_id, lane) : 0;
+  const float* xr = x + ((size_t)smp * S + pos) * D;
+  float4 v[kLnMaxVec];
+  float s = 0.f;
+#pragma unroll
+  for (int it = 0; it < kLnMaxVec; ++it) {
+    const int idx = it * 256 + lane * 4;
+    if (idx < D) { v[it] = *reinterpret_cast<const float4*>(xr + idx); s += (v[it].x + v[it].y) + (v[it].z + v[it].w); }
+  }
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int it = 0; it < kLnMaxVec; ++it) {
+    const int idx = it * 256 + lane * 4;
+    if (idx < D) {
+      const float a = v[it].x - mean, c = v[it].y - mean, d = v[it].z - mean, e = v[it].w - mean;
+      q += (a * a + c * c) + (d * d + e * e);
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+  float* yr = out + (size_t)smp * D;
+#pragma unroll
+  for (int it = 0; it < kLnMaxVec; ++it) {
+    const int idx = it * 256 + lane * 4;
+    if (idx < D) {
+      const float4 gg = *reinterpret_cast<const float4*>(g + idx), bb = *reinterpret_cast<const float4*>(b + idx);
+      store4(yr + idx, (v[it].x - mean) * rstd * gg.x + bb.x, (v[it].y - mean) * rstd * gg.y + bb.y,
+             (v[it].z - mean) * rstd * gg.z + bb.z, (v[it].w - mean) * rstd * gg.w + bb.w);
+    }
+  }
+}
+hipError_t launch_pool_layernorm(const float* x, int S, int D, const int64_t* ids, int eos_id, const float* ln_w,
+                                 const float* ln_b, float eps, float* out, int B, hipStream_t s) {
+  if (B <= 0) return hipSuccess;
+  if (D % 4 || D > kLnMaxVec * 256) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(pool_layernorm_kernel, dim3((B + 3) / 4), dim3(256), 0, s, x, S, D, ids, eos_id, ln_w, ln_b, eps, out, B);
+  return hipGetLastError();
+}
+
 // x / sqrt(sum x^2), no epsilon (modeling_clip.py:57-65; plip.py:75)
 __global__ __launch_bounds__(256) void l2_normalize_kernel(float* __restrict__ x, int N, int D) {
   const int lane = threadIdx.x & 63;

@@ -49,7 +49,7 @@ def all_gather_rows(local: torch.Tensor, group=None) -> torch.Tensor:
 
 
 def sharded_pair_logits(model, pixels_local: torch.Tensor, ids_local: torch.Tensor,
-                        attention_mask_local: Optional[torch.Tensor] = None, group=None):
+                        attention_mask_local: Optional[torch.Tensor] = None, group=None, overlap: bool = True):
     """One data-parallel step of CLIPModel.forward: this rank embeds ITS images and captions,
     the normalised embeddings are all-gathered, and the rank computes its row block of
     ``logits_per_image`` ([n_local, N_text]) against every caption of the global batch.
@@ -57,8 +57,11 @@ def sharded_pair_logits(model, pixels_local: torch.Tensor, ids_local: torch.Tens
     Returns ``(logits_rows, image_embeds_all, text_embeds_all)``.
     """
     eng = model.engine
-    img = eng.encode_image(pixels_local, normalize=True)
-    txt = eng.encode_text(ids_local, attention_mask_local, normalize=True)
+    if hasattr(eng, "encode_pair"):
+        img, txt = eng.encode_pair(pixels_local, ids_local, attention_mask_local, normalize=True, overlap=overlap)
+    else:
+        img = eng.encode_image(pixels_local, normalize=True)
+        txt = eng.encode_text(ids_local, attention_mask_local, normalize=True)
     txt_all = all_gather_rows(txt, group)
     img_all = all_gather_rows(img, group)
     lpi, _, _ = eng.logits(img, txt_all, scale=eng.logit_scale_exp, want_text=False)

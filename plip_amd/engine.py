@@ -144,6 +144,25 @@ class Engine:
                            "plipmi_encode_text")
         return out
 
+    def encode_pair(self, pixels: torch.Tensor, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
+                    normalize: bool = True, overlap: bool = True):
+        """Both towers of one step.  With ``overlap`` the text tower is enqueued on a second HIP stream:
+        the towers are independent (separate workspaces), so the tail of one tower's GEMM grid -- 150..600
+        workgroups over 256 CUs -- is filled by the other tower's kernels instead of idling."""
+        if not overlap:
+            return self.encode_image(pixels, normalize), self.encode_text(input_ids, attention_mask, normalize)
+        main = torch.cuda.current_stream(self.device)
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        side = self._side
+        side.wait_stream(main)                      # inputs produced on the main stream are ready
+        with torch.cuda.stream(side):
+            txt = self.encode_text(input_ids, attention_mask, normalize)
+        img = self.encode_image(pixels, normalize)
+        main.wait_stream(side)
+        txt.record_stream(main)
+        return img, txt
+
     def l2_normalize_(self, x: torch.Tensor) -> torch.Tensor:
         assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 2
         with torch.cuda.device(self.device):

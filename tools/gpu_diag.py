@@ -179,6 +179,41 @@ def sec_gemmbench():
             print(f"{name:8s} {M:6d}x{N:5d}x{K:5d} epi{epi}: " + " ".join(row))
 
 
+def sec_gemmone():
+    """One variant / one shape in a loop -- the target of rocprofv3 --pmc runs.
+    usage: gpu_diag.py gemmone <variant> <M> <N> <K> <epi> [bf16|f32] [iters]"""
+    v, M, N, K, epi = (int(x) for x in sys.argv[2:7])
+    dtype = torch.float32 if (len(sys.argv) > 7 and sys.argv[7] == "f32") else torch.bfloat16
+    iters = int(sys.argv[8]) if len(sys.argv) > 8 else 20
+    g = torch.Generator().manual_seed(0)
+    a = torch.randn(M, K, generator=g).to(dev).to(dtype)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev).to(dtype)
+    bias = torch.randn(N, generator=g).to(dev)
+    out = torch.zeros(M, N, device=dev, dtype=dtype if epi in (0, 1) else torch.float32)
+    ms = _time(lambda: gemm_nt(a, w, bias, epilogue=epi, variant=v, out=out), iters=iters, warm=3)
+    print(f"gemmone variant {v} {M}x{N}x{K} epi{epi} {dtype}: {ms * 1e3:.1f} us  {2.0 * M * N * K / ms / 1e9:.1f} TFLOP/s")
+
+
+def sec_overlap():
+    """One-stream vs two-stream step time at bs=256 (bf16)."""
+    from plip_amd.dist import sharded_pair_logits
+    cfg = get_config("ViT-B/32")
+    sd = W.synthetic_state_dict(cfg, 0)
+    B = 256
+    px = torch.from_numpy(W.synthetic_pixels(cfg, B, 1)).to(dev)
+    ids_np, mask_np = W.synthetic_ids(cfg, B, 2)
+    ids, mask = torch.from_numpy(ids_np).to(dev), torch.from_numpy(mask_np).to(dev)
+    model = PlipModel(cfg, sd, dtype="bf16", max_batch=B)
+    for rep in range(2):
+        for ov in (False, True):
+            ms = _time(lambda: sharded_pair_logits(model, px, ids, mask, overlap=ov), iters=20, warm=3)
+            print(f"overlap={ov}: {ms:.3f} ms/step  {B / ms * 1e3:.0f} pairs/s")
+    a = sharded_pair_logits(model, px, ids, mask, overlap=False)[0]
+    b = sharded_pair_logits(model, px, ids, mask, overlap=True)[0]
+    torch.cuda.synchronize()
+    print("bitwise equal one-stream vs two-stream:", bool(torch.equal(a, b)))
+
+
 def sec_e2e():
     cfg = get_config("ViT-B/32")
     sd = W.synthetic_state_dict(cfg, 0)
@@ -208,5 +243,6 @@ def sec_e2e():
 
 if __name__ == "__main__":
     t0 = time.time()
-    {"gemm": sec_gemm, "attn": sec_attn, "tiny": sec_tiny, "vitb32": sec_vitb32, "gemmbench": sec_gemmbench, "e2e": sec_e2e}[sys.argv[1]]()
+    {"gemm": sec_gemm, "attn": sec_attn, "tiny": sec_tiny, "vitb32": sec_vitb32, "gemmbench": sec_gemmbench, "e2e": sec_e2e, "gemmone": sec_gemmone,
+     "overlap": sec_overlap}[sys.argv[1]]()
     print(f"[{sys.argv[1]} done in {time.time() - t0:.1f} s]")
