@@ -165,6 +165,10 @@ int plipmi_debug_hidden(plipmi_handle h, int tower, int layer, const void* input
 int plipmi_gemm_nt(int dtype, int epilogue, int variant, int M, int N, int K, const void* A, const void* W,
                    const float* bias, float alpha, void* C, void* stream);
 const char* plipmi_gemm_variant_name(int variant);
+/* same call with an in-kernel timeline: trace = device buffer of 8 x uint64 per workgroup
+ * {start, prologue done, main loop done, epilogue done (s_memtime ticks), tile id, HW_ID|XCC_ID<<32, k tiles, 0} */
+int plipmi_gemm_nt_traced(int dtype, int epilogue, int variant, int M, int N, int K, const void* A, const void* W,
+                          const float* bias, float alpha, void* C, uint64_t* trace, void* stream);
 
 /* Kernel-level entry for the attention kernels: out[B*S, H*64] = softmax(q k^T + masks) v over the fused
  * activation qkv [B*S, 3*H*64] (q | k | v, 1/sqrt(64) already folded into q).

@@ -51,6 +51,9 @@ struct GemmParams {
   int lda, ldw, ldc;  // in elements
   float alpha;
   int np;             // patches per image (EPI_PATCH)
+  // test hook (plipmi_gemm_nt_traced): per workgroup 8 x u64 {start, prologue done, main loop done, epilogue
+  // done, logical tile id, HW_ID, k tiles, 0}, s_memtime ticks.  nullptr on the product path.
+  unsigned long long* trace = nullptr;
 };
 
 // LDS-DMA (global_load_lds_dwordx4): each lane's 16 bytes at `gsrc` land at
@@ -262,9 +265,18 @@ void gemm_nt_kernel(const GemmParams p) {                                       
 
   // ---- main loop: tile kt+1 streams in while tile kt is multiplied; one barrier per tile.
   const int KT = p.K / BK;
+  unsigned long long* trace = p.trace ? p.trace + (size_t)bid * 8 : nullptr;
+  if (trace && tid == 0) {
+    trace[0] = __builtin_amdgcn_s_memtime();
+    trace[4] = lid;
+    trace[5] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4 /* HW_ID [31:0] */) |
+               ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20 /* XCC_ID [3:0] */) << 32);
+    trace[6] = KT;
+  }
   stage_issue(0);
   stage_commit(0);
   __syncthreads();
+  if (trace && tid == 0) trace[1] = __builtin_amdgcn_s_memtime();
   for (int kt = 0; kt < KT - 1; ++kt) {
     const int cur = kt & 1;
     stage_issue(cur ^ 1);
@@ -273,6 +285,7 @@ void gemm_nt_kernel(const GemmParams p) {                                       
     __syncthreads();
   }
   compute((KT - 1) & 1);
+  if (trace && tid == 0) trace[2] = __builtin_amdgcn_s_memtime();
 
   // ---- epilogue: acc[i][j][4q+e] = C[m = .. + lrow][n = .. + 8q + 4*lgrp + e] ----
 #pragma unroll
@@ -291,6 +304,10 @@ void gemm_nt_kernel(const GemmParams p) {                                       
                                     acc[i][j][4 * q + 3], add[q]);
       }
     }
+  }
+  if (trace) {
+    __builtin_amdgcn_s_waitcnt(0);  // stores issued and acknowledged before the stamp
+    if (tid == 0) trace[3] = __builtin_amdgcn_s_memtime();
   }
 }
 

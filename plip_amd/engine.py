@@ -230,7 +230,8 @@ class Engine:
 
 
 def gemm_nt(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, epilogue: int = 0,
-            variant: int = -1, alpha: float = 1.0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+            variant: int = -1, alpha: float = 1.0, out: Optional[torch.Tensor] = None,
+            trace: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Kernel-level entry (tests / micro-bench): epilogue(A[M,K] @ W[N,K]^T); a, w fp32 or bf16 CUDA tensors."""
     lib = _lib.load()
     assert a.is_cuda and w.is_cuda and a.dtype == w.dtype and a.is_contiguous() and w.is_contiguous()
@@ -241,8 +242,9 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = Non
         odt = a.dtype if epilogue in (0, 1) else torch.float32
         out = torch.zeros((M, N), dtype=odt, device=a.device)
     with torch.cuda.device(a.device):
-        _lib.check(lib.plipmi_gemm_nt(code, epilogue, variant, M, N, K, _ptr(a), _ptr(w), _ptr(bias), float(alpha),
-                                      _ptr(out), C.c_void_p(torch.cuda.current_stream(a.device).cuda_stream)),
+        _lib.check(lib.plipmi_gemm_nt_traced(code, epilogue, variant, M, N, K, _ptr(a), _ptr(w), _ptr(bias), float(alpha),
+                                             _ptr(out), _ptr(trace),
+                                             C.c_void_p(torch.cuda.current_stream(a.device).cuda_stream)),
                    "plipmi_gemm_nt")
     return out
 

@@ -194,6 +194,53 @@ def sec_gemmone():
     print(f"gemmone variant {v} {M}x{N}x{K} epi{epi} {dtype}: {ms * 1e3:.1f} us  {2.0 * M * N * K / ms / 1e9:.1f} TFLOP/s")
 
 
+def sec_gemmtrace():
+    """In-kernel timeline of one GEMM launch: where a workgroup's lifetime goes.
+    usage: gpu_diag.py gemmtrace <variant> <M> <N> <K> <epi>"""
+    v, M, N, K, epi = (int(x) for x in sys.argv[2:7]) if len(sys.argv) > 6 else (5, 12800, 3072, 768, 1)
+    g = torch.Generator().manual_seed(0)
+    dtype = torch.bfloat16
+    a = torch.randn(M, K, generator=g).to(dev).to(dtype)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev).to(dtype)
+    bias = torch.randn(N, generator=g).to(dev)
+    out = torch.zeros(M, N, device=dev, dtype=dtype if epi in (0, 1) else torch.float32)
+    names = gemm_variants()
+    bm, bn = (int(x) for x in names[v].split("_")[0].split("x"))
+    nblk = ((M + bm - 1) // bm) * (N // bn)
+    for _ in range(3):
+        gemm_nt(a, w, bias, epilogue=epi, variant=v, out=out)
+    tr = torch.zeros(nblk * 8, dtype=torch.int64, device=dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    gemm_nt(a, w, bias, epilogue=epi, variant=v, out=out, trace=tr)
+    e1.record()
+    torch.cuda.synchronize()
+    t = tr.cpu().numpy().reshape(nblk, 8).astype(np.int64)
+    t0 = t[:, 0].min()
+    start, pro, loop, epi_t, end = t[:, 0] - t0, t[:, 1] - t[:, 0], t[:, 2] - t[:, 1], t[:, 3] - t[:, 2], t[:, 3] - t0
+    span = end.max()
+    ms = e0.elapsed_time(e1)
+    tick_us = span / (ms * 1e3)
+    print(f"variant {names[v]} {M}x{N}x{K} epi{epi}: {nblk} workgroups, kernel {ms * 1e3:.1f} us by events "
+          f"({2.0 * M * N * K / ms / 1e9:.0f} TFLOP/s), {span} ticks first-start -> last-end => {tick_us:.1f} ticks/us")
+    q = lambda x: (f"min {x.min() / tick_us:7.2f}  p50 {np.median(x) / tick_us:7.2f}  p90 {np.percentile(x, 90) / tick_us:7.2f}"
+                   f"  max {x.max() / tick_us:7.2f} us")
+    kt = max(1, int(t[0, 6]) - 1)
+    print("  start offset :", q(start))
+    print("  prologue     :", q(pro))
+    print("  main loop    :", q(loop), f"  ({np.median(loop) / tick_us / kt * 1e3:.0f} ns per k-tile, {kt} tiles)")
+    print("  epilogue     :", q(epi_t))
+    print("  lifetime     :", q(t[:, 3] - t[:, 0]))
+    xcc = (t[:, 5] >> 32) & 0xF
+    print("  workgroups per XCC:", np.bincount(xcc, minlength=8).tolist())
+    first_end = end.min()
+    print(f"  workgroups started before the first one ended: {(start < first_end).sum()} (of {nblk})")
+    order = np.argsort(start)
+    for i in list(order[:3]) + list(order[len(order) // 2: len(order) // 2 + 2]) + list(order[-3:]):
+        print(f"    wg {i:4d} tile {t[i, 4]:4d} xcc {xcc[i]} hw_id {t[i, 5] & 0xffffffff:08x}: start {start[i] / tick_us:7.2f} "
+              f"pro {pro[i] / tick_us:6.2f} loop {loop[i] / tick_us:7.2f} epi {epi_t[i] / tick_us:6.2f} us")
+
+
 def sec_overlap():
     """One-stream vs two-stream step time at bs=256 (bf16)."""
     from plip_amd.dist import sharded_pair_logits
@@ -243,6 +290,6 @@ def sec_e2e():
 
 if __name__ == "__main__":
     t0 = time.time()
-    {"gemm": sec_gemm, "attn": sec_attn, "tiny": sec_tiny, "vitb32": sec_vitb32, "gemmbench": sec_gemmbench, "e2e": sec_e2e, "gemmone": sec_gemmone,
+    {"gemm": sec_gemm, "attn": sec_attn, "tiny": sec_tiny, "vitb32": sec_vitb32, "gemmbench": sec_gemmbench, "e2e": sec_e2e, "gemmone": sec_gemmone, "gemmtrace": sec_gemmtrace,
      "overlap": sec_overlap}[sys.argv[1]]()
     print(f"[{sys.argv[1]} done in {time.time() - t0:.1f} s]")
