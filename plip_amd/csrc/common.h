@@ -48,9 +48,10 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // QuickGELU: x * sigmoid(1.702 x)  (transformers/activations.py:117-123)
+// fp32 engine: libm exp + IEEE divide; bf16 engine: v_exp_f32 + v_rcp_f32 (1 ulp), far below bf16 rounding
 template <bool kAccurate> __device__ __forceinline__ float quick_gelu(float x) {
-  float e = kAccurate ? expf(-1.702f * x) : __expf(-1.702f * x);
-  return x / (1.0f + e);
+  if constexpr (kAccurate) return x / (1.0f + expf(-1.702f * x));
+  else return x * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x));
 }
 
 }  // namespace plipmi

@@ -135,7 +135,10 @@ struct EpilogueOp {
 };
 
 // BM x BN block tile, WM x WN waves, each wave a (BM/WM) x (BN/WN) sub-tile of 32x32 MFMA tiles.
-template <typename T, int BM, int BN, int WM, int WN, int EPI, bool GLDS>
+// SCHED 0: fragment reads / MFMAs in compiler order (it sinks every ds_read next to its first use);
+//       1: reads of K-step ks+1 pinned in front of the MFMAs of step ks (register double buffering);
+//       2: as 1, plus s_setprio 1 around each MFMA group.
+template <typename T, int BM, int BN, int WM, int WN, int EPI, bool GLDS, int SCHED = 0>
 __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))  // LDS caps residency at 2 waves/SIMD:
 void gemm_nt_kernel(const GemmParams p) {                                            // let the allocator use 256 VGPRs
   constexpr int NT = WM * WN * 64;
@@ -256,10 +259,14 @@ void gemm_nt_kernel(const GemmParams p) {                                       
         for (int j = 0; j < NI; ++j)
           wf[(ks + 1) & 1][j] = *reinterpret_cast<const u32x4*>(sb + w_tile + j * 32 * 128 + foff[ks + 1]);
       }
+      if constexpr (SCHED >= 1) __builtin_amdgcn_sched_barrier(0);
+      if constexpr (SCHED == 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j) mma16<T>(acc[i][j], wf[ks & 1][j], xf[ks & 1][i]);
+      if constexpr (SCHED == 2) __builtin_amdgcn_s_setprio(0);
+      if constexpr (SCHED >= 1) __builtin_amdgcn_sched_barrier(0);
     }
   };
 
@@ -287,22 +294,50 @@ void gemm_nt_kernel(const GemmParams p) {                                       
   compute((KT - 1) & 1);
   if (trace && tid == 0) trace[2] = __builtin_amdgcn_s_memtime();
 
-  // ---- epilogue: acc[i][j][4q+e] = C[m = .. + lrow][n = .. + 8q + 4*lgrp + e] ----
+  // ---- epilogue -------------------------------------------------------------------------------
+  // The accumulator layout gives a lane ONE output row: acc[i][j][4q+e] = C[m = .. + lrow][n = .. + 8q + 4*lgrp + e].
+  // Stored straight from there every store instruction touches 32 different rows (64 scattered 16-byte
+  // pieces), and the in-kernel timeline showed that costing 22-34k cycles per 256x256 tile -- a third of the
+  // workgroup's lifetime.  So each wave transposes its sub-tile through a private LDS slab (32 rows x 64
+  // columns fp32, row pitch 272 B: conflict-free ds_write_b128) and writes it back ROW-contiguous: 16 lanes
+  // cover 256 B (fp32) / 128 B (bf16) of one row, so loads/stores are whole cache lines.
+  constexpr int SLAB_PITCH = 64 * 4 + 16;
+  constexpr int SLAB_BYTES = 32 * SLAB_PITCH;
+  static_assert(WM * WN * SLAB_BYTES <= 2 * STAGE, "epilogue slabs must fit in the staging buffers");
+  static_assert(NI % 2 == 0, "epilogue handles two 32-column MFMA tiles per slab");
+  __syncthreads();  // every wave is done reading the last K tile: the staging LDS can be reused
+  char* slab = smem + wave * SLAB_BYTES;
+  const int rd_row = lane >> 4, rd_col = (lane & 15) * 4;
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
-    const int m = m0 + wm * TM + i * 32 + lrow;
-    if (m < p.M) {
 #pragma unroll
-      for (int j = 0; j < NI; ++j) {
-        const int nb = n0 + wn * TN + j * 32 + 4 * lgrp;
-        float4 add[4];
+    for (int jp = 0; jp < NI / 2; ++jp) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) add[q] = EpilogueOp<T, EPI>::load(p, m, nb + 8 * q);
+      for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-          EpilogueOp<T, EPI>::store(p, m, nb + 8 * q, acc[i][j][4 * q + 0], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2],
-                                    acc[i][j][4 * q + 3], add[q]);
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 v = {acc[i][2 * jp + jj][4 * q + 0], acc[i][2 * jp + jj][4 * q + 1], acc[i][2 * jp + jj][4 * q + 2],
+                           acc[i][2 * jp + jj][4 * q + 3]};
+          *reinterpret_cast<f32x4*>(slab + lrow * SLAB_PITCH + (jj * 32 + 8 * q + 4 * lgrp) * 4) = v;
+        }
+      __builtin_amdgcn_wave_barrier();  // LDS ops of one wave execute in order; keep the compiler from reordering
+      const int n = n0 + wn * TN + jp * 64 + rd_col;
+      f32x4 v[8];
+      float4 add[8];
+#pragma unroll
+      for (int it = 0; it < 8; ++it)
+        v[it] = *reinterpret_cast<const f32x4*>(slab + (it * 4 + rd_row) * SLAB_PITCH + rd_col * 4);
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {  // unconditional loads from a clamped row: no branches, all in flight together
+        const int m = m0 + wm * TM + i * 32 + it * 4 + rd_row;
+        add[it] = EpilogueOp<T, EPI>::load(p, m < p.M ? m : p.M - 1, n);
       }
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int m = m0 + wm * TM + i * 32 + it * 4 + rd_row;
+        if (m < p.M) EpilogueOp<T, EPI>::store(p, m, n, v[it][0], v[it][1], v[it][2], v[it][3], add[it]);
+      }
+      __builtin_amdgcn_wave_barrier();
     }
   }
   if (trace) {

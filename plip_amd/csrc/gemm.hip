@@ -9,6 +9,8 @@ static const GemmVariant kVariants[kNumVariants] = {
     {"128x128_w2x2_regstage", 128, 128, 256, false}, {"128x128_w2x2_glds", 128, 128, 256, true},
     {"256x128_w4x2_regstage", 256, 128, 512, false}, {"256x128_w4x2_glds", 256, 128, 512, true},
     {"256x256_w4x2_regstage", 256, 256, 512, false}, {"256x256_w4x2_glds", 256, 256, 512, true},
+    {"256x256_w4x2_glds_fragpipe", 256, 256, 512, true}, {"256x256_w4x2_glds_fragpipe_prio", 256, 256, 512, true},
+    {"128x128_w2x2_glds_fragpipe", 128, 128, 256, true}, {"256x128_w4x2_glds_fragpipe", 256, 128, 512, true},
 };
 
 int gemm_num_variants() { return kNumVariants; }

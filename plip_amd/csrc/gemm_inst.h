@@ -7,11 +7,11 @@ namespace plipmi {
 
 typedef int (*GemmLaunchFn)(const GemmParams&, hipStream_t);
 
-template <typename T, int BM, int BN, int WM, int WN, int EPI, bool GLDS>
+template <typename T, int BM, int BN, int WM, int WN, int EPI, bool GLDS, int SCHED = 0>
 int launch_tiled(const GemmParams& p, hipStream_t stream) {
   constexpr int NT = WM * WN * 64;
   constexpr int LDS = 2 * (BM + BN) * 128;
-  auto kern = gemm_nt_kernel<T, BM, BN, WM, WN, EPI, GLDS>;
+  auto kern = gemm_nt_kernel<T, BM, BN, WM, WN, EPI, GLDS, SCHED>;
   static bool attr_set = false;  // one handle per process; set once per instantiation
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -30,7 +30,7 @@ int launch_naive(const GemmParams& p, hipStream_t stream) {
   return (int)hipGetLastError();
 }
 
-constexpr int kNumVariants = 6;
+constexpr int kNumVariants = 10;
 
 // table[variant][epilogue]
 template <typename T>
@@ -44,6 +44,10 @@ struct GemmTable {
       case 3: return launch_tiled<T, 256, 128, 4, 2, EPI, true>;
       case 4: return launch_tiled<T, 256, 256, 4, 2, EPI, false>;
       case 5: return launch_tiled<T, 256, 256, 4, 2, EPI, true>;
+      case 6: return launch_tiled<T, 256, 256, 4, 2, EPI, true, 1>;
+      case 7: return launch_tiled<T, 256, 256, 4, 2, EPI, true, 2>;
+      case 8: return launch_tiled<T, 128, 128, 2, 2, EPI, true, 1>;
+      case 9: return launch_tiled<T, 256, 128, 4, 2, EPI, true, 1>;
       case -2: return launch_naive<T, EPI>;
       default: return nullptr;
     }

@@ -34,7 +34,7 @@ def sec_gemm():
             bias = torch.randn(N, generator=g).to(dev)
             c0 = torch.randn(M, N, generator=g).to(dev)
             base = a.double() @ w.double().T
-            for variant in (-2, 0, 1, 2, 3, 4, 5):
+            for variant in [-2] + list(range(len(gemm_variants()))):
                 for epi in (0, 1, 2, 3):
                     ref = base + (bias.double() if epi < 3 else 0)
                     if epi == 1:
@@ -216,29 +216,41 @@ def sec_gemmtrace():
     e1.record()
     torch.cuda.synchronize()
     t = tr.cpu().numpy().reshape(nblk, 8).astype(np.int64)
-    t0 = t[:, 0].min()
-    start, pro, loop, epi_t, end = t[:, 0] - t0, t[:, 1] - t[:, 0], t[:, 2] - t[:, 1], t[:, 3] - t[:, 2], t[:, 3] - t0
-    span = end.max()
     ms = e0.elapsed_time(e1)
-    tick_us = span / (ms * 1e3)
+    xcc = (t[:, 5] >> 32) & 0xF
+    # s_memtime is a per-XCD counter (not synchronised across XCDs): normalise per XCC
+    start = np.zeros(nblk, dtype=np.int64)
+    end = np.zeros(nblk, dtype=np.int64)
+    spans = []
+    for x in range(8):
+        m = xcc == x
+        if not m.any():
+            continue
+        t0 = t[m, 0].min()
+        start[m] = t[m, 0] - t0
+        end[m] = t[m, 3] - t0
+        spans.append(end[m].max())
+    pro, loop, epi_t = t[:, 1] - t[:, 0], t[:, 2] - t[:, 1], t[:, 3] - t[:, 2]
+    tick_us = float(np.median(spans)) / (ms * 1e3)          # ticks per microsecond, from the per-XCC span
     print(f"variant {names[v]} {M}x{N}x{K} epi{epi}: {nblk} workgroups, kernel {ms * 1e3:.1f} us by events "
-          f"({2.0 * M * N * K / ms / 1e9:.0f} TFLOP/s), {span} ticks first-start -> last-end => {tick_us:.1f} ticks/us")
+          f"({2.0 * M * N * K / ms / 1e9:.0f} TFLOP/s); per-XCC spans {spans} ticks => ~{tick_us:.1f} ticks/us")
     q = lambda x: (f"min {x.min() / tick_us:7.2f}  p50 {np.median(x) / tick_us:7.2f}  p90 {np.percentile(x, 90) / tick_us:7.2f}"
                    f"  max {x.max() / tick_us:7.2f} us")
     kt = max(1, int(t[0, 6]) - 1)
     print("  start offset :", q(start))
     print("  prologue     :", q(pro))
-    print("  main loop    :", q(loop), f"  ({np.median(loop) / tick_us / kt * 1e3:.0f} ns per k-tile, {kt} tiles)")
+    print("  main loop    :", q(loop), f"  ({np.median(loop) / tick_us / kt * 1e3:.0f} ns = {np.median(loop) / kt:.0f} ticks per k-tile, {kt} tiles)")
     print("  epilogue     :", q(epi_t))
     print("  lifetime     :", q(t[:, 3] - t[:, 0]))
-    xcc = (t[:, 5] >> 32) & 0xF
     print("  workgroups per XCC:", np.bincount(xcc, minlength=8).tolist())
-    first_end = end.min()
-    print(f"  workgroups started before the first one ended: {(start < first_end).sum()} (of {nblk})")
-    order = np.argsort(start)
-    for i in list(order[:3]) + list(order[len(order) // 2: len(order) // 2 + 2]) + list(order[-3:]):
-        print(f"    wg {i:4d} tile {t[i, 4]:4d} xcc {xcc[i]} hw_id {t[i, 5] & 0xffffffff:08x}: start {start[i] / tick_us:7.2f} "
-              f"pro {pro[i] / tick_us:6.2f} loop {loop[i] / tick_us:7.2f} epi {epi_t[i] / tick_us:6.2f} us")
+    m0 = xcc == 0
+    first_end = end[m0].min()
+    print(f"  XCC0: {m0.sum()} workgroups, {(start[m0] < first_end).sum()} started before its first one ended")
+    idx = np.nonzero(m0)[0]
+    order = idx[np.argsort(start[idx])]
+    for i in list(order[:4]) + list(order[len(order) // 2: len(order) // 2 + 3]) + list(order[-3:]):
+        print(f"    wg {i:4d} tile {t[i, 4]:4d} hw_id {t[i, 5] & 0xffffffff:08x}: start {start[i] / tick_us:7.2f} "
+              f"pro {pro[i] / tick_us:6.2f} loop {loop[i] / tick_us:7.2f} epi {epi_t[i] / tick_us:6.2f} end {end[i] / tick_us:7.2f} us")
 
 
 def sec_overlap():

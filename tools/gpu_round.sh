@@ -19,7 +19,7 @@ for s in $SECTIONS; do
                tag=$(echo $pass | cut -d' ' -f1)
                (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d "$OLDPWD/gpurun_out/pmc_$tag" -o pmc -- python "$OLDPWD/tools/gpu_diag.py" gemmone ${PMC_ARGS:-5 12800 3072 768 1} >> "$OLDPWD/gpurun_out/pmc.log" 2>&1)
              done ;;
-    trace)   for a in "5 12800 3072 768 1" "5 12800 768 3072 2" "1 12800 768 768 2" "1 12800 3072 768 1" "3 12800 3072 768 1"; do
+    trace)   echo "${TRACE_ARGS:-5 12800 3072 768 1;6 12800 3072 768 1;7 12800 3072 768 1;5 12800 768 3072 2;1 12800 768 768 2;8 12800 768 768 2}" | tr ';' '\n' | while read a; do
                timeout 120 python tools/gpu_diag.py gemmtrace $a >> gpurun_out/diag_gemmtrace.log 2>&1; done ;;
     smoke)   timeout 600 python __graft_entry__.py --smoke > gpurun_out/smoke.log 2>&1 ;;
     *)       timeout 600 python tools/gpu_diag.py $s > gpurun_out/diag_$s.log 2>&1 ;;
