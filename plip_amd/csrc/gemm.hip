@@ -11,7 +11,21 @@ static const GemmVariant kVariants[kNumVariants] = {
     {"256x256_w4x2_regstage", 256, 256, 512, false}, {"256x256_w4x2_glds", 256, 256, 512, true},
     {"256x256_w4x2_glds_fragpipe", 256, 256, 512, true}, {"256x256_w4x2_glds_fragpipe_prio", 256, 256, 512, true},
     {"128x128_w2x2_glds_fragpipe", 128, 128, 256, true}, {"256x128_w4x2_glds_fragpipe", 256, 128, 512, true},
+    {"256x256_w4x2_persist", 256, 256, 512, true}, {"128x128_w2x2_persist", 128, 128, 256, true},
+    {"256x128_w4x2_persist", 256, 128, 512, true},
 };
+
+int gemm_num_cus() {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+    cus = cus / 8 * 8;
+  }
+  return cus;
+}
 
 int gemm_num_variants() { return kNumVariants; }
 const GemmVariant& gemm_variant(int v) { return kVariants[v]; }

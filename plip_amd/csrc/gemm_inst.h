@@ -2,6 +2,7 @@
 // so the two halves compile in parallel).
 #pragma once
 #include "gemm.h"
+#include "gemm_persist.h"
 
 namespace plipmi {
 
@@ -23,6 +24,29 @@ int launch_tiled(const GemmParams& p, hipStream_t stream) {
   return (int)hipGetLastError();
 }
 
+int gemm_num_cus();  // gemm.hip
+
+// persistent form: one resident workgroup per CU slot walks a strip of tiles
+template <typename T, int BM, int BN, int WM, int WN, int EPI, int SCHED = 1>
+int launch_persist(const GemmParams& p, hipStream_t stream) {
+  constexpr int NT = WM * WN * 64;
+  constexpr int LDS = 2 * (BM + BN) * 128;
+  auto kern = gemm_nt_persist_kernel<T, BM, BN, WM, WN, EPI, SCHED>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  const int ntiles = ((p.M + BM - 1) / BM) * (p.N / BN);
+  const int per_cu = (160 * 1024) / LDS;                       // resident workgroups per CU (LDS-bound)
+  int grid = gemm_num_cus() * (per_cu < 1 ? 1 : per_cu);
+  const int need = (ntiles + 7) / 8 * 8;                        // grid must be a multiple of 8 (XCD strips)
+  if (grid > need) grid = need;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), LDS, stream, p);
+  return (int)hipGetLastError();
+}
+
 template <typename T, int EPI>
 int launch_naive(const GemmParams& p, hipStream_t stream) {
   dim3 grid((p.N / 4 + 63) / 64, p.M);
@@ -30,7 +54,7 @@ int launch_naive(const GemmParams& p, hipStream_t stream) {
   return (int)hipGetLastError();
 }
 
-constexpr int kNumVariants = 10;
+constexpr int kNumVariants = 13;
 
 // table[variant][epilogue]
 template <typename T>
@@ -48,6 +72,9 @@ struct GemmTable {
       case 7: return launch_tiled<T, 256, 256, 4, 2, EPI, true, 2>;
       case 8: return launch_tiled<T, 128, 128, 2, 2, EPI, true, 1>;
       case 9: return launch_tiled<T, 256, 128, 4, 2, EPI, true, 1>;
+      case 10: return launch_persist<T, 256, 256, 4, 2, EPI, 1>;
+      case 11: return launch_persist<T, 128, 128, 2, 2, EPI, 1>;
+      case 12: return launch_persist<T, 256, 128, 4, 2, EPI, 1>;
       case -2: return launch_naive<T, EPI>;
       default: return nullptr;
     }

@@ -7,7 +7,8 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-SHAPES = [(1, 256, 64), (37, 256, 128), (128, 256, 192), (300, 512, 768), (515, 256, 3072)]
+SHAPES = [(1, 256, 64), (37, 256, 128), (128, 256, 192), (300, 512, 768), (515, 256, 3072),
+          (5000, 768, 256)]       # 40 x 6 tiles of 128^2: more tiles than resident workgroups per XCD strip step
 
 
 def _ref(a, w, bias, epi, alpha, c0):
@@ -24,7 +25,7 @@ def _ref(a, w, bias, epi, alpha, c0):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, -2])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, -2])
 @pytest.mark.parametrize("epi", [0, 1, 2, 3])
 def test_gemm_variants(dtype, variant, epi):
     from plip_amd.engine import gemm_nt
