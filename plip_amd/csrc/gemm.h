@@ -54,6 +54,9 @@ struct GemmParams {
   // test hook (plipmi_gemm_nt_traced): per workgroup 8 x u64 {start, prologue done, main loop done, epilogue
   // done, logical tile id, HW_ID, k tiles, 0}, s_memtime ticks.  nullptr on the product path.
   unsigned long long* trace = nullptr;
+  // test hook (PLIPMI_GEMM_ABLATE, timeline runs only; results are wrong by construction):
+  // bit 0 = skip the global->LDS fills of the K loop, bit 1 = skip the MFMA block, bit 2 = skip the epilogue
+  int ablate = 0;
 };
 
 // LDS-DMA (global_load_lds_dwordx4): each lane's 16 bytes at `gsrc` land at
@@ -286,12 +289,12 @@ void gemm_nt_kernel(const GemmParams p) {                                       
   if (trace && tid == 0) trace[1] = __builtin_amdgcn_s_memtime();
   for (int kt = 0; kt < KT - 1; ++kt) {
     const int cur = kt & 1;
-    stage_issue(cur ^ 1);
-    compute(cur);
+    if (!(p.ablate & 1)) stage_issue(cur ^ 1);
+    if (!(p.ablate & 2)) compute(cur);
     stage_commit(cur ^ 1);
     __syncthreads();
   }
-  compute((KT - 1) & 1);
+  if (!(p.ablate & 2)) compute((KT - 1) & 1);
   if (trace && tid == 0) trace[2] = __builtin_amdgcn_s_memtime();
 
   // ---- epilogue -------------------------------------------------------------------------------
@@ -306,10 +309,21 @@ void gemm_nt_kernel(const GemmParams p) {                                       
   static_assert(WM * WN * SLAB_BYTES <= 2 * STAGE, "epilogue slabs must fit in the staging buffers");
   static_assert(NI % 2 == 0, "epilogue handles two 32-column MFMA tiles per slab");
   __syncthreads();  // every wave is done reading the last K tile: the staging LDS can be reused
+  if (p.ablate & 4) return;
   char* slab = smem + wave * SLAB_BYTES;
   const int rd_row = lane >> 4, rd_col = (lane & 15) * 4;
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
+    // every bias / residual / position row this 32-row block needs is requested up front, so the wave pays
+    // ONE memory latency per row block instead of one per slab (the residual rows come from MALL/HBM)
+    float4 add[NI / 2][8];
+#pragma unroll
+    for (int jp = 0; jp < NI / 2; ++jp)
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int m = m0 + wm * TM + i * 32 + it * 4 + rd_row;
+        add[jp][it] = EpilogueOp<T, EPI>::load(p, m < p.M ? m : p.M - 1, n0 + wn * TN + jp * 64 + rd_col);
+      }
 #pragma unroll
     for (int jp = 0; jp < NI / 2; ++jp) {
 #pragma unroll
@@ -323,19 +337,13 @@ void gemm_nt_kernel(const GemmParams p) {                                       
       __builtin_amdgcn_wave_barrier();  // LDS ops of one wave execute in order; keep the compiler from reordering
       const int n = n0 + wn * TN + jp * 64 + rd_col;
       f32x4 v[8];
-      float4 add[8];
 #pragma unroll
       for (int it = 0; it < 8; ++it)
         v[it] = *reinterpret_cast<const f32x4*>(slab + (it * 4 + rd_row) * SLAB_PITCH + rd_col * 4);
 #pragma unroll
-      for (int it = 0; it < 8; ++it) {  // unconditional loads from a clamped row: no branches, all in flight together
-        const int m = m0 + wm * TM + i * 32 + it * 4 + rd_row;
-        add[it] = EpilogueOp<T, EPI>::load(p, m < p.M ? m : p.M - 1, n);
-      }
-#pragma unroll
       for (int it = 0; it < 8; ++it) {
         const int m = m0 + wm * TM + i * 32 + it * 4 + rd_row;
-        if (m < p.M) EpilogueOp<T, EPI>::store(p, m, n, v[it][0], v[it][1], v[it][2], v[it][3], add[it]);
+        if (m < p.M) EpilogueOp<T, EPI>::store(p, m, n, v[it][0], v[it][1], v[it][2], v[it][3], add[jp][it]);
       }
       __builtin_amdgcn_wave_barrier();
     }

@@ -68,6 +68,11 @@ int gemm_launch(int dtype, int epi, int variant, const GemmParams& p, hipStream_
   }
   GemmLaunchFn fn = dtype == 1 ? gemm_get_bf16(variant, epi) : gemm_get_f32(variant, epi);
   if (!fn) return (int)hipErrorInvalidValue;
+  if (p.trace) {  // timeline runs may ablate parts of the kernel (never on the product path: trace is null there)
+    static int ablate = -1;
+    if (ablate < 0) { const char* e = getenv("PLIPMI_GEMM_ABLATE"); ablate = e ? atoi(e) : 0; }
+    if (ablate) { GemmParams q = p; q.ablate = ablate; return fn(q, stream); }
+  }
   if (kernel_name) {
     // static table of names: "gemm_nt<dtype,tile,epi>"
     static char names[2][kNumVariants + 1][EPI_COUNT][64];

@@ -173,6 +173,15 @@ void gemm_nt_persist_kernel(const GemmParams p) {
       const int rd_row = lane >> 3, rd_col = (lane & 7) * 4;  // 8 lanes x 16 B = one 128-byte slab row
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
+        // one memory latency per 32-row block: all bias / residual / position rows requested up front
+        float4 add[NI][4];
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+          for (int it = 0; it < 4; ++it) {
+            const int m = m0 + wm * TM + i * 32 + it * 8 + rd_row;
+            add[j][it] = EpilogueOp<T, EPI>::load(p, m < p.M ? m : p.M - 1, n0 + wn * TN + j * 32 + rd_col);
+          }
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
 #pragma unroll
@@ -183,19 +192,13 @@ void gemm_nt_persist_kernel(const GemmParams p) {
           __builtin_amdgcn_wave_barrier();
           const int n = n0 + wn * TN + j * 32 + rd_col;
           f32x4 v[4];
-          float4 add[4];
 #pragma unroll
           for (int it = 0; it < 4; ++it)
             v[it] = *reinterpret_cast<const f32x4*>(slab + (it * 8 + rd_row) * SLAB_PITCH + rd_col * 4);
 #pragma unroll
           for (int it = 0; it < 4; ++it) {
             const int m = m0 + wm * TM + i * 32 + it * 8 + rd_row;
-            add[it] = EpilogueOp<T, EPI>::load(p, m < p.M ? m : p.M - 1, n);
-          }
-#pragma unroll
-          for (int it = 0; it < 4; ++it) {
-            const int m = m0 + wm * TM + i * 32 + it * 8 + rd_row;
-            if (m < p.M) EpilogueOp<T, EPI>::store(p, m, n, v[it][0], v[it][1], v[it][2], v[it][3], add[it]);
+            if (m < p.M) EpilogueOp<T, EPI>::store(p, m, n, v[it][0], v[it][1], v[it][2], v[it][3], add[j][it]);
           }
           __builtin_amdgcn_wave_barrier();
         }

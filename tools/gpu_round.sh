@@ -21,6 +21,8 @@ for s in $SECTIONS; do
              done ;;
     trace)   echo "${TRACE_ARGS:-5 12800 3072 768 1;6 12800 3072 768 1;7 12800 3072 768 1;5 12800 768 3072 2;1 12800 768 768 2;8 12800 768 768 2}" | tr ';' '\n' | while read a; do
                timeout 120 python tools/gpu_diag.py gemmtrace $a >> gpurun_out/diag_gemmtrace.log 2>&1; done ;;
+    ablate)  for ab in 0 1 2 3 4 6; do echo "=== PLIPMI_GEMM_ABLATE=$ab (1: no K-loop fills, 2: no MFMA, 4: no epilogue)" >> gpurun_out/diag_ablate.log
+               PLIPMI_GEMM_ABLATE=$ab timeout 120 python tools/gpu_diag.py gemmtrace ${ABLATE_ARGS:-6 12800 3072 768 1} 2>&1 | grep -E "variant|prologue|main loop|epilogue|lifetime" >> gpurun_out/diag_ablate.log; done ;;
     smoke)   timeout 600 python __graft_entry__.py --smoke > gpurun_out/smoke.log 2>&1 ;;
     *)       timeout 600 python tools/gpu_diag.py $s > gpurun_out/diag_$s.log 2>&1 ;;
   esac
