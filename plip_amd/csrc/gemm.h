@@ -141,7 +141,11 @@ struct EpilogueOp {
 // SCHED 0: fragment reads / MFMAs in compiler order (it sinks every ds_read next to its first use);
 //       1: reads of K-step ks+1 pinned in front of the MFMAs of step ks (register double buffering);
 //       2: as 1, plus s_setprio 1 around each MFMA group.
-template <typename T, int BM, int BN, int WM, int WN, int EPI, bool GLDS, int SCHED = 0>
+// L2PF d > 0: every K iteration also touches (one dword per 128-byte line) the K tile d steps further on, so
+//       the LDS-DMA fill that needs it later hits the XCD's L2 instead of paying a MALL/HBM round trip.
+//       The ablation timeline showed a K-tile fill taking ~2300 cycles on its own (latency, not bandwidth)
+//       against ~2050 cycles of MFMA work; with one tile of lookahead the two do not overlap fully.
+template <typename T, int BM, int BN, int WM, int WN, int EPI, bool GLDS, int SCHED = 0, int L2PF = 0>
 __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))  // LDS caps residency at 2 waves/SIMD:
 void gemm_nt_kernel(const GemmParams p) {                                            // let the allocator use 256 VGPRs
   constexpr int NT = WM * WN * 64;
@@ -227,6 +231,22 @@ void gemm_nt_kernel(const GemmParams p) {                                       
     }
   };
 
+  // ---- L2 prefetch: thread tid owns line tid of the (BM + BN)-row K tile ---------------------
+  unsigned touch = 0;  // destination of the touch loads; kept live so its register is never reused under them
+  const char* touch_ptr = nullptr;
+  if constexpr (L2PF > 0) {
+    const int line = tid < BM + BN ? tid : BM + BN - 1;  // every lane touches (no exec-masked wave may skip the op)
+    if (line < BM) {
+      const int r = m0 + line < p.M ? m0 + line : p.M - 1;
+      touch_ptr = reinterpret_cast<const char*>(p.A) + (size_t)r * p.lda * sizeof(T);
+    } else {
+      touch_ptr = reinterpret_cast<const char*>(p.W) + (size_t)(n0 + line - BM) * p.ldw * sizeof(T);
+    }
+  }
+  auto l2_touch = [&](int ktile) {
+    asm volatile("global_load_dword %0, %1, off" : "+v"(touch) : "v"(touch_ptr + (size_t)ktile * 128) : "memory");
+  };
+
   // ---- fragment read offsets (lane-constant) -----------------------------------
   const int lrow = lane & 31, lgrp = lane >> 5;
   const int lsw = (lrow >> 1) & 7;
@@ -284,17 +304,36 @@ void gemm_nt_kernel(const GemmParams p) {                                       
     trace[6] = KT;
   }
   stage_issue(0);
+  if constexpr (L2PF > 0) {
+#pragma unroll
+    for (int d = 1; d <= L2PF; ++d)
+      if (d < KT) l2_touch(d);
+  }
   stage_commit(0);
   __syncthreads();
   if (trace && tid == 0) trace[1] = __builtin_amdgcn_s_memtime();
   for (int kt = 0; kt < KT - 1; ++kt) {
     const int cur = kt & 1;
     if (!(p.ablate & 1)) stage_issue(cur ^ 1);
+    bool touched = false;
+    if constexpr (L2PF > 0) {
+      touched = kt + 1 + L2PF < KT;  // uniform
+      if (touched) l2_touch(kt + 1 + L2PF);
+    }
     if (!(p.ablate & 2)) compute(cur);
-    stage_commit(cur ^ 1);
+    if (GLDS && touched) {
+      // vmcnt retires in order: everything but the youngest op (the touch) done == the K tile has landed
+      asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    } else {
+      stage_commit(cur ^ 1);
+    }
     __syncthreads();
   }
   if (!(p.ablate & 2)) compute((KT - 1) & 1);
+  if constexpr (L2PF > 0) {
+    wait_vm0();
+    asm volatile("" ::"v"(touch));
+  }
   if (trace && tid == 0) trace[2] = __builtin_amdgcn_s_memtime();
 
   // ---- epilogue -------------------------------------------------------------------------------
