@@ -140,7 +140,9 @@ struct EpilogueOp {
 // BM x BN block tile, WM x WN waves, each wave a (BM/WM) x (BN/WN) sub-tile of 32x32 MFMA tiles.
 // SCHED 0: fragment reads / MFMAs in compiler order (it sinks every ds_read next to its first use);
 //       1: reads of K-step ks+1 pinned in front of the MFMAs of step ks (register double buffering);
-//       2: as 1, plus s_setprio 1 around each MFMA group.
+//       2: as 1, plus s_setprio 1 around each MFMA group;
+//       3: as 1, and the next K tile's LDS-DMA requests are issued in 4 parts, one in front of each K step's
+//          MFMA group, instead of all at once after the barrier.
 // L2PF d > 0: every K iteration also touches (one dword per 128-byte line) the K tile d steps further on, so
 //       the LDS-DMA fill that needs it later hits the XCD's L2 instead of paying a MALL/HBM round trip.
 //       The ablation timeline showed a K-tile fill taking ~2300 cycles on its own (latency, not bandwidth)
@@ -219,6 +221,18 @@ void gemm_nt_kernel(const GemmParams p) {                                       
 #pragma unroll
     for (int i = 0; i < PW; ++i) w_src[i] += 128;
   };
+  // the same fill cut in 4 parts (one per K step of the MFMA block): SCHED 3 spreads the LDS-DMA issue over the
+  // iteration instead of queueing all PA+PW requests of every wave on the texture-address unit right after the barrier
+  auto stage_issue_part = [&](int buf, int part) {
+    constexpr int PER = (PA + PW + 3) / 4;
+    const unsigned base = lds0 + buf * STAGE + wave * 1024;
+#pragma unroll
+    for (int e = 0; e < PER; ++e) {
+      const int idx = part * PER + e;  // compile-time after unrolling
+      if (idx < PA) { glds16(a_src[idx], base + idx * NT * 16); a_src[idx] += 128; }
+      else if (idx < PA + PW) { glds16(w_src[idx - PA], base + A_BYTES + (idx - PA) * NT * 16); w_src[idx - PA] += 128; }
+    }
+  };
   auto stage_commit = [&](int buf) {  // make the staged tile visible in LDS buffer `buf`
     if constexpr (GLDS) {
       wait_vm0();
@@ -264,7 +278,7 @@ void gemm_nt_kernel(const GemmParams p) {                                       
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  auto compute = [&](int buf) {
+  auto compute = [&](int buf, int fill_buf) {
     const char* sb = smem + buf * STAGE;
     // fragments of K-step ks+1 are fetched from LDS before the MFMAs of step ks issue
     u32x4 xf[2][MI], wf[2][NI];
@@ -281,6 +295,9 @@ void gemm_nt_kernel(const GemmParams p) {                                       
 #pragma unroll
         for (int j = 0; j < NI; ++j)
           wf[(ks + 1) & 1][j] = *reinterpret_cast<const u32x4*>(sb + w_tile + j * 32 * 128 + foff[ks + 1]);
+      }
+      if constexpr (SCHED == 3 && GLDS) {
+        if (fill_buf >= 0) stage_issue_part(fill_buf, ks);
       }
       if constexpr (SCHED >= 1) __builtin_amdgcn_sched_barrier(0);
       if constexpr (SCHED == 2) __builtin_amdgcn_s_setprio(1);
@@ -314,13 +331,15 @@ void gemm_nt_kernel(const GemmParams p) {                                       
   if (trace && tid == 0) trace[1] = __builtin_amdgcn_s_memtime();
   for (int kt = 0; kt < KT - 1; ++kt) {
     const int cur = kt & 1;
-    if (!(p.ablate & 1)) stage_issue(cur ^ 1);
+    if constexpr (!(SCHED == 3 && GLDS)) {
+      if (!(p.ablate & 1)) stage_issue(cur ^ 1);
+    }
     bool touched = false;
     if constexpr (L2PF > 0) {
       touched = kt + 1 + L2PF < KT;  // uniform
       if (touched) l2_touch(kt + 1 + L2PF);
     }
-    if (!(p.ablate & 2)) compute(cur);
+    if (!(p.ablate & 2)) compute(cur, (p.ablate & 1) ? -1 : (cur ^ 1));
     if (GLDS && touched) {
       // vmcnt retires in order: everything but the youngest op (the touch) done == the K tile has landed
       asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
@@ -329,7 +348,7 @@ void gemm_nt_kernel(const GemmParams p) {                                       
     }
     __syncthreads();
   }
-  if (!(p.ablate & 2)) compute((KT - 1) & 1);
+  if (!(p.ablate & 2)) compute((KT - 1) & 1, -1);
   if constexpr (L2PF > 0) {
     wait_vm0();
     asm volatile("" ::"v"(touch));

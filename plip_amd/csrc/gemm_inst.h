@@ -54,7 +54,7 @@ int launch_naive(const GemmParams& p, hipStream_t stream) {
   return (int)hipGetLastError();
 }
 
-constexpr int kNumVariants = 16;
+constexpr int kNumVariants = 18;
 
 // table[variant][epilogue]
 template <typename T>
@@ -78,6 +78,8 @@ struct GemmTable {
       case 13: return launch_tiled<T, 256, 256, 4, 2, EPI, true, 1, 2>;
       case 14: return launch_tiled<T, 128, 128, 2, 2, EPI, true, 1, 2>;
       case 15: return launch_tiled<T, 256, 256, 4, 2, EPI, true, 1, 3>;
+      case 16: return launch_tiled<T, 256, 256, 4, 2, EPI, true, 3>;
+      case 17: return launch_tiled<T, 128, 128, 2, 2, EPI, true, 3>;
       case -2: return launch_naive<T, EPI>;
       default: return nullptr;
     }
