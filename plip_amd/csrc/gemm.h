@@ -147,7 +147,9 @@ struct EpilogueOp {
 //       the LDS-DMA fill that needs it later hits the XCD's L2 instead of paying a MALL/HBM round trip.
 //       The ablation timeline showed a K-tile fill taking ~2300 cycles on its own (latency, not bandwidth)
 //       against ~2050 cycles of MFMA work; with one tile of lookahead the two do not overlap fully.
-template <typename T, int BM, int BN, int WM, int WN, int EPI, bool GLDS, int SCHED = 0, int L2PF = 0>
+// NSTAGE 3 (LDS-DMA only): three LDS stages, the fill runs TWO K tiles ahead and the end-of-iteration wait is a
+//       counted vmcnt(PA+PW) (in-order retirement: the older tile has landed, the newest may still fly).
+template <typename T, int BM, int BN, int WM, int WN, int EPI, bool GLDS, int SCHED = 0, int L2PF = 0, int NSTAGE = 2>
 __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))  // LDS caps residency at 2 waves/SIMD:
 void gemm_nt_kernel(const GemmParams p) {                                            // let the allocator use 256 VGPRs
   constexpr int NT = WM * WN * 64;
@@ -320,6 +322,31 @@ void gemm_nt_kernel(const GemmParams p) {                                       
                ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20 /* XCC_ID [3:0] */) << 32);
     trace[6] = KT;
   }
+  if constexpr (NSTAGE == 3) {
+    static_assert(NSTAGE != 3 || (GLDS && L2PF == 0 && SCHED != 3), "3-stage ring: LDS-DMA fills issued at the loop top");
+    stage_issue(0);
+    if (KT > 1) {
+      stage_issue(1);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PA + PW) : "memory");  // tile 0 landed, tile 1 may be in flight
+    } else {
+      wait_vm0();
+    }
+    __syncthreads();
+    if (trace && tid == 0) trace[1] = __builtin_amdgcn_s_memtime();
+    int cur = 0, nxt2 = 2;  // stage of tile kt, stage of tile kt+2
+    for (int kt = 0; kt < KT; ++kt) {
+      const bool fetch = kt + 2 < KT;
+      if (fetch && !(p.ablate & 1)) stage_issue(nxt2);
+      if (!(p.ablate & 2)) compute(cur, -1);
+      if (kt + 1 < KT) {
+        if (fetch) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PA + PW) : "memory");
+        else wait_vm0();
+        __syncthreads();  // tile kt+1 visible to all waves; stage `cur` free for tile kt+3
+      }
+      cur = cur == 2 ? 0 : cur + 1;
+      nxt2 = nxt2 == 2 ? 0 : nxt2 + 1;
+    }
+  } else {
   stage_issue(0);
   if constexpr (L2PF > 0) {
 #pragma unroll
@@ -353,6 +380,7 @@ void gemm_nt_kernel(const GemmParams p) {                                       
     wait_vm0();
     asm volatile("" ::"v"(touch));
   }
+  }  // NSTAGE == 2
   if (trace && tid == 0) trace[2] = __builtin_amdgcn_s_memtime();
 
   // ---- epilogue -------------------------------------------------------------------------------
@@ -364,7 +392,7 @@ void gemm_nt_kernel(const GemmParams p) {                                       
   // cover 256 B (fp32) / 128 B (bf16) of one row, so loads/stores are whole cache lines.
   constexpr int SLAB_PITCH = 64 * 4 + 16;
   constexpr int SLAB_BYTES = 32 * SLAB_PITCH;
-  static_assert(WM * WN * SLAB_BYTES <= 2 * STAGE, "epilogue slabs must fit in the staging buffers");
+  static_assert(WM * WN * SLAB_BYTES <= NSTAGE * STAGE, "epilogue slabs must fit in the staging buffers");
   static_assert(NI % 2 == 0, "epilogue handles two 32-column MFMA tiles per slab");
   __syncthreads();  // every wave is done reading the last K tile: the staging LDS can be reused
   if (p.ablate & 4) return;

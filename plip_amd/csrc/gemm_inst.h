@@ -8,11 +8,11 @@ namespace plipmi {
 
 typedef int (*GemmLaunchFn)(const GemmParams&, hipStream_t);
 
-template <typename T, int BM, int BN, int WM, int WN, int EPI, bool GLDS, int SCHED = 0, int L2PF = 0>
+template <typename T, int BM, int BN, int WM, int WN, int EPI, bool GLDS, int SCHED = 0, int L2PF = 0, int NSTAGE = 2>
 int launch_tiled(const GemmParams& p, hipStream_t stream) {
   constexpr int NT = WM * WN * 64;
-  constexpr int LDS = 2 * (BM + BN) * 128;
-  auto kern = gemm_nt_kernel<T, BM, BN, WM, WN, EPI, GLDS, SCHED, L2PF>;
+  constexpr int LDS = NSTAGE * (BM + BN) * 128;
+  auto kern = gemm_nt_kernel<T, BM, BN, WM, WN, EPI, GLDS, SCHED, L2PF, NSTAGE>;
   static bool attr_set = false;  // one handle per process; set once per instantiation
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -54,7 +54,7 @@ int launch_naive(const GemmParams& p, hipStream_t stream) {
   return (int)hipGetLastError();
 }
 
-constexpr int kNumVariants = 18;
+constexpr int kNumVariants = 20;
 
 // table[variant][epilogue]
 template <typename T>
@@ -80,6 +80,8 @@ struct GemmTable {
       case 15: return launch_tiled<T, 256, 256, 4, 2, EPI, true, 1, 3>;
       case 16: return launch_tiled<T, 256, 256, 4, 2, EPI, true, 3>;
       case 17: return launch_tiled<T, 128, 128, 2, 2, EPI, true, 3>;
+      case 18: return launch_tiled<T, 256, 128, 4, 2, EPI, true, 1, 0, 3>;
+      case 19: return launch_tiled<T, 128, 256, 2, 4, EPI, true, 1, 0, 3>;
       case -2: return launch_naive<T, EPI>;
       default: return nullptr;
     }
