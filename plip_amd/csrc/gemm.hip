@@ -46,16 +46,17 @@ int gemm_default_variant(int dtype, int M, int N, int K) {
     if (g_override >= 0 && N % kVariants[g_override].bn != 0) return 1;
     return g_override;
   }
-  // Tuned on MI355X (profiles/r01_run1_gemm_variants_tflops.txt): the 256x256 LDS-DMA tile wins whenever N is
-  // wide or K is long (fewer L2->LDS bytes per FLOP); the short-K, narrow-N out-projections and small M
-  // prefer the 128x128 tile at two workgroups per CU.
+  // Tuned on MI355X (profiles/r01_gemm_variants_tflops.txt, bs=256 shapes): the 256x256 LDS-DMA tile with
+  // pipelined fragments and the fill spread over the iteration wins whenever N is wide or K is long (fewest
+  // L2->LDS bytes per FLOP); the short-K, narrow-N out-projections and small M prefer the 128x128 tile at two
+  // workgroups per CU, whose epilogues overlap the other workgroup's K loop.
   if (M <= 1024) return 1;
   if (dtype == 1) {
-    if (N % 256 == 0 && (N >= 1536 || K >= 1536)) return 5;
-    return 1;
+    if (N % 256 == 0 && (N >= 1536 || K >= 1536)) return 16;
+    return 8;
   }
-  if (N % 256 == 0 && N >= 1536 && K <= 1024) return 5;
-  return 1;
+  if (N % 256 == 0 && N >= 1536 && K <= 1024) return 9;
+  return 8;
 }
 
 static const char* kEpiNames[EPI_COUNT] = {"bias", "bias_qgelu", "bias_resid", "scale", "patch"};
