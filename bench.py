@@ -47,6 +47,18 @@ def parse():
     return ap.parse_args()
 
 
+def load_pmc_traffic(kernel_name):
+    """HBM/fabric bytes per launch of a kernel from the committed rocprofv3 --pmc summary
+    (profiles/pmc_traffic.json, produced by tools/pmc_summary.py on the GPU box); None if absent."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            db = json.load(f)
+        return db.get(kernel_name)
+    except (OSError, ValueError):
+        return None
+
+
 def usable_cores() -> int:
     """Host cores this process may actually run on: affinity mask, capped by the cgroup CPU quota.
     (os.cpu_count() reports every core of the node; asking torch for 256 threads inside a container
@@ -167,30 +179,49 @@ def main():
     logits = out[0]
     assert logits.shape == (B, B * world) and bool(torch.isfinite(logits).all())
 
-    # ---- roofline of the dominant kernel: HIP events on the launch stream, same K steps ----------
-    roofline = None
-    kernels = []
-    if not args.no_profile:
+    # ---- roofline of the dominant kernel: HIP events on the launch stream(s), same K steps, same stream
+    # setup as the timed region; then once more single-stream, where no other kernel shares the CUs ----------
+    def profile_pass(overlap):
         rows = []
         with model.engine.profile(rows):
             for _ in range(args.steps):
-                step()
+                sharded_pair_logits(model, px, ids, mask, overlap=overlap)
         rows.sort(key=lambda r: -r["total_ms"])
+        return rows
+
+    def roofline_of(rows, name=None):
+        dom = next((r for r in rows if r["flops"] > 0 and (name is None or r["name"] == name)), None)
+        if not dom:
+            return None
+        ach = dom["flops"] / (dom["total_ms"] * 1e-3) / 1e12
+        peak = PEAK_TFLOPS[args.dtype]
+        gem = [r for r in rows if r["name"].startswith("gemm")]
+        return {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                "traffic": None, "kernel": dom["name"], "avg_launch_us": round(dom["total_ms"] * 1e3 / dom["calls"], 2),
+                "flops_per_launch": round(dom["flops"] / dom["calls"]),
+                "all_gemm_tflops": round(sum(r["flops"] for r in gem) / (sum(r["total_ms"] for r in gem) * 1e9), 1)}
+
+    roofline = None
+    kernels = []
+    roofline_1s = None
+    if not args.no_profile:
+        rows = profile_pass(bool(args.overlap))
         total = sum(r["total_ms"] for r in rows) or 1.0
         kernels = [{"name": r["name"], "calls_per_step": r["calls"] / args.steps,
                     "ms_per_step": round(r["total_ms"] / args.steps, 4), "share": round(r["total_ms"] / total, 4),
                     "tflops": round(r["flops"] / (r["total_ms"] * 1e9), 1) if r["flops"] else None}
                    for r in rows[:8]]
-        dom = next((r for r in rows if r["flops"] > 0), None)
-        if dom:
-            ach = dom["flops"] / (dom["total_ms"] * 1e-3) / 1e12
-            peak = PEAK_TFLOPS[args.dtype]
-            roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                        "frac": round(ach / peak, 4), "traffic": None, "kernel": dom["name"],
-                        "avg_launch_us": round(dom["total_ms"] * 1e3 / dom["calls"], 2),
-                        "flops_per_launch": round(dom["flops"] / dom["calls"]),
-                        "all_gemm_tflops": round(sum(r["flops"] for r in rows if r["name"].startswith("gemm")) /
-                                                 (sum(r["total_ms"] for r in rows if r["name"].startswith("gemm")) * 1e9), 1)}
+        roofline = roofline_of(rows)
+        if roofline:
+            roofline["mode"] = "two HIP streams (towers co-scheduled, as in the timed region)" if args.overlap else "one stream"
+            tr = load_pmc_traffic(roofline["kernel"])
+            if tr:
+                roofline["traffic"] = tr["bytes_per_launch"]
+                roofline["traffic_note"] = tr["note"]
+        if args.overlap and roofline:
+            roofline_1s = roofline_of(profile_pass(False), roofline["kernel"])
+            if roofline_1s:
+                roofline_1s["mode"] = "one stream: the kernel owns the GPU (kernel quality, not the timed configuration)"
 
     if rank != 0:
         if world > 1:
@@ -213,6 +244,7 @@ def main():
                    "streams": 2 if args.overlap else 1, "device": model.engine.device_name},
         "algorithmic_tflops": round(value * cfg.pair_flops() / 1e12, 2),
         "roofline": roofline,
+        "roofline_single_stream": roofline_1s,
         "kernels": kernels,
     }
     if world == 1 and not args.no_cpu_baseline:

@@ -72,6 +72,12 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    try:
+        # torch ships its own libamdhip64; load it FIRST so libplipmi.so binds to the same HIP runtime instance
+        # (two runtimes in one process do not share devices/streams: plipmi_create then sees "no device")
+        import torch  # noqa: F401
+    except ImportError:  # pragma: no cover - the host layer needs torch anyway
+        pass
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             f"{LIB_PATH} is missing: the HIP engine is not built. Run `python -m plip_amd.build` "
