@@ -51,6 +51,11 @@ struct GemmParams {
   int lda, ldw, ldc;  // in elements
   float alpha;
   int np;             // patches per image (EPI_PATCH)
+  // Tile raster: the N tiles are cut in column groups `gw` tiles wide; logical tile ids run group by group,
+  // M-major inside a group.  An XCD's contiguous id range is then a compact (rows x gw) patch whose W panels
+  // (gw*BN rows of W) stay resident in its 4 MiB L2 while the A row panels stream through once.
+  // 0 = one group (N-major sweep of whole rows).  Set by gemm_launch.
+  int gw = 0;
   // test hook (plipmi_gemm_nt_traced): per workgroup 8 x u64 {start, prologue done, main loop done, epilogue
   // done, logical tile id, HW_ID, k tiles, 0}, s_memtime ticks.  nullptr on the product path.
   unsigned long long* trace = nullptr;
@@ -177,7 +182,9 @@ void gemm_nt_kernel(const GemmParams p) {                                       
   const int bid = blockIdx.x;
   const int xcd = bid & 7, xi = bid >> 3, xq = nblk >> 3, xr = nblk & 7;
   const int lid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + xi;
-  const int m0 = (lid / nbn) * BM, n0 = (lid % nbn) * BN;
+  const int gw = p.gw > 0 ? p.gw : nbn, tpg = nbm * gw;  // column group width, tiles per group
+  const int cgrp = lid / tpg, crem = lid - cgrp * tpg;
+  const int m0 = (crem / gw) * BM, n0 = (cgrp * gw + crem % gw) * BN;
 
   // ---- staging addresses --------------------------------------------------
   // thread -> LDS chunk position q = pass*NT + tid: row = q>>3, slot = q&7, and the

@@ -73,10 +73,30 @@ int gemm_launch(int dtype, int epi, int variant, const GemmParams& p, hipStream_
   }
   GemmLaunchFn fn = dtype == 1 ? gemm_get_bf16(variant, epi) : gemm_get_f32(variant, epi);
   if (!fn) return (int)hipErrorInvalidValue;
+  GemmParams pr = p;
+  if (variant >= 0) {
+    // column-group raster: minimise A*xn + W*(8/xn) fabric bytes subject to an XCD's W share fitting its L2
+    const double esz = dtype == 1 ? 2.0 : 4.0;
+    const int nbn = p.N / kVariants[variant].bn;
+    const double a_bytes = (double)p.M * p.K * esz, w_bytes = (double)p.N * p.K * esz;
+    static int force = -2;
+    if (force == -2) { const char* e = getenv("PLIPMI_GEMM_XN"); force = e ? atoi(e) : -1; }
+    int best_xn = 1;
+    double best = 1e300;
+    for (int xn = 1; xn <= 8; xn *= 2) {
+      if (nbn % xn) continue;
+      const double share = w_bytes / xn;
+      double cost = a_bytes * xn + w_bytes * (8.0 / xn);
+      if (share > 2.5e6) cost += 4.0 * w_bytes * 8.0;  // W share thrashes the L2: every M row re-fetches it
+      if (cost < best) { best = cost; best_xn = xn; }
+    }
+    if (force > 0 && nbn % force == 0) best_xn = force;
+    pr.gw = nbn / best_xn;
+  }
   if (p.trace) {  // timeline runs may ablate parts of the kernel (never on the product path: trace is null there)
     static int ablate = -1;
     if (ablate < 0) { const char* e = getenv("PLIPMI_GEMM_ABLATE"); ablate = e ? atoi(e) : 0; }
-    if (ablate) { GemmParams q = p; q.ablate = ablate; return fn(q, stream); }
+    if (ablate) { pr.ablate = ablate; return fn(pr, stream); }
   }
   if (kernel_name) {
     // static table of names: "gemm_nt<dtype,tile,epi>"
@@ -87,7 +107,7 @@ int gemm_launch(int dtype, int epi, int variant, const GemmParams& p, hipStream_
                kEpiNames[epi]);
     *kernel_name = nm;
   }
-  return fn(p, stream);
+  return fn(pr, stream);
 }
 
 }  // namespace plipmi

@@ -62,8 +62,10 @@ void gemm_nt_persist_kernel(const GemmParams p) {
   const char* w_src[PW];
   auto set_tile = [&](int loc, int& m0, int& n0) {
     const int lid = xbase + loc;
-    m0 = (lid / nbn) * BM;
-    n0 = (lid % nbn) * BN;
+    const int gw = p.gw > 0 ? p.gw : nbn, tpg = nbm * gw;
+    const int cgrp = lid / tpg, crem = lid - cgrp * tpg;
+    m0 = (crem / gw) * BM;
+    n0 = (cgrp * gw + crem % gw) * BN;
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
       int r = m0 + i * (NT / 8) + srow;

@@ -29,6 +29,7 @@ for s in $SECTIONS; do
                (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d "$OLDPWD/gpurun_out/pmc_bench_$pass" -o pmc -- python "$OLDPWD/bench.py" --steps 3 --warmup 1 --overlap 0 --no-cpu-baseline --no-profile >> "$OLDPWD/gpurun_out/pmcbench.log" 2>&1)
              done
              python tools/pmc_summary.py gpurun_out/pmc_bench_FETCH_SIZE gpurun_out/pmc_bench_WRITE_SIZE > gpurun_out/pmc_traffic.json 2>> gpurun_out/pmcbench.log ;;
+    gemmbench_xn1) PLIPMI_GEMM_XN=1 timeout 600 python tools/gpu_diag.py gemmbench > gpurun_out/diag_gemmbench_xn1.log 2>&1 ;;
     smoke)   timeout 600 python __graft_entry__.py --smoke > gpurun_out/smoke.log 2>&1 ;;
     *)       timeout 600 python tools/gpu_diag.py $s > gpurun_out/diag_$s.log 2>&1 ;;
   esac
