@@ -11,6 +11,7 @@
  *                            clip.load(arch) + load_state_dict(...)           reproducibility/embedders/factory.py:21-25
  *   plipmi_encode_image   <- self.model.get_image_features(**batch)           plip.py:50
  *                            self.model.encode_image(images)                  reproducibility/embedders/plip.py:48
+ *   plipmi_encode_image_u8<- self.preprocess(images=...) + get_image_features           plip.py:32-35,50
  *   plipmi_encode_text    <- self.model.get_text_features(**batch)            plip.py:68
  *                            self.model.encode_text(clip.tokenize(...))       reproducibility/embedders/plip.py:65-66
  *   plipmi_l2_normalize   <- x / np.linalg.norm(x, axis=-1, keepdims=True)    plip.py:75, embedders/plip.py:53,73
@@ -123,6 +124,11 @@ const char* plipmi_device_name(plipmi_handle h);
  *           (what CLIPEmbedder returns, embedders/plip.py:53).
  * B may be anything in [0, max_batch]. */
 int plipmi_encode_image(plipmi_handle h, const float* pixels, int B, float* out, int normalize, void* stream);
+
+/* Same, from raw tiles: uint8 [B,H,W,3] (HWC RGB, already image_size x image_size).  The CLIP normalisation
+ * (u8/255 - mean)/std of reproducibility/embedders/transform.py:45-52 / HF CLIPImageProcessor is fused into the
+ * patch unfold, so a tile crosses PCIe and HBM as 150 KB instead of 602 KB of fp32. */
+int plipmi_encode_image_u8(plipmi_handle h, const uint8_t* tiles, int B, float* out, int normalize, void* stream);
 
 /* ids            : int64 [B, context_length] token ids
  * attention_mask : int64 [B, context_length] (1 = token, 0 = padding) or NULL;

@@ -51,6 +51,7 @@ SYMBOLS = {
     "plipmi_last_error": (C.c_char_p, []),
     "plipmi_device_name": (C.c_char_p, [_vp]),
     "plipmi_encode_image": (_i, [_vp, _vp, _i, _vp, _i, _vp]),
+    "plipmi_encode_image_u8": (_i, [_vp, _vp, _i, _vp, _i, _vp]),
     "plipmi_encode_text": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _vp]),
     "plipmi_l2_normalize": (_i, [_vp, _vp, _i, _i, _vp]),
     "plipmi_logits": (_i, [_vp, _vp, _i, _vp, _i, _i, _f, _vp, _vp, _vp, _vp]),

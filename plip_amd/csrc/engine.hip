@@ -227,10 +227,14 @@ int run_layers(plipmi_engine* e, Tower& t, int B, int n_layers, int causal, cons
 }
 
 // CLIPVisionEmbeddings + pre_layrnorm (modeling_clip.py:202-218,642): x = LN(cat(cls, conv(pixels)) + pos)
-int vision_embed(plipmi_engine* e, const float* pixels, int B, hipStream_t s) {
+int vision_embed(plipmi_engine* e, const float* pixels, const uint8_t* tiles_u8, int B, hipStream_t s) {
   const plipmi_config& g = e->cfg;
   Tower& t = e->vis;
-  { Scope sc(e, s, "unfold_patches", 0, (double)B * 3 * g.image_size * g.image_size * 4 + (double)B * e->np * e->kpad * e->esz);
+  if (tiles_u8) {
+    Scope sc(e, s, "unfold_patches_u8", 0, (double)B * 3 * g.image_size * g.image_size + (double)B * e->np * e->kpad * e->esz);
+    HIP_TRY(launch_unfold_patches_u8(tiles_u8, e->patches, e->dtype, B, g.image_size, g.patch_size, e->kpad, s));
+  } else {
+    Scope sc(e, s, "unfold_patches", 0, (double)B * 3 * g.image_size * g.image_size * 4 + (double)B * e->np * e->kpad * e->esz);
     HIP_TRY(launch_unfold_patches(pixels, e->patches, e->dtype, B, g.image_size, g.patch_size, e->kpad, s)); }
   { Scope sc(e, s, "cls_rows", 0, (double)B * t.D * 4);
     HIP_TRY(launch_cls_rows(e->cls, e->vpos, t.x, B, t.S, t.D, s)); }
@@ -388,7 +392,17 @@ int plipmi_encode_image(plipmi_handle h, const float* pixels, int B, float* out,
   if (B == 0) return PLIPMI_OK;
   if (!pixels || !out) return fail(PLIPMI_ERR_INVALID, "null pixels/out");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  RUN(vision_embed(h, pixels, B, s));
+  RUN(vision_embed(h, pixels, nullptr, B, s));
+  RUN(run_layers(h, h->vis, B, h->vis.L, 0, nullptr, s));
+  return run_head(h, h->vis, nullptr, -1, h->post_w, h->post_b, h->vproj, h->vproj_t, h->vpooled, out, B, normalize, s);
+}
+
+int plipmi_encode_image_u8(plipmi_handle h, const uint8_t* tiles, int B, float* out, int normalize, void* stream) {
+  RUN(check_batch(h, B));
+  if (B == 0) return PLIPMI_OK;
+  if (!tiles || !out) return fail(PLIPMI_ERR_INVALID, "null tiles/out");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  RUN(vision_embed(h, nullptr, tiles, B, s));
   RUN(run_layers(h, h->vis, B, h->vis.L, 0, nullptr, s));
   return run_head(h, h->vis, nullptr, -1, h->post_w, h->post_b, h->vproj, h->vproj_t, h->vpooled, out, B, normalize, s);
 }
@@ -412,7 +426,7 @@ int plipmi_debug_hidden(plipmi_handle h, int tower, int layer, const void* input
   Tower& t = tower == PLIPMI_VISION ? h->vis : h->txt;
   if (tower != PLIPMI_VISION && tower != PLIPMI_TEXT) return fail(PLIPMI_ERR_INVALID, "tower must be 0 or 1");
   if (layer < 0 || layer > t.L) return fail(PLIPMI_ERR_INVALID, "layer %d outside [0,%d]", layer, t.L);
-  if (tower == PLIPMI_VISION) RUN(vision_embed(h, reinterpret_cast<const float*>(input), B, s));
+  if (tower == PLIPMI_VISION) RUN(vision_embed(h, reinterpret_cast<const float*>(input), nullptr, B, s));
   else RUN(text_embed(h, reinterpret_cast<const int64_t*>(input), B, s));
   RUN(run_layers(h, t, B, layer, tower == PLIPMI_TEXT, nullptr, s));
   HIP_TRY(hipMemcpyAsync(out, t.x, (size_t)B * t.S * t.D * 4, hipMemcpyDeviceToDevice, s));

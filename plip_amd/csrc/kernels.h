@@ -15,6 +15,11 @@ hipError_t launch_layernorm(const float* x, size_t x_row_stride, const float* g,
 hipError_t launch_unfold_patches(const float* pixels, void* out, int out_dtype, int B, int image, int patch, int Kpad,
                                  hipStream_t s);
 
+// Same unfold for raw tiles: uint8 [B,H,W,3] (HWC, what PIL / np.asarray give) with the CLIP normalisation
+// (u8/255 - mean[c]) / std[c] of reproducibility/embedders/transform.py:45-52 fused in.
+hipError_t launch_unfold_patches_u8(const uint8_t* tiles, void* out, int out_dtype, int B, int image, int patch,
+                                    int Kpad, hipStream_t s);
+
 // x[b,0,:] = class_embedding + pos[0,:]   (token rows 1.. are written by the patch GEMM epilogue)
 hipError_t launch_cls_rows(const float* cls, const float* pos, float* x, int B, int tokens, int D, hipStream_t s);
 

@@ -119,6 +119,46 @@ hipError_t launch_unfold_patches(const float* pixels, void* out, int out_dtype, 
   return hipGetLastError();
 }
 
+// uint8 HWC tiles: one thread produces 4 consecutive v of one (c,u) row = 4 pixels -> reads 4 x 3 bytes (12 contiguous).
+// Normalisation constants: CLIP mean/std (transform.py:50; HF CLIPImageProcessor defaults).
+template <typename TOut>
+__global__ __launch_bounds__(256) void unfold_u8_kernel(const uint8_t* __restrict__ px, TOut* __restrict__ out, int image,
+                                                        int P, int K, int Kpad) {
+  const float mean[3] = {0.48145466f, 0.4578275f, 0.40821073f};
+  const float istd[3] = {1.0f / 0.26862954f, 1.0f / 0.26130258f, 1.0f / 0.27577711f};
+  const int g = image / P;
+  const int row = blockIdx.x;
+  const int img = row / (g * g), cell = row - img * g * g, gi = cell / g, gj = cell - gi * g;
+  const uint8_t* base = px + ((size_t)img * image * image + (size_t)(gi * P) * image + gj * P) * 3;
+  TOut* orow = out + (size_t)row * Kpad;
+  for (int k = threadIdx.x * 4; k < Kpad; k += 256 * 4) {
+    float r[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int kk = k + e;
+      if (kk < K) {
+        const int c = kk / (P * P), rem = kk - c * P * P, u = rem / P, v = rem - u * P;
+        const float x = (float)base[((size_t)u * image + v) * 3 + c] / 255.0f;   // same op order as the reference
+        r[e] = (x - mean[c]) * istd[c];
+      } else {
+        r[e] = 0.f;
+      }
+    }
+    store4(orow + k, r[0], r[1], r[2], r[3]);
+  }
+}
+hipError_t launch_unfold_patches_u8(const uint8_t* tiles, void* out, int out_dtype, int B, int image, int patch,
+                                    int Kpad, hipStream_t s) {
+  if (B <= 0) return hipSuccess;
+  const int g = image / patch, K = 3 * patch * patch;
+  const dim3 grid(B * g * g), block(256);
+  if (out_dtype == 1)
+    hipLaunchKernelGGL(unfold_u8_kernel<bf16_t>, grid, block, 0, s, tiles, (bf16_t*)out, image, patch, K, Kpad);
+  else
+    hipLaunchKernelGGL(unfold_u8_kernel<float>, grid, block, 0, s, tiles, (float*)out, image, patch, K, Kpad);
+  return hipGetLastError();
+}
+
 // x[b,0,:] = class_embedding + position_embedding[0]   (modeling_clip.py:212-217)
 __global__ void cls_rows_kernel(const float* __restrict__ cls, const float* __restrict__ pos, float* __restrict__ x,
                                 int tokens, int D) {

@@ -122,6 +122,20 @@ class Engine:
                                                         self._stream()), "plipmi_encode_image")
         return out
 
+    def encode_image_u8(self, tiles: torch.Tensor, normalize: bool = False) -> torch.Tensor:
+        """uint8 [B,H,W,3] RGB tiles already at the model resolution -> fp32 [B,P]; the CLIP
+        normalisation is fused into the patch unfold on the GPU."""
+        cfg = self.cfg
+        if tiles.dtype != torch.uint8 or tiles.dim() != 4 or tuple(tiles.shape[1:]) != (cfg.image_size, cfg.image_size, 3):
+            raise ValueError(f"tiles must be uint8 [B,{cfg.image_size},{cfg.image_size},3], got {tiles.dtype} {tuple(tiles.shape)}")
+        with torch.cuda.device(self.device):
+            t = tiles.to(device=self.device).contiguous()
+            out = torch.empty((t.shape[0], cfg.projection_dim), dtype=torch.float32, device=self.device)
+            for a, b in self._chunks(t.shape[0]):
+                _lib.check(self.lib.plipmi_encode_image_u8(self._h, _ptr(t[a:b]), b - a, _ptr(out[a:b]), int(normalize),
+                                                           self._stream()), "plipmi_encode_image_u8")
+        return out
+
     def encode_text(self, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
                     normalize: bool = False, eos_token_id: Optional[int] = None) -> torch.Tensor:
         """int [B,ctx] token ids -> fp32 [B,P] on the GPU."""

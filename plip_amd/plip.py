@@ -22,6 +22,24 @@ from .model import PlipModel
 from .preprocess import load_tokenizer, preprocess_images
 
 
+def _native_u8_tiles(chunk, n_px):
+    """uint8 HWC tiles that are already at the model resolution -> one [B,n,n,3] array, else None."""
+    if torch.is_tensor(chunk):
+        return None
+    if isinstance(chunk, np.ndarray):
+        ok = chunk.dtype == np.uint8 and chunk.ndim == 4 and chunk.shape[1:] == (n_px, n_px, 3)
+        return np.ascontiguousarray(chunk) if ok else None
+    arrs = []
+    for im in chunk:
+        if isinstance(im, np.ndarray) and im.dtype == np.uint8 and im.shape == (n_px, n_px, 3):
+            arrs.append(im)
+        elif hasattr(im, "size") and hasattr(im, "mode") and im.size == (n_px, n_px):   # PIL image
+            arrs.append(np.asarray(im.convert("RGB"), dtype=np.uint8))
+        else:
+            return None
+    return np.stack(arrs) if arrs else None
+
+
 class PLIP:
     def __init__(self, model_name: str = None, auth_token=None, *, model: Optional[PlipModel] = None,
                  tokenizer: Optional[Callable] = None, dtype: str = "bf16", max_batch: int = 256,
@@ -48,6 +66,10 @@ class PLIP:
         with torch.no_grad():
             for s in range(0, len(images), batch_size):
                 chunk = images[s:s + batch_size]
+                tiles = _native_u8_tiles(chunk, n_px)
+                if tiles is not None:      # already n_px x n_px uint8: normalise on the GPU, fused into the unfold
+                    outs.append(self.model.engine.encode_image_u8(torch.from_numpy(tiles)))
+                    continue
                 if torch.is_tensor(chunk):
                     px = chunk
                 elif isinstance(chunk, np.ndarray) and chunk.dtype != np.uint8:

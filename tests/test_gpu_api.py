@@ -52,6 +52,24 @@ def test_plip_class_matches_oracle(engines):
     np.testing.assert_array_equal(nn, want_nn)
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_fused_u8_preprocessing_matches_processor_path(dtype, engines):
+    """plipmi_encode_image_u8 == CLIPImageProcessor arithmetic on native tiles + plipmi_encode_image."""
+    from plip_amd.preprocess import preprocess_images
+    model, cfg, sd, *_ = engines("tiny_b6", dtype)
+    rs = np.random.RandomState(9)
+    tiles = rs.randint(0, 256, size=(11, cfg.image_size, cfg.image_size, 3), dtype=np.uint8)
+    got = model.engine.encode_image_u8(torch.from_numpy(tiles)).cpu().numpy()
+    px = preprocess_images(list(tiles), cfg.image_size)
+    want = model.engine.encode_image(torch.from_numpy(px)).cpu().numpy()
+    # identical op order in fp32; differences only from the (x-mean)*(1/std) vs /std rounding before the bf16 cast
+    assert np.abs(got - want).max() < (2e-5 if dtype == "f32" else 3e-2)
+    ref = O.vision_tower(px, sd, cfg)
+    assert np.abs(got - ref).max() < (2e-4 if dtype == "f32" else 6e-2)
+    with pytest.raises(ValueError):
+        model.engine.encode_image_u8(torch.zeros(1, 8, 8, 3, dtype=torch.uint8))
+
+
 def test_openai_style_surface(engines):
     """encode_image / encode_text / model(images, tokens) of reproducibility/embedders/plip.py:48,66."""
     model, cfg, sd, px, ids, mask = engines("tiny_b5_zero_pad_ln100", "f32")
