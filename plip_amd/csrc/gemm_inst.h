@@ -3,6 +3,7 @@
 #pragma once
 #include "gemm.h"
 #include "gemm_persist.h"
+#include "gemm_8phase.h"
 
 namespace plipmi {
 
@@ -48,13 +49,28 @@ int launch_persist(const GemmParams& p, hipStream_t stream) {
 }
 
 template <typename T, int EPI>
+int launch_8phase(const GemmParams& p, hipStream_t stream) {
+  constexpr int LDS = 2 * 512 * 128;
+  auto kern = gemm_nt_8phase_kernel<T, EPI>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  const int nblk = ((p.M + 255) / 256) * (p.N / 256);
+  hipLaunchKernelGGL(kern, dim3(nblk), dim3(512), LDS, stream, p);
+  return (int)hipGetLastError();
+}
+
+template <typename T, int EPI>
 int launch_naive(const GemmParams& p, hipStream_t stream) {
   dim3 grid((p.N / 4 + 63) / 64, p.M);
   hipLaunchKernelGGL((gemm_nt_naive_kernel<T, EPI>), grid, dim3(64), 0, stream, p);
   return (int)hipGetLastError();
 }
 
-constexpr int kNumVariants = 20;
+constexpr int kNumVariants = 21;
 
 // table[variant][epilogue]
 template <typename T>
@@ -82,6 +98,7 @@ struct GemmTable {
       case 17: return launch_tiled<T, 128, 128, 2, 2, EPI, true, 3>;
       case 18: return launch_tiled<T, 256, 128, 4, 2, EPI, true, 1, 0, 3>;
       case 19: return launch_tiled<T, 128, 256, 2, 4, EPI, true, 1, 0, 3>;
+      case 20: return launch_8phase<T, EPI>;
       case -2: return launch_naive<T, EPI>;
       default: return nullptr;
     }
