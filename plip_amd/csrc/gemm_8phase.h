@@ -14,11 +14,12 @@
 //     h likewise for the four N groups.  A half-tile (128 rows x 128 B = 16 KB = 2 LDS-DMA ops per
 //     thread) is refilled for K tile t+2 as soon as its last reader is two barriers behind, so fills
 //     run up to 1.75 K tiles ahead and are issued one half-tile per phase;
-//   * the only memory wait in the loop is one counted `s_waitcnt vmcnt(4)` per K tile (vmcnt retires in
-//     order: K tile t+1 has landed, the two newest half-tiles may still be in flight).
+//   * the memory waits in the loop are counted (`s_waitcnt vmcnt(8)` / `vmcnt(4)`, never 0 in steady state):
+//     vmcnt retires in order, so "all but the N newest LDS-DMA ops" == "the half-tiles needed next have landed".
 // Hazard rules used (two wave groups one barrier apart, cf. cdna_hip_programming.md 8-phase notes):
-//   RAW  data waited for before program barrier n may be read after program barrier n+1;
-//   WAR  a slot whose reads were retired (lgkmcnt 0) before program barrier n may be refilled after n+1.
+//   RAW  a half-tile waited for (vmcnt) in phase p may be read from phase p+1 on;
+//   WAR  a slot whose last ds_read was issued in phase p may be refilled from phase p+2 on (the read itself
+//        is only retired after that phase's first barrier).
 #pragma once
 #include "gemm.h"
 
@@ -118,11 +119,12 @@ void gemm_nt_8phase_kernel(const GemmParams p) {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) bf[ks] = *reinterpret_cast<const u32x4*>(sb + foff[ks]);
   };
-  // end of a load section: LDS reads retired, then the barrier that hands the matrix pipe to this wave
+  // end of a load section: the ds_reads are only ISSUED here; they are waited for after the barrier, so their
+  // latency overlaps the barrier wait / the tail of the partner group's MFMA section
   auto bar_load = [&]() {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
   };
   auto mma_q = [&](int qa, int qb, const u32x4 (&bf)[4]) {
@@ -160,6 +162,12 @@ void gemm_nt_8phase_kernel(const GemmParams p) {
   if (wm == 1) __builtin_amdgcn_s_barrier();  // group 1 now runs one barrier behind group 0
   if (trace && tid == 0) trace[1] = __builtin_amdgcn_s_memtime();
 
+  // Slot reuse (refill >= 2 phases after the slot's last ds_read was issued) and the waits (>= 1 phase before
+  // the first read of the data):
+  //   phase 1 reads A0,B0(t)   issues A1(t+1)            [A1 slot of the other stage: last read phase 3 of t-1]
+  //   phase 2 reads B1(t)      waits A1(t)     vmcnt(8)  [younger: A0,B0,B1,A1 of t+1]
+  //   phase 3 reads A1(t)      issues A0(t+2)            [A0 slot: last read phase 1]
+  //   phase 4 reads -          waits A0,B0,B1(t+1) vmcnt(4) [younger: A1(t+1), A0(t+2)]; issues B0,B1(t+2)
   for (int t = 0; t < KT; ++t) {
     const int buf = t & 1;
     const bool n1 = t + 1 < KT, n2 = t + 2 < KT;
@@ -170,21 +178,22 @@ void gemm_nt_8phase_kernel(const GemmParams p) {
     bar_load();
     mma_q(0, 0, bf0);
     // phase 2: (A0, B1)
-    if (n2) fill_a(0, buf);
+    if (n1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else wait_vm0();
     read_b(buf, 1, bf1);
     bar_load();
     mma_q(0, 1, bf1);
     // phase 3: (A1, B1)
-    if (n2) fill_w(0, buf);
+    if (n2) fill_a(0, buf);
     read_a(buf, 1);
     bar_load();
     mma_q(1, 1, bf1);
-    // phase 4: (A1, B0) -- no new fragments; K tile t+1 must have landed two barriers before its first read
+    // phase 4: (A1, B0)
     if (n1) {
       if (n2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else wait_vm0();
+      else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     }
-    if (n2) fill_w(1, buf);
+    if (n2) { fill_w(0, buf); fill_w(1, buf); }
     bar_load();
     mma_q(1, 0, bf0);
   }
