@@ -23,6 +23,8 @@ for s in $SECTIONS; do
              done ;;
     trace)   echo "${TRACE_ARGS:-5 12800 3072 768 1;6 12800 3072 768 1;7 12800 3072 768 1;5 12800 768 3072 2;1 12800 768 768 2;8 12800 768 768 2}" | tr ';' '\n' | while read a; do
                timeout 120 python tools/gpu_diag.py gemmtrace $a >> gpurun_out/diag_gemmtrace.log 2>&1; done ;;
+    ablate8) for ab in 0 1 2 8 9 10 16 17 26 27; do echo "=== 8phase ABLATE=$ab (1 no fills, 2 no MFMA, 8 no loop barriers, 16 no LDS reads)" >> gpurun_out/diag_ablate8.log
+               PLIPMI_GEMM_ABLATE=$ab timeout 120 python tools/gpu_diag.py gemmtrace 20 12800 2304 768 0 2>&1 | grep -E "main loop" >> gpurun_out/diag_ablate8.log; done ;;
     ablate)  for ab in 0 1 2 3 4 6; do echo "=== PLIPMI_GEMM_ABLATE=$ab (1: no K-loop fills, 2: no MFMA, 4: no epilogue)" >> gpurun_out/diag_ablate.log
                PLIPMI_GEMM_ABLATE=$ab timeout 120 python tools/gpu_diag.py gemmtrace ${ABLATE_ARGS:-6 12800 3072 768 1} 2>&1 | grep -E "variant|prologue|main loop|epilogue|lifetime" >> gpurun_out/diag_ablate.log; done ;;
     pmcbench) for pass in "FETCH_SIZE" "WRITE_SIZE"; do
