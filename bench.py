@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="lower bound of CPU work for the baseline sample")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--no-fp32-tower", action="store_true", help="skip the BASELINE configs[1] side measurement")
     ap.add_argument("--overlap", type=int, default=1, help="1: text tower on a second HIP stream (default), 0: one stream")
     return ap.parse_args()
 
@@ -247,6 +248,38 @@ def main():
         "roofline_single_stream": roofline_1s,
         "kernels": kernels,
     }
+    if world == 1 and not args.no_fp32_tower and args.dtype == "bf16":
+        # BASELINE.json configs[1]: ViT-B/32 image tower only, bs=256, fp32 (exact-fp32 MFMA engine), same pixels
+        try:
+            m32 = PlipModel(cfg, sd, device=dev, dtype="f32", max_batch=B)
+            for _ in range(2):
+                m32.engine.encode_image(px, True)
+            torch.cuda.synchronize(dev)
+            n32 = max(3, args.steps // 4)
+            t1 = time.perf_counter()
+            for _ in range(n32):
+                e32 = m32.engine.encode_image(px, True)
+            torch.cuda.synchronize(dev)
+            dt32 = (time.perf_counter() - t1) / n32
+            rows32 = []
+            with m32.engine.profile(rows32):
+                m32.engine.encode_image(px, True)
+            rows32.sort(key=lambda r: -r["total_ms"])
+            dom32 = next((r for r in rows32 if r["flops"] > 0), None)
+            e16 = model.engine.encode_image(px, True)
+            res["config1_fp32_image_tower"] = {
+                "workload": "ViT-B/32 image tower only, bs=256, fp32 (v_mfma_f32_32x32x2_f32), synthetic 224px tiles",
+                "images_per_s": round(B / dt32, 1), "ms_per_step": round(dt32 * 1e3, 3),
+                "algorithmic_tflops": round(B * cfg.image_flops() / dt32 / 1e12, 2),
+                "roofline": None if dom32 is None else {
+                    "bound": "mfma", "kernel": dom32["name"], "peak": PEAK_TFLOPS["f32"], "unit": "TFLOP/s",
+                    "achieved": round(dom32["flops"] / (dom32["total_ms"] * 1e9), 2),
+                    "frac": round(dom32["flops"] / (dom32["total_ms"] * 1e9) / PEAK_TFLOPS["f32"], 4)},
+                "bf16_vs_fp32_embedding_max_abs_diff": float((e16 - e32).abs().max())}
+            m32.engine.close()
+            del m32
+        except Exception as e:  # pragma: no cover
+            res["config1_fp32_image_tower"] = {"error": repr(e)}
     if world == 1 and not args.no_cpu_baseline:
         # parity on a small sample, then the timed CPU baseline (rank 0, N=1 only)
         try:

@@ -319,6 +319,31 @@ void gemm_nt_kernel(const GemmParams p) {                                       
     }
   };
 
+  // SCHED 4 (3-stage ring only): the fragments of the NEXT K tile's first K step are read during the last K
+  // step of the current tile -- that tile has been visible since the previous barrier -- so no wave starts an
+  // iteration with an exposed LDS round trip behind the barrier.
+  u32x4 xfp[2][MI], wfp[2][NI];
+  auto load_frags = [&](int buf, int ks, int set) {
+    const char* sb = smem + buf * STAGE;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) xfp[set][i] = *reinterpret_cast<const u32x4*>(sb + a_tile + i * 32 * 128 + foff[ks]);
+#pragma unroll
+    for (int j = 0; j < NI; ++j) wfp[set][j] = *reinterpret_cast<const u32x4*>(sb + w_tile + j * 32 * 128 + foff[ks]);
+  };
+  auto compute_x = [&](int buf, int next_buf) {  // set 0 already holds K step 0 of `buf`
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      if (ks < 3) load_frags(buf, ks + 1, (ks + 1) & 1);
+      else if (next_buf >= 0) load_frags(next_buf, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) mma16<T>(acc[i][j], wfp[ks & 1][j], xfp[ks & 1][i]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
   // ---- main loop: tile kt+1 streams in while tile kt is multiplied; one barrier per tile.
   const int KT = p.K / BK;
   unsigned long long* trace = p.trace ? p.trace + (size_t)bid * 8 : nullptr;
@@ -329,7 +354,25 @@ void gemm_nt_kernel(const GemmParams p) {                                       
                ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20 /* XCC_ID [3:0] */) << 32);
     trace[6] = KT;
   }
-  if constexpr (NSTAGE == 3) {
+  if constexpr (NSTAGE == 3 && SCHED == 4) {
+    static_assert(SCHED != 4 || (GLDS && L2PF == 0), "cross-tile fragment prefetch needs the LDS-DMA 3-stage ring");
+    stage_issue(0);
+    if (KT > 1) stage_issue(1);
+    wait_vm0();
+    __syncthreads();  // tiles 0 and 1 visible
+    if (trace && tid == 0) trace[1] = __builtin_amdgcn_s_memtime();
+    load_frags(0, 0, 0);
+    int cur = 0, nxt1 = 1, nxt2 = 2;
+    for (int kt = 0; kt < KT; ++kt) {
+      if (kt + 2 < KT) stage_issue(nxt2);          // stage of tile kt-1: every wave left it at the last barrier
+      compute_x(cur, kt + 1 < KT ? nxt1 : -1);
+      if (kt + 1 < KT) {
+        wait_vm0();                                // tile kt+2 landed (one whole iteration in flight)
+        __syncthreads();                           // ... and is visible; stage `cur` is free
+      }
+      const int tmp = cur; cur = nxt1; nxt1 = nxt2; nxt2 = tmp;
+    }
+  } else if constexpr (NSTAGE == 3) {
     static_assert(NSTAGE != 3 || (GLDS && L2PF == 0 && SCHED != 3), "3-stage ring: LDS-DMA fills issued at the loop top");
     stage_issue(0);
     if (KT > 1) {

@@ -18,6 +18,7 @@ static const GemmVariant kVariants[kNumVariants] = {
     {"256x256_w4x2_glds_spreadfill", 256, 256, 512, true}, {"128x128_w2x2_glds_spreadfill", 128, 128, 256, true},
     {"256x128_w4x2_glds_3stage", 256, 128, 512, true}, {"128x256_w2x4_glds_3stage", 128, 256, 512, true},
     {"256x256_w2x4_8phase", 256, 256, 512, true},
+    {"256x128_w4x2_3stage_xprefetch", 256, 128, 512, true}, {"128x256_w2x4_3stage_xprefetch", 128, 256, 512, true},
 };
 
 int gemm_num_cus() {
