@@ -171,6 +171,9 @@ int plipmi_debug_hidden(plipmi_handle h, int tower, int layer, const void* input
 int plipmi_gemm_nt(int dtype, int epilogue, int variant, int M, int N, int K, const void* A, const void* W,
                    const float* bias, float alpha, void* C, void* stream);
 const char* plipmi_gemm_variant_name(int variant);
+/* same call with explicit leading dimensions (in elements) for A [M,K] and W [N,K]: rows may be padded */
+int plipmi_gemm_nt_ld(int dtype, int epilogue, int variant, int M, int N, int K, const void* A, int lda, const void* W,
+                      int ldw, const float* bias, float alpha, void* C, void* stream);
 /* same call with an in-kernel timeline: trace = device buffer of 8 x uint64 per workgroup
  * {start, prologue done, main loop done, epilogue done (s_memtime ticks), tile id, HW_ID|XCC_ID<<32, k tiles, 0} */
 int plipmi_gemm_nt_traced(int dtype, int epilogue, int variant, int M, int N, int K, const void* A, const void* W,

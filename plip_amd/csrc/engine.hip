@@ -488,6 +488,23 @@ int plipmi_attention(int dtype, int impl, const void* qkv, void* out, int B, int
   return PLIPMI_OK;
 }
 
+int plipmi_gemm_nt_ld(int dtype, int epilogue, int variant, int M, int N, int K, const void* A, int lda, const void* W,
+                      int ldw, const float* bias, float alpha, void* C, void* stream) {
+  if (dtype != PLIPMI_F32 && dtype != PLIPMI_BF16) return fail(PLIPMI_ERR_INVALID, "bad dtype");
+  if (epilogue < 0 || epilogue > EPI_SCALE) return fail(PLIPMI_ERR_INVALID, "epilogue must be 0..3");
+  const int per16 = dtype == PLIPMI_BF16 ? 8 : 4;
+  if (M < 0 || N <= 0 || K <= 0 || !A || !W || !C || lda < K || ldw < K || lda % per16 || ldw % per16)
+    return fail(PLIPMI_ERR_INVALID, "bad shape / leading dimension (must be >= K and a multiple of 16 bytes)");
+  if (epilogue != EPI_SCALE && !bias) return fail(PLIPMI_ERR_INVALID, "bias required for this epilogue");
+  GemmParams p;
+  p.A = A; p.W = W; p.C = C; p.bias = bias; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldc = N;
+  p.alpha = alpha; p.np = 1;
+  const int rc = gemm_launch(dtype, epilogue, variant, p, reinterpret_cast<hipStream_t>(stream), nullptr);
+  if (rc != 0) return fail(PLIPMI_ERR_HIP, "gemm launch failed (variant %d, M=%d N=%d K=%d): %s", variant, M, N, K,
+                           hipGetErrorString((hipError_t)rc));
+  return PLIPMI_OK;
+}
+
 const char* plipmi_gemm_variant_name(int variant) {
   if (variant < 0 || variant >= gemm_num_variants()) return nullptr;
   return gemm_variant(variant).name;

@@ -263,6 +263,22 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = Non
     return out
 
 
+def gemm_nt_ld(a: torch.Tensor, w: torch.Tensor, K: int, bias: Optional[torch.Tensor] = None, epilogue: int = 0,
+               variant: int = -1, alpha: float = 1.0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """epilogue(A[:, :K] @ W[:, :K]^T) on row-padded operands: a [M, lda >= K], w [N, ldw >= K] (tests)."""
+    lib = _lib.load()
+    assert a.is_cuda and w.is_cuda and a.dtype == w.dtype and a.is_contiguous() and w.is_contiguous()
+    code = _lib.BF16 if a.dtype == torch.bfloat16 else _lib.F32
+    M, N = a.shape[0], w.shape[0]
+    if out is None:
+        out = torch.zeros((M, N), dtype=a.dtype if epilogue in (0, 1) else torch.float32, device=a.device)
+    with torch.cuda.device(a.device):
+        _lib.check(lib.plipmi_gemm_nt_ld(code, epilogue, variant, M, N, K, _ptr(a), a.shape[1], _ptr(w), w.shape[1],
+                                         _ptr(bias), float(alpha), _ptr(out),
+                                         C.c_void_p(torch.cuda.current_stream(a.device).cuda_stream)), "plipmi_gemm_nt_ld")
+    return out
+
+
 def attention(qkv: torch.Tensor, B: int, S: int, H: int, causal: bool = False, key_mask: Optional[torch.Tensor] = None,
               impl: int = 0) -> torch.Tensor:
     """Kernel-level entry (tests): qkv [B*S, 3*H*64] (scale folded into q) -> [B*S, H*64]."""

@@ -179,6 +179,30 @@ def sec_gemmbench():
             print(f"{name:8s} {M:6d}x{N:5d}x{K:5d} epi{epi}: " + " ".join(row))
 
 
+def sec_ldpad():
+    """Does padding the leading dimension (rows no longer a multiple of 2 KB apart) change the fill rate?"""
+    from plip_amd.engine import gemm_nt_ld
+    g = torch.Generator().manual_seed(0)
+    shapes = [("v.qkv", 12800, 2304, 768, 0), ("v.fc1", 12800, 3072, 768, 1), ("v.fc2", 12800, 768, 3072, 2),
+              ("t.fc1", 19712, 2048, 512, 1), ("t.fc2", 19712, 512, 2048, 2), ("v.out", 12800, 768, 768, 2)]
+    for name, M, N, K, epi in shapes:
+        row = []
+        for pad in (0, 8, 32, 64, 72, 128):
+            a = torch.randn(M, K + pad, generator=g).to(dev).to(torch.bfloat16)
+            w = (torch.randn(N, K + pad, generator=g) / K ** 0.5).to(dev).to(torch.bfloat16)
+            bias = torch.randn(N, generator=g).to(dev)
+            out = torch.zeros(M, N, device=dev, dtype=torch.bfloat16 if epi in (0, 1) else torch.float32)
+            res = []
+            for v in (16, 8):
+                if N % 256 and v == 16:
+                    res.append("  n/a")
+                    continue
+                ms = _time(lambda: gemm_nt_ld(a, w, K, bias, epilogue=epi, variant=v, out=out), iters=20)
+                res.append(f"{2.0 * M * N * K / ms / 1e9:6.1f}")
+            row.append(f"pad{pad}: " + "/".join(res))
+        print(f"{name:6s} {M}x{N}x{K} (variants 16/8): " + "   ".join(row))
+
+
 def sec_gemmone():
     """One variant / one shape in a loop -- the target of rocprofv3 --pmc runs.
     usage: gpu_diag.py gemmone <variant> <M> <N> <K> <epi> [bf16|f32] [iters]"""
@@ -302,6 +326,6 @@ def sec_e2e():
 
 if __name__ == "__main__":
     t0 = time.time()
-    {"gemm": sec_gemm, "attn": sec_attn, "tiny": sec_tiny, "vitb32": sec_vitb32, "gemmbench": sec_gemmbench, "e2e": sec_e2e, "gemmone": sec_gemmone, "gemmtrace": sec_gemmtrace,
+    {"gemm": sec_gemm, "attn": sec_attn, "tiny": sec_tiny, "vitb32": sec_vitb32, "gemmbench": sec_gemmbench, "e2e": sec_e2e, "gemmone": sec_gemmone, "ldpad": sec_ldpad, "gemmtrace": sec_gemmtrace,
      "overlap": sec_overlap}[sys.argv[1]]()
     print(f"[{sys.argv[1]} done in {time.time() - t0:.1f} s]")
