@@ -157,7 +157,7 @@ def main():
     ids, mask = torch.from_numpy(ids_np).to(dev), torch.from_numpy(mask_np).to(dev)
 
     def step():
-        return sharded_pair_logits(model, px, ids, mask, overlap=bool(args.overlap))
+        return sharded_pair_logits(model, px, ids, mask, overlap=bool(args.overlap), equal_shards=True)
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -186,7 +186,7 @@ def main():
         rows = []
         with model.engine.profile(rows):
             for _ in range(args.steps):
-                sharded_pair_logits(model, px, ids, mask, overlap=overlap)
+                sharded_pair_logits(model, px, ids, mask, overlap=overlap, equal_shards=True)
         rows.sort(key=lambda r: -r["total_ms"])
         return rows
 

@@ -22,15 +22,22 @@ def shard_bounds(n: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def all_gather_rows(local: torch.Tensor, group=None) -> torch.Tensor:
+def all_gather_rows(local: torch.Tensor, group=None, equal_shards: bool = False) -> torch.Tensor:
     """Concatenate every rank's ``[n_r, ...]`` rows in rank order -> ``[sum n_r, ...]``.
 
     Equal shards go through one ``all_gather_into_tensor`` (a single RCCL collective on
-    contiguous buffers); ragged shards are padded to the longest one first.
+    contiguous buffers); ragged shards are padded to the longest one first.  ``equal_shards=True``
+    (the caller guarantees n_r is the same on every rank, e.g. a fixed per-GPU batch) skips the
+    size exchange and its host synchronisation: the step then contains exactly ONE collective per matrix.
     """
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
         return local
     world = dist.get_world_size(group)
+    if equal_shards:
+        local = local.contiguous()
+        out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out, local, group=group)
+        return out
     n_local = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
     sizes = [torch.zeros_like(n_local) for _ in range(world)]
     dist.all_gather(sizes, n_local, group=group)
@@ -49,7 +56,8 @@ def all_gather_rows(local: torch.Tensor, group=None) -> torch.Tensor:
 
 
 def sharded_pair_logits(model, pixels_local: torch.Tensor, ids_local: torch.Tensor,
-                        attention_mask_local: Optional[torch.Tensor] = None, group=None, overlap: bool = True):
+                        attention_mask_local: Optional[torch.Tensor] = None, group=None, overlap: bool = True,
+                        equal_shards: bool = False):
     """One data-parallel step of CLIPModel.forward: this rank embeds ITS images and captions,
     the normalised embeddings are all-gathered, and the rank computes its row block of
     ``logits_per_image`` ([n_local, N_text]) against every caption of the global batch.
@@ -62,8 +70,8 @@ def sharded_pair_logits(model, pixels_local: torch.Tensor, ids_local: torch.Tens
     else:
         img = eng.encode_image(pixels_local, normalize=True)
         txt = eng.encode_text(ids_local, attention_mask_local, normalize=True)
-    txt_all = all_gather_rows(txt, group)
-    img_all = all_gather_rows(img, group)
+    txt_all = all_gather_rows(txt, group, equal_shards)
+    img_all = all_gather_rows(img, group, equal_shards)
     lpi, _, _ = eng.logits(img, txt_all, scale=eng.logit_scale_exp, want_text=False)
     return lpi, img_all, txt_all
 

@@ -59,6 +59,9 @@ def _worker(rank, world, port, n, q):
         cls = model.engine.encode_text(ids[:3], normalize=True)
         pred = sharded_zero_shot(model, px[lo:hi], cls)
         ragged = all_gather_rows(torch.full((rank + 1, 2), float(rank)))
+        if n % world == 0:   # the fixed-batch fast path (no size exchange) must give the same matrix
+            fast = sharded_pair_logits(model, px[lo:hi], ids[lo:hi], equal_shards=True)
+            assert torch.equal(fast[0], rows) and torch.equal(fast[1], img_all) and torch.equal(fast[2], txt_all)
         q.put((rank, lo, hi, rows.numpy(), img_all.numpy(), txt_all.numpy(), pred.numpy(), ragged.numpy()))
     finally:
         dist.destroy_process_group()

@@ -32,6 +32,7 @@ for s in $SECTIONS; do
              done
              python tools/pmc_summary.py gpurun_out/pmc_bench_FETCH_SIZE gpurun_out/pmc_bench_WRITE_SIZE > gpurun_out/pmc_traffic.json 2>> gpurun_out/pmcbench.log ;;
     gemmbench_xn1) PLIPMI_GEMM_XN=1 timeout 600 python tools/gpu_diag.py gemmbench > gpurun_out/diag_gemmbench_xn1.log 2>&1 ;;
+    torchrun1) timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline --no-fp32-tower > gpurun_out/bench_torchrun1.json 2> gpurun_out/bench_torchrun1.err ;;
     smoke)   timeout 600 python __graft_entry__.py --smoke > gpurun_out/smoke.log 2>&1 ;;
     *)       timeout 600 python tools/gpu_diag.py $s > gpurun_out/diag_$s.log 2>&1 ;;
   esac
