@@ -12,8 +12,8 @@ for s in $SECTIONS; do
     pytest)  timeout 1200 python -m pytest tests -m gpu -q -x > gpurun_out/pytest_gpu.log 2>&1 ;;
     pytestall) timeout 1500 python -m pytest tests -m gpu -q > gpurun_out/pytest_gpu.log 2>&1 ;;
     bench)   timeout 600 python bench.py --steps 20 --warmup 3 > gpurun_out/bench.json 2> gpurun_out/bench.err ;;
-    rocprof) (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/gpurun_out/prof" -o plip -- python "$OLDPWD/bench.py" --steps 10 --warmup 2 --no-cpu-baseline --no-profile > "$OLDPWD/gpurun_out/rocprof_bench.json" 2> "$OLDPWD/gpurun_out/rocprof.err")
-             (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/gpurun_out/prof1s" -o plip -- python "$OLDPWD/bench.py" --steps 10 --warmup 2 --no-cpu-baseline --no-profile --overlap 0 > "$OLDPWD/gpurun_out/rocprof_bench_1stream.json" 2>> "$OLDPWD/gpurun_out/rocprof.err") ;;
+    rocprof) (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/gpurun_out/prof" -o plip -- python "$OLDPWD/bench.py" --steps 10 --warmup 2 --no-cpu-baseline --no-profile --no-fp32-tower > "$OLDPWD/gpurun_out/rocprof_bench.json" 2> "$OLDPWD/gpurun_out/rocprof.err")
+             (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/gpurun_out/prof1s" -o plip -- python "$OLDPWD/bench.py" --steps 10 --warmup 2 --no-cpu-baseline --no-profile --no-fp32-tower --overlap 0 > "$OLDPWD/gpurun_out/rocprof_bench_1stream.json" 2>> "$OLDPWD/gpurun_out/rocprof.err") ;;
     bench1s) timeout 600 python bench.py --steps 20 --warmup 3 --overlap 0 --no-cpu-baseline > gpurun_out/bench_1stream.json 2>> gpurun_out/bench.err ;;
     pmc)     # hardware counters of the dominant GEMM (own passes, kernel-trace only -- see MI355X_MICROARCH rocprofv3 notes)
              for pass in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_VALU_MFMA_BUSY_CYCLES" \
@@ -28,7 +28,7 @@ for s in $SECTIONS; do
     ablate)  for ab in 0 1 2 3 4 6; do echo "=== PLIPMI_GEMM_ABLATE=$ab (1: no K-loop fills, 2: no MFMA, 4: no epilogue)" >> gpurun_out/diag_ablate.log
                PLIPMI_GEMM_ABLATE=$ab timeout 120 python tools/gpu_diag.py gemmtrace ${ABLATE_ARGS:-6 12800 3072 768 1} 2>&1 | grep -E "variant|prologue|main loop|epilogue|lifetime" >> gpurun_out/diag_ablate.log; done ;;
     pmcbench) for pass in "FETCH_SIZE" "WRITE_SIZE"; do
-               (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d "$OLDPWD/gpurun_out/pmc_bench_$pass" -o pmc -- python "$OLDPWD/bench.py" --steps 3 --warmup 1 --overlap 0 --no-cpu-baseline --no-profile >> "$OLDPWD/gpurun_out/pmcbench.log" 2>&1)
+               (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d "$OLDPWD/gpurun_out/pmc_bench_$pass" -o pmc -- python "$OLDPWD/bench.py" --steps 3 --warmup 1 --overlap 0 --no-cpu-baseline --no-profile --no-fp32-tower >> "$OLDPWD/gpurun_out/pmcbench.log" 2>&1)
              done
              python tools/pmc_summary.py gpurun_out/pmc_bench_FETCH_SIZE gpurun_out/pmc_bench_WRITE_SIZE > gpurun_out/pmc_traffic.json 2>> gpurun_out/pmcbench.log ;;
     gemmbench_xn1) PLIPMI_GEMM_XN=1 timeout 600 python tools/gpu_diag.py gemmbench > gpurun_out/diag_gemmbench_xn1.log 2>&1 ;;
