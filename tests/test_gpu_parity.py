@@ -146,3 +146,39 @@ def test_eos_pooling_rules(engines):
     o = O.text_tower(ids2, sd, cfg.replace(eos_token_id=tok), None)
     c = model.engine.encode_text(torch.from_numpy(ids2), None, eos_token_id=tok).cpu().numpy()
     assert np.abs(c - o).max() < 2e-4
+
+
+def test_long_sequence_vision_tower_uses_exact_attention():
+    """196+1 vision tokens (patch 16 at 224 px, as ViT-B/16): beyond the 128-token MFMA attention kernel, so the
+    bf16 engine dispatches the exact-fp32 attention kernel for that tower; parity vs the oracle either way."""
+    from plip_amd import weights as W
+    from plip_amd.config import get_config
+    from plip_amd.model import PlipModel
+    cfg = get_config("tiny").replace(image_size=224, patch_size=16)      # 197 tokens, width 128
+    sd = W.synthetic_state_dict(cfg, 4)
+    px = W.synthetic_pixels(cfg, 3, 5)
+    ids, mask = W.synthetic_ids(cfg, 3, 6)
+    ref = O.clip_forward(px, ids, sd, cfg, mask)
+    for dtype, tol in (("f32", 2e-4), ("bf16", 6e-2)):
+        m = PlipModel(cfg, sd, dtype=dtype, max_batch=4)
+        img = m.get_image_features(pixel_values=torch.from_numpy(px)).cpu().numpy()
+        assert np.abs(img - ref["image_features"]).max() < tol, dtype
+        out = m(input_ids=torch.from_numpy(ids), pixel_values=torch.from_numpy(px), attention_mask=torch.from_numpy(mask))
+        scale = float(np.exp(np.float64(sd["logit_scale"])))
+        err = np.abs(out.logits_per_image.cpu().numpy() - ref["logits_per_image"]).max() / scale
+        assert err < (1e-5 if dtype == "f32" else 3e-3), (dtype, err)
+        m.engine.close()
+
+
+def test_batch_edge_cases(engines):
+    """B = 1, B = max_batch, B = max_batch + 1 (chunked) and empty input."""
+    model, cfg, sd, px, ids, mask = engines("tiny_b6", "f32", 4)
+    tpx, tids = torch.from_numpy(px), torch.from_numpy(ids)
+    full = model.get_image_features(pixel_values=tpx)                     # 6 > max_batch 4 -> two engine calls
+    one = model.get_image_features(pixel_values=tpx[2:3])
+    assert torch.equal(one, full[2:3])
+    four = model.get_image_features(pixel_values=tpx[:4])
+    assert torch.equal(four, full[:4])
+    t_full = model.get_text_features(input_ids=tids)
+    assert torch.equal(model.get_text_features(input_ids=tids[5:6]), t_full[5:6])
+    assert model.get_text_features(input_ids=tids[:0]).shape == (0, cfg.projection_dim)
