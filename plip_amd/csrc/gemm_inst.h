@@ -70,7 +70,7 @@ int launch_naive(const GemmParams& p, hipStream_t stream) {
   return (int)hipGetLastError();
 }
 
-constexpr int kNumVariants = 25;
+constexpr int kNumVariants = 27;
 
 // table[variant][epilogue]
 template <typename T>
@@ -103,6 +103,8 @@ struct GemmTable {
       case 22: return launch_tiled<T, 128, 256, 2, 4, EPI, true, 4, 0, 3>;
       case 23: return launch_tiled<T, 192, 256, 2, 4, EPI, true, 3>;
       case 24: return launch_tiled<T, 192, 256, 2, 4, EPI, true, 1>;
+      case 25: return launch_tiled<T, 320, 256, 2, 4, EPI, true, 3>;
+      case 26: return launch_tiled<T, 320, 256, 2, 4, EPI, true, 0>;
       case -2: return launch_naive<T, EPI>;
       default: return nullptr;
     }
