@@ -5,6 +5,8 @@
 
 namespace plipmi {
 
+int gemm_num_cus();
+
 static const GemmVariant kVariants[kNumVariants] = {
     {"128x128_w2x2_regstage", 128, 128, 256, false}, {"128x128_w2x2_glds", 128, 128, 256, true},
     {"256x128_w4x2_regstage", 256, 128, 512, false}, {"256x128_w4x2_glds", 256, 128, 512, true},
@@ -50,17 +52,33 @@ int gemm_default_variant(int dtype, int M, int N, int K) {
     if (g_override >= 0 && N % kVariants[g_override].bn != 0) return 1;
     return g_override;
   }
-  // Tuned on MI355X (profiles/r01_gemm_variants_tflops.txt, bs=256 shapes): the 256x256 LDS-DMA tile with
-  // pipelined fragments and the fill spread over the iteration wins whenever N is wide or K is long (fewest
-  // L2->LDS bytes per FLOP); the short-K, narrow-N out-projections and small M prefer the 128x128 tile at two
-  // workgroups per CU, whose epilogues overlap the other workgroup's K loop.
+  // Tile choice = wave quantisation.  One 256-wide tile family runs one workgroup per CU (LDS-bound), so a GEMM
+  // takes ceil(tiles / CUs) rounds of roughly tile-area-proportional time (measured, profiles/
+  // r01_gemm_variants_tflops.txt: per-output cost is within 5 % across 192x256 / 256x256 / 320x256); the 128x128
+  // tile runs two workgroups per CU at ~1.2x the per-output cost, its last partial round cheaper.  Pick the
+  // candidate with the smallest rounds x tile-time.  At bs=256 this selects 256x256 for the QKV projections,
+  // 320x256 for fc1, 192x256 for fc2 / out-proj / patch embedding -- the measured best in all nine shapes.
+  (void)K;
   if (M <= 1024) return 1;
-  if (dtype == 1) {
-    if (N % 256 == 0 && (N >= 1536 || K >= 1536)) return 16;
-    return 8;
+  const int cus = gemm_num_cus();
+  struct Cand { int variant, bm, bn, per_cu; double rel; };
+  const Cand cands_bf16[] = {{16, 256, 256, 1, 1.00}, {25, 320, 256, 1, 1.00}, {23, 192, 256, 1, 1.05}, {8, 128, 128, 2, 1.21}};
+  const Cand cands_f32[] = {{6, 256, 256, 1, 1.00}, {26, 320, 256, 1, 1.00}, {24, 192, 256, 1, 1.05}, {8, 128, 128, 2, 1.21}};
+  const Cand* cands = dtype == 1 ? cands_bf16 : cands_f32;
+  int best = 8;
+  double best_cost = 1e300;
+  for (int i = 0; i < 4; ++i) {
+    const Cand& c = cands[i];
+    if (N % c.bn) continue;
+    const long tiles = (long)((M + c.bm - 1) / c.bm) * (N / c.bn);
+    const long slots = (long)cus * c.per_cu;
+    const double t_round = (double)c.bm * c.bn * c.per_cu * c.rel;   // time for a CU to finish its resident tiles
+    const long full = tiles / slots, rem = tiles % slots;
+    double cost = full * t_round;
+    if (rem) cost += (c.per_cu == 2 && rem <= cus) ? 0.6 * t_round : t_round;  // lone workgroups run faster
+    if (cost < best_cost) { best_cost = cost; best = c.variant; }
   }
-  if (N % 256 == 0 && N >= 1536 && K <= 1024) return 9;
-  return 8;
+  return best;
 }
 
 static const char* kEpiNames[EPI_COUNT] = {"bias", "bias_qgelu", "bias_resid", "scale", "patch"};
