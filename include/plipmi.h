@@ -171,6 +171,9 @@ int plipmi_debug_hidden(plipmi_handle h, int tower, int layer, const void* input
 int plipmi_gemm_nt(int dtype, int epilogue, int variant, int M, int N, int K, const void* A, const void* W,
                    const float* bias, float alpha, void* C, void* stream);
 const char* plipmi_gemm_variant_name(int variant);
+/* force every GEMM of the process onto one tile variant (>= 0), or back to the engine's own choice (-1):
+ * for in-process A/B runs (the environment variable PLIPMI_GEMM_VARIANT sets the same thing at start-up) */
+void plipmi_set_gemm_variant(int variant);
 /* same call with explicit leading dimensions (in elements) for A [M,K] and W [N,K]: rows may be padded */
 int plipmi_gemm_nt_ld(int dtype, int epilogue, int variant, int M, int N, int K, const void* A, int lda, const void* W,
                       int ldw, const float* bias, float alpha, void* C, void* stream);

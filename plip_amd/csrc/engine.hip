@@ -505,6 +505,8 @@ int plipmi_gemm_nt_ld(int dtype, int epilogue, int variant, int M, int N, int K,
   return PLIPMI_OK;
 }
 
+void plipmi_set_gemm_variant(int variant) { gemm_set_default_override(variant); }
+
 const char* plipmi_gemm_variant_name(int variant) {
   if (variant < 0 || variant >= gemm_num_variants()) return nullptr;
   return gemm_variant(variant).name;

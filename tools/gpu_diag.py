@@ -277,6 +277,35 @@ def sec_gemmtrace():
               f"pro {pro[i] / tick_us:6.2f} loop {loop[i] / tick_us:7.2f} epi {epi_t[i] / tick_us:6.2f} end {end[i] / tick_us:7.2f} us")
 
 
+def sec_policy():
+    """In-process interleaved A/B of GEMM tile policies (forced variant vs the cost model), one and two streams."""
+    from plip_amd import _lib
+    from plip_amd.dist import sharded_pair_logits
+    lib = _lib.load()
+    cfg = get_config("ViT-B/32")
+    sd = W.synthetic_state_dict(cfg, 0)
+    B = 256
+    px = torch.from_numpy(W.synthetic_pixels(cfg, B, 1)).to(dev)
+    ids_np, mask_np = W.synthetic_ids(cfg, B, 2)
+    ids, mask = torch.from_numpy(ids_np).to(dev), torch.from_numpy(mask_np).to(dev)
+    model = PlipModel(cfg, sd, dtype="bf16", max_batch=B)
+    pols = [-1, 16, 25, 23, 10, 6]
+    res = {(p, ov): [] for p in pols for ov in (False, True)}
+    for rep in range(4):
+        for pol in pols:
+            lib.plipmi_set_gemm_variant(pol)
+            for ov in (False, True):
+                ms = _time(lambda: sharded_pair_logits(model, px, ids, mask, overlap=ov), iters=10, warm=2)
+                if rep:                      # rep 0 = warm-up of clocks / caches
+                    res[(pol, ov)].append(ms)
+    lib.plipmi_set_gemm_variant(-1)
+    names = gemm_variants()
+    for pol in pols:
+        a, b = res[(pol, False)], res[(pol, True)]
+        print(f"policy {'cost model' if pol < 0 else names[pol]:34s} one stream {np.median(a):6.3f} ms (min {min(a):6.3f})   "
+              f"two streams {np.median(b):6.3f} ms (min {min(b):6.3f})  -> {B / np.median(b) * 1e3:7.0f} pairs/s")
+
+
 def sec_overlap():
     """One-stream vs two-stream step time at bs=256 (bf16)."""
     from plip_amd.dist import sharded_pair_logits
@@ -326,6 +355,6 @@ def sec_e2e():
 
 if __name__ == "__main__":
     t0 = time.time()
-    {"gemm": sec_gemm, "attn": sec_attn, "tiny": sec_tiny, "vitb32": sec_vitb32, "gemmbench": sec_gemmbench, "e2e": sec_e2e, "gemmone": sec_gemmone, "ldpad": sec_ldpad, "gemmtrace": sec_gemmtrace,
+    {"gemm": sec_gemm, "attn": sec_attn, "tiny": sec_tiny, "vitb32": sec_vitb32, "gemmbench": sec_gemmbench, "e2e": sec_e2e, "gemmone": sec_gemmone, "policy": sec_policy, "ldpad": sec_ldpad, "gemmtrace": sec_gemmtrace,
      "overlap": sec_overlap}[sys.argv[1]]()
     print(f"[{sys.argv[1]} done in {time.time() - t0:.1f} s]")
