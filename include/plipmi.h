@@ -174,6 +174,9 @@ const char* plipmi_gemm_variant_name(int variant);
 /* force every GEMM of the process onto one tile variant (>= 0), or back to the engine's own choice (-1):
  * for in-process A/B runs (the environment variable PLIPMI_GEMM_VARIANT sets the same thing at start-up) */
 void plipmi_set_gemm_variant(int variant);
+/* tile policy of the engine's own choice: 0 = wave-quantisation cost model (kernels run one at a time),
+ * 1 = the caller runs the two towers on two streams (idle CUs are filled by the other tower: largest tile wins) */
+void plipmi_set_gemm_policy(int policy);
 /* same call with explicit leading dimensions (in elements) for A [M,K] and W [N,K]: rows may be padded */
 int plipmi_gemm_nt_ld(int dtype, int epilogue, int variant, int M, int N, int K, const void* A, int lda, const void* W,
                       int ldw, const float* bias, float alpha, void* C, void* stream);

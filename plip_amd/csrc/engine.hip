@@ -506,6 +506,7 @@ int plipmi_gemm_nt_ld(int dtype, int epilogue, int variant, int M, int N, int K,
 }
 
 void plipmi_set_gemm_variant(int variant) { gemm_set_default_override(variant); }
+void plipmi_set_gemm_policy(int policy) { gemm_set_policy(policy); }
 
 const char* plipmi_gemm_variant_name(int variant) {
   if (variant < 0 || variant >= gemm_num_variants()) return nullptr;

@@ -521,5 +521,6 @@ const GemmVariant& gemm_variant(int v);
 int gemm_launch(int dtype, int epi, int variant, const GemmParams& p, hipStream_t stream, const char** kernel_name);
 int gemm_default_variant(int dtype, int M, int N, int K);
 void gemm_set_default_override(int variant);  // PLIPMI_GEMM_VARIANT / tests
+void gemm_set_policy(int policy);             // 0: wave-quantisation cost model (one stream), 1: co-scheduled streams
 
 }  // namespace plipmi

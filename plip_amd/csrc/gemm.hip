@@ -42,6 +42,8 @@ const GemmVariant& gemm_variant(int v) { return kVariants[v]; }
 
 static int g_override = -100;  // -100 = not yet read
 void gemm_set_default_override(int variant) { g_override = variant; }
+static int g_policy = 0;
+void gemm_set_policy(int policy) { g_policy = policy; }
 
 int gemm_default_variant(int dtype, int M, int N, int K) {
   if (g_override == -100) {
@@ -60,6 +62,10 @@ int gemm_default_variant(int dtype, int M, int N, int K) {
   // 320x256 for fc1, 192x256 for fc2 / out-proj / patch embedding -- the measured best in all nine shapes.
   (void)K;
   if (M <= 1024) return 1;
+  // Policy 1 = the two towers are co-scheduled on two streams: CUs a partial round would leave idle are taken by
+  // the other tower's kernels, so quantisation stops mattering and the tile with the fewest L2->LDS bytes per FLOP
+  // wins (in-process A/B, profiles/r01_gemm_policy_ab.txt: 5.69 ms/step vs 6.04 ms with the cost model).
+  if (g_policy == 1 && dtype == 1 && N % 256 == 0) return 25;
   const int cus = gemm_num_cus();
   struct Cand { int variant, bm, bn, per_cu; double rel; };
   const Cand cands_bf16[] = {{16, 256, 256, 1, 1.00}, {25, 320, 256, 1, 1.00}, {23, 192, 256, 1, 1.05}, {8, 128, 128, 2, 1.21}};

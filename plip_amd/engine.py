@@ -164,7 +164,15 @@ class Engine:
         the towers are independent (separate workspaces), so the tail of one tower's GEMM grid -- 150..600
         workgroups over 256 CUs -- is filled by the other tower's kernels instead of idling."""
         if not overlap:
+            self.lib.plipmi_set_gemm_policy(0)
             return self.encode_image(pixels, normalize), self.encode_text(input_ids, attention_mask, normalize)
+        self.lib.plipmi_set_gemm_policy(1)      # co-scheduled towers: tile choice by bytes/FLOP, not by wave quantisation
+        try:
+            return self._encode_pair_two_streams(pixels, input_ids, attention_mask, normalize)
+        finally:
+            self.lib.plipmi_set_gemm_policy(0)
+
+    def _encode_pair_two_streams(self, pixels, input_ids, attention_mask, normalize):
         main = torch.cuda.current_stream(self.device)
         if getattr(self, "_side", None) is None:
             self._side = torch.cuda.Stream(device=self.device)

@@ -289,7 +289,7 @@ def sec_policy():
     ids_np, mask_np = W.synthetic_ids(cfg, B, 2)
     ids, mask = torch.from_numpy(ids_np).to(dev), torch.from_numpy(mask_np).to(dev)
     model = PlipModel(cfg, sd, dtype="bf16", max_batch=B)
-    pols = [-1, 16, 25, 23, 10, 6]
+    pols = [-1, 16, 25, 10]
     res = {(p, ov): [] for p in pols for ov in (False, True)}
     for rep in range(4):
         for pol in pols:
