@@ -220,7 +220,12 @@ def main():
                 roofline["traffic"] = tr["bytes_per_launch"]
                 roofline["traffic_note"] = tr["note"]
         if args.overlap and roofline:
-            roofline_1s = roofline_of(profile_pass(False), roofline["kernel"])
+            roofline_1s = roofline_of(profile_pass(False))
+            if roofline_1s:
+                tr = load_pmc_traffic(roofline_1s["kernel"])
+                if tr:
+                    roofline_1s["traffic"] = tr["bytes_per_launch"]
+                    roofline_1s["traffic_note"] = tr["note"]
             if roofline_1s:
                 roofline_1s["mode"] = "one stream: the kernel owns the GPU (kernel quality, not the timed configuration)"
 

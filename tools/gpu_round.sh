@@ -27,11 +27,11 @@ for s in $SECTIONS; do
                PLIPMI_GEMM_ABLATE=$ab timeout 120 python tools/gpu_diag.py gemmtrace 20 12800 2304 768 0 2>&1 | grep -E "main loop" >> gpurun_out/diag_ablate8.log; done ;;
     ablate)  for ab in 0 1 2 3 4 6; do echo "=== PLIPMI_GEMM_ABLATE=$ab (1: no K-loop fills, 2: no MFMA, 4: no epilogue)" >> gpurun_out/diag_ablate.log
                PLIPMI_GEMM_ABLATE=$ab timeout 120 python tools/gpu_diag.py gemmtrace ${ABLATE_ARGS:-6 12800 3072 768 1} 2>&1 | grep -E "variant|prologue|main loop|epilogue|lifetime" >> gpurun_out/diag_ablate.log; done ;;
-    pmcbench) for pass in "FETCH_SIZE" "WRITE_SIZE"; do
-               (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d "$OLDPWD/gpurun_out/pmc_bench_$pass" -o pmc -- python "$OLDPWD/bench.py" --steps 3 --warmup 1 --overlap 0 --no-cpu-baseline --no-profile --no-fp32-tower >> "$OLDPWD/gpurun_out/pmcbench.log" 2>&1)
-             done
-             python tools/pmc_summary.py gpurun_out/pmc_bench_FETCH_SIZE gpurun_out/pmc_bench_WRITE_SIZE > gpurun_out/pmc_traffic.json 2>> gpurun_out/pmcbench.log ;;
-    gemmbench_xn1) PLIPMI_GEMM_XN=1 timeout 600 python tools/gpu_diag.py gemmbench > gpurun_out/diag_gemmbench_xn1.log 2>&1 ;;
+    pmcbench) rm -rf gpurun_out/pmc_bench_*
+             for ov in 0 1; do for pass in "FETCH_SIZE" "WRITE_SIZE"; do
+               (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d "$OLDPWD/gpurun_out/pmc_bench_${pass}_ov$ov" -o pmc -- python "$OLDPWD/bench.py" --steps 3 --warmup 1 --overlap $ov --no-cpu-baseline --no-profile --no-fp32-tower >> "$OLDPWD/gpurun_out/pmcbench.log" 2>&1)
+             done; done
+             python tools/pmc_summary.py gpurun_out/pmc_bench_FETCH_SIZE_ov0 gpurun_out/pmc_bench_WRITE_SIZE_ov0 gpurun_out/pmc_bench_FETCH_SIZE_ov1 gpurun_out/pmc_bench_WRITE_SIZE_ov1 > gpurun_out/pmc_traffic.json 2>> gpurun_out/pmcbench.log ;;
     torchrun1) timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline --no-fp32-tower > gpurun_out/bench_torchrun1.json 2> gpurun_out/bench_torchrun1.err ;;
     smoke)   timeout 600 python __graft_entry__.py --smoke > gpurun_out/smoke.log 2>&1 ;;
     *)       timeout 600 python tools/gpu_diag.py $s > gpurun_out/diag_$s.log 2>&1 ;;

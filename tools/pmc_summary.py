@@ -30,7 +30,9 @@ def pretty(sym, variants):
 VARIANTS = {("128", "128", "0", "0", "0", "2"): "128x128_w2x2_regstage", ("128", "128", "1", "0", "0", "2"): "128x128_w2x2_glds",
             ("256", "256", "1", "0", "0", "2"): "256x256_w4x2_glds", ("256", "256", "1", "1", "0", "2"): "256x256_w4x2_glds_fragpipe",
             ("128", "128", "1", "1", "0", "2"): "128x128_w2x2_glds_fragpipe", ("256", "128", "1", "1", "0", "2"): "256x128_w4x2_glds_fragpipe",
-            ("256", "256", "1", "3", "0", "2"): "256x256_w4x2_glds_spreadfill", ("128", "128", "1", "3", "0", "2"): "128x128_w2x2_glds_spreadfill"}
+            ("256", "256", "1", "3", "0", "2"): "256x256_w4x2_glds_spreadfill", ("128", "128", "1", "3", "0", "2"): "128x128_w2x2_glds_spreadfill",
+            ("192", "256", "1", "3", "0", "2"): "192x256_w2x4_glds_spreadfill", ("192", "256", "1", "1", "0", "2"): "192x256_w2x4_glds_fragpipe",
+            ("320", "256", "1", "3", "0", "2"): "320x256_w2x4_glds_spreadfill", ("320", "256", "1", "0", "0", "2"): "320x256_w2x4_glds"}
 
 
 def main():
@@ -48,7 +50,7 @@ def main():
         out[k] = {"bytes_per_launch": round(fetch + write), "fetch_bytes": round(fetch), "write_bytes": round(write),
                   "launches": len(c["FETCH_SIZE"]),
                   "note": "rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE, separate passes, "
-                          "mean over the launches of `bench.py --overlap 0 --steps 3`"}
+                          "mean over the launches of `bench.py --steps 3` (both stream modes)"}
     json.dump(out, sys.stdout, indent=1, sort_keys=True)
 
 
