@@ -154,9 +154,15 @@ struct EpilogueOp {
 //       against ~2050 cycles of MFMA work; with one tile of lookahead the two do not overlap fully.
 // NSTAGE 3 (LDS-DMA only): three LDS stages, the fill runs TWO K tiles ahead and the end-of-iteration wait is a
 //       counted vmcnt(PA+PW) (in-order retirement: the older tile has landed, the newest may still fly).
+// waves per SIMD the kernel is built for: 2 (LDS caps residency there, so let the allocator use 256 VGPRs), or
+// 1 for the 4-wave 256x256 form whose 128x128 wave tile keeps 256 accumulator registers (unified 512-entry file)
+template <int BM, int BN, int WM, int WN>
+constexpr int gemm_waves_per_simd() { return (WM * WN == 4 && BM * BN >= 256 * 256) ? 1 : 2; }
+
 template <typename T, int BM, int BN, int WM, int WN, int EPI, bool GLDS, int SCHED = 0, int L2PF = 0, int NSTAGE = 2>
-__global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))  // LDS caps residency at 2 waves/SIMD:
-void gemm_nt_kernel(const GemmParams p) {                                            // let the allocator use 256 VGPRs
+__global__ __launch_bounds__(WM* WN * 64)
+__attribute__((amdgpu_waves_per_eu(gemm_waves_per_simd<BM, BN, WM, WN>(), gemm_waves_per_simd<BM, BN, WM, WN>())))
+void gemm_nt_kernel(const GemmParams p) {
   constexpr int NT = WM * WN * 64;
   constexpr int TM = BM / WM, TN = BN / WN;
   constexpr int MI = TM / 32, NI = TN / 32;

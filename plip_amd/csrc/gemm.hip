@@ -23,6 +23,7 @@ static const GemmVariant kVariants[kNumVariants] = {
     {"256x128_w4x2_3stage_xprefetch", 256, 128, 512, true}, {"128x256_w2x4_3stage_xprefetch", 128, 256, 512, true},
     {"192x256_w2x4_glds_spreadfill", 192, 256, 512, true}, {"192x256_w2x4_glds_fragpipe", 192, 256, 512, true},
     {"320x256_w2x4_glds_spreadfill", 320, 256, 512, true}, {"320x256_w2x4_glds", 320, 256, 512, true},
+    {"256x256_w2x2_1wave_fragpipe", 256, 256, 256, true}, {"256x256_w2x2_1wave_spreadfill", 256, 256, 256, true},
 };
 
 int gemm_num_cus() {

@@ -70,7 +70,7 @@ int launch_naive(const GemmParams& p, hipStream_t stream) {
   return (int)hipGetLastError();
 }
 
-constexpr int kNumVariants = 27;
+constexpr int kNumVariants = 29;
 
 // table[variant][epilogue]
 template <typename T>
@@ -105,6 +105,8 @@ struct GemmTable {
       case 24: return launch_tiled<T, 192, 256, 2, 4, EPI, true, 1>;
       case 25: return launch_tiled<T, 320, 256, 2, 4, EPI, true, 3>;
       case 26: return launch_tiled<T, 320, 256, 2, 4, EPI, true, 0>;
+      case 27: return launch_tiled<T, 256, 256, 2, 2, EPI, true, 1>;
+      case 28: return launch_tiled<T, 256, 256, 2, 2, EPI, true, 3>;
       case -2: return launch_naive<T, EPI>;
       default: return nullptr;
     }
