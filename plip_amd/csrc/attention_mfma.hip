@@ -27,6 +27,12 @@ __global__ __launch_bounds__(64 * KT) void attention_mfma_kernel(const bf16_t* _
                                                                  const int64_t* __restrict__ key_mask) {
   constexpr int SP = 32 * KT;   // padded sequence
   constexpr int VLD = SP + 4;   // Vt row stride (bf16): (SP/2 + 2) dwords, odd multiple of 2 -> all 64 banks
+  // Q and K rows are staged through LDS in whole 128-byte lines (8 lanes x 16 B per row) instead of being loaded
+  // fragment-shaped (16 B from each of 32 rows per instruction, which costs the texture-address unit 2x the
+  // time for the same bytes); the LDS image uses the GEMM's XOR swizzle so the fragment ds_read_b128 are
+  // conflict-free.  V is transposed on the way in.
+  __shared__ __attribute__((aligned(16))) char Qs[SP * 128];
+  __shared__ __attribute__((aligned(16))) char Ks[SP * 128];
   __shared__ __attribute__((aligned(16))) bf16_t Vt[64 * VLD];
   __shared__ unsigned long long mk[4];
 
@@ -43,14 +49,18 @@ __global__ __launch_bounds__(64 * KT) void attention_mfma_kernel(const bf16_t* _
     if (lane == 0) mk[wave] = bits;
     if (KT < 4 && tid < 4 - KT) mk[KT + tid] = 0ull;
   }
-  // V^T into LDS: thread -> (key, 4 consecutive d)
-  for (int e = tid; e < SP * 16; e += 64 * KT) {
-    const int key = e >> 4, dc = (e & 15) * 4;
-    const int kg = key < S ? key : S - 1;
-    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-    const bf16x4 v = *reinterpret_cast<const bf16x4*>(base + (size_t)kg * ld + 2 * D + dc);
+  for (int e = tid; e < SP * 8; e += 64 * KT) {
+    const int row = e >> 3, c = e & 7;
+    const int rg = row < S ? row : S - 1;
+    const bf16_t* src = base + (size_t)rg * ld + c * 8;
+    const u32x4 q16 = *reinterpret_cast<const u32x4*>(src);
+    const u32x4 k16 = *reinterpret_cast<const u32x4*>(src + D);
+    const bf16x8 v8 = *reinterpret_cast<const bf16x8*>(src + 2 * D);
+    const int off = row * 128 + ((c ^ ((row >> 1) & 7)) << 4);
+    *reinterpret_cast<u32x4*>(Qs + off) = q16;
+    *reinterpret_cast<u32x4*>(Ks + off) = k16;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) Vt[(dc + i) * VLD + key] = v[i];
+    for (int i = 0; i < 8; ++i) Vt[(c * 8 + i) * VLD + row] = v8[i];
   }
   __syncthreads();
 
@@ -58,14 +68,13 @@ __global__ __launch_bounds__(64 * KT) void attention_mfma_kernel(const bf16_t* _
   if (q0 >= S) return;
   const int lrow = lane & 31, hi = lane >> 5;
   const int qidx = q0 + lrow;
+  const int lsw = (lrow >> 1) & 7;
 
   // Q fragments (B operand): Q[query = lrow][d = 16ks + 8hi .. +7]
   u32x4 qf[4];
-  {
-    const bf16_t* qr = base + (size_t)(qidx < S ? qidx : S - 1) * ld + 8 * hi;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const u32x4*>(qr + 16 * ks);
-  }
+  for (int ks = 0; ks < 4; ++ks)
+    qf[ks] = *reinterpret_cast<const u32x4*>(Qs + (q0 + lrow) * 128 + (((ks * 2 + hi) ^ lsw) << 4));
 
   // scores^T tiles
   f32x16 sc[KT];
@@ -77,11 +86,9 @@ __global__ __launch_bounds__(64 * KT) void attention_mfma_kernel(const bf16_t* _
 #pragma unroll
     for (int r = 0; r < 16; ++r) sc[t][r] = 0.f;
     if (live) {
-      const int krow = 32 * t + lrow;
-      const bf16_t* kr = base + (size_t)(krow < S ? krow : S - 1) * ld + D + 8 * hi;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        const u32x4 kf = *reinterpret_cast<const u32x4*>(kr + 16 * ks);
+        const u32x4 kf = *reinterpret_cast<const u32x4*>(Ks + (32 * t + lrow) * 128 + (((ks * 2 + hi) ^ lsw) << 4));
         sc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf), __builtin_bit_cast(bf16x8, qf[ks]),
                                                         sc[t], 0, 0, 0);
       }
@@ -131,15 +138,30 @@ __global__ __launch_bounds__(64 * KT) void attention_mfma_kernel(const bf16_t* _
       }
     }
   }
-  if (qidx < S) {
+  // The accumulator layout gives a lane one query ROW (like the GEMM): write the normalised 32 x 64 bf16 tile
+  // into this wave's own (already consumed) Q rows of the LDS image, then store whole 128-byte rows.
+  {
     const float inv = 1.0f / rsum;
-    bf16_t* orow = out + ((size_t)b * S + qidx) * D + h * 64;
+    char* orow_lds = Qs + (q0 + lrow) * 128;
+    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-      for (int q4 = 0; q4 < 4; ++q4)
-        store4(orow + dt * 32 + 8 * q4 + 4 * hi, acc[dt][4 * q4 + 0] * inv, acc[dt][4 * q4 + 1] * inv,
-               acc[dt][4 * q4 + 2] * inv, acc[dt][4 * q4 + 3] * inv);
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const int d = dt * 32 + 8 * q4 + 4 * hi;                 // 4 consecutive head-dim columns
+        const int c = d >> 3;                                    // 16-byte chunk, half (d&4) inside it
+        const bf16x4 v = {(bf16_t)(acc[dt][4 * q4 + 0] * inv), (bf16_t)(acc[dt][4 * q4 + 1] * inv),
+                          (bf16_t)(acc[dt][4 * q4 + 2] * inv), (bf16_t)(acc[dt][4 * q4 + 3] * inv)};
+        *reinterpret_cast<bf16x4*>(orow_lds + ((c ^ lsw) << 4) + (d & 4) * 2) = v;
+      }
+    __builtin_amdgcn_wave_barrier();
+    const int c = lane & 7;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int r = q0 + it * 8 + (lane >> 3);
+      const u32x4 v = *reinterpret_cast<const u32x4*>(Qs + r * 128 + ((c ^ ((r >> 1) & 7)) << 4));
+      if (r < S) *reinterpret_cast<u32x4*>(out + ((size_t)b * S + r) * D + h * 64 + c * 8) = v;
+    }
   }
 }
 
