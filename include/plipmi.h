@@ -18,6 +18,7 @@
  *   plipmi_logits         <- CLIPModel.forward -> logits_per_image/_text      README.md:45-50 (HF modeling_clip.py:810-817)
  *                            image_embeddings.dot(text_embeddings.T); argmax  reproducibility/evaluation/zero_shot/zero_shot.py:12-13
  *   plipmi_topk           <- cosine_sim.argsort()[:, -k:][:, ::-1]            plip.py:78-87, evaluation/retrieval/retrieval.py:13-18
+ *   plipmi_similarity_topk<- the same two call sites, fused with the dot product (no [N,N] matrix)
  *
  * Conventions
  *   - plain C, no torch / HIP types in the signatures: device buffers are raw
@@ -153,6 +154,16 @@ int plipmi_logits(plipmi_handle h, const float* img, int Ni, const float* txt, i
 /* top-k columns of each row of scores [N,M], descending (ties: lower index first);
  * idx int64 [N,k].  Replaces argsort()[:, -k:][:, ::-1] (plip.py:84). */
 int plipmi_topk(plipmi_handle h, const float* scores, int N, int M, int k, int64_t* idx, void* stream);
+
+/* Fused similarity + top-k: for every row q of keys [Nq,D] the k rows j of space [Ns,D] with the largest <q, space_j>,
+ * descending (ties: lower j first), WITHOUT materialising the [Nq,Ns] score matrix: scores are produced in
+ * [<=4096, <=8192] fp32 panels (MFMA fp32 GEMM) and folded into per-row running lists.  idx int64 [Nq,k] (required),
+ * vals fp32 [Nq,k] (optional, may be NULL).  1 <= k <= min(Ns, 1024), D % 32 == 0.  Scratch (<= ~150 MiB) is
+ * allocated inside the handle on first use.  Replaces the per-query `t.dot(image_embeddings.T).argsort()[-50:][::-1]`
+ * loop of reproducibility/evaluation/retrieval/retrieval.py:13-18 and cosine_sim.argsort()[:, -k:][:, ::-1] of
+ * plip.py:78-87 for corpora whose [N,N] matrix would not fit. */
+int plipmi_similarity_topk(plipmi_handle h, const float* keys, int Nq, const float* space, int Ns, int D, int k,
+                           int64_t* idx, float* vals, void* stream);
 
 /* ---- test / measurement hooks ---------------------------------------------- */
 /* Parity tests only: run `tower` on `input` (pixels or ids; mask = NULL) through its

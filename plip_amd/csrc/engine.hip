@@ -14,6 +14,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -80,6 +81,9 @@ struct plipmi_engine {
   size_t slab_bytes = 0;
   int attn_impl = 0, attn_impl_vis = 0, attn_impl_txt = 0;
   char devname[128] = "";
+  // plipmi_similarity_topk scratch (allocated on first use, grown on demand)
+  char* sim_ws = nullptr;
+  size_t sim_ws_bytes = 0;
   // profiling
   bool prof = false;
   std::vector<ProfRec> recs;
@@ -384,6 +388,7 @@ void plipmi_destroy(plipmi_handle h) {
   for (ProfRec& r : h->recs) { hipEventDestroy(r.t0); hipEventDestroy(r.t1); }
   for (hipEvent_t ev : h->pool) hipEventDestroy(ev);
   if (h->slab) hipFree(h->slab);
+  if (h->sim_ws) hipFree(h->sim_ws);
   delete h;
 }
 
@@ -455,6 +460,61 @@ int plipmi_topk(plipmi_handle h, const float* scores, int N, int M, int k, int64
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   Scope sc(h, s, "topk", 0, (double)N * M * 4 * k);
   HIP_TRY(launch_topk(scores, N, M, k, idx, s));
+  return PLIPMI_OK;
+}
+
+int plipmi_similarity_topk(plipmi_handle h, const float* keys, int Nq, const float* space, int Ns, int D, int k,
+                           int64_t* idx, float* vals, void* stream) {
+  if (!h || Nq < 0 || Ns <= 0 || D <= 0) return fail(PLIPMI_ERR_INVALID, "bad argument");
+  if (Nq > 0 && (!keys || !space || !idx)) return fail(PLIPMI_ERR_INVALID, "null keys/space/idx");
+  if (k <= 0 || k > Ns || k > kTopkMaxK)
+    return fail(PLIPMI_ERR_INVALID, "need 0 < k <= min(Ns, %d), got k=%d Ns=%d", kTopkMaxK, k, Ns);
+  if (D % 32) return fail(PLIPMI_ERR_INVALID, "embedding width %d must be a multiple of 32", D);
+  if (Nq == 0) return PLIPMI_OK;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  // panel geometry: [QB queries] x [PB space vectors] of fp32 scores at a time (<= 128 MiB), never [Nq, Ns]
+  const int PB = (int)std::min<size_t>(8192, align_up((size_t)Ns, 256));
+  const int QB = std::min(Nq, 4096);
+  const int tail = Ns % PB;  // the last panel is staged zero-padded so the GEMM's N stays a whole number of tiles
+  const size_t sc_bytes = align_up((size_t)QB * PB * 4, 256);
+  const size_t tl_bytes = tail ? align_up((size_t)align_up((size_t)tail, 256) * D * 4, 256) : 0;
+  const size_t vl_bytes = vals ? 0 : align_up((size_t)QB * k * 4, 256);
+  const size_t need = sc_bytes + tl_bytes + vl_bytes;
+  if (need > h->sim_ws_bytes) {
+    if (h->sim_ws) { HIP_TRY(hipStreamSynchronize(s)); HIP_TRY(hipFree(h->sim_ws)); h->sim_ws = nullptr; h->sim_ws_bytes = 0; }
+    hipError_t me = hipMalloc(reinterpret_cast<void**>(&h->sim_ws), need);
+    if (me != hipSuccess) { h->sim_ws = nullptr; return fail(PLIPMI_ERR_NOMEM, "hipMalloc(%zu bytes) failed: %s", need, hipGetErrorString(me)); }
+    h->sim_ws_bytes = need;
+  }
+  float* scores = reinterpret_cast<float*>(h->sim_ws);
+  float* tail_w = reinterpret_cast<float*>(h->sim_ws + sc_bytes);
+  float* own_vals = reinterpret_cast<float*>(h->sim_ws + sc_bytes + tl_bytes);
+  const int tail_n = (int)align_up((size_t)tail, 256);
+  if (tail) {
+    HIP_TRY(hipMemsetAsync(tail_w, 0, (size_t)tail_n * D * 4, s));
+    HIP_TRY(hipMemcpyAsync(tail_w, space + (size_t)(Ns - tail) * D, (size_t)tail * D * 4, hipMemcpyDeviceToDevice, s));
+  }
+  for (int q0 = 0; q0 < Nq; q0 += QB) {
+    const int rows = std::min(QB, Nq - q0);
+    float* v = vals ? vals + (size_t)q0 * k : own_vals;
+    int64_t* ix = idx + (size_t)q0 * k;
+    HIP_TRY(launch_topk_init(v, ix, (size_t)rows * k, s));
+    for (int p0 = 0; p0 < Ns; p0 += PB) {
+      const int cols = std::min(PB, Ns - p0);
+      const bool is_tail = cols < PB;
+      GemmParams p;
+      p.A = keys + (size_t)q0 * D; p.W = is_tail ? tail_w : space + (size_t)p0 * D; p.C = scores; p.bias = nullptr;
+      p.M = rows; p.N = is_tail ? tail_n : PB; p.K = D; p.lda = D; p.ldw = D; p.ldc = PB; p.alpha = 1.f; p.np = 1;
+      const char* name = "gemm_nt";
+      { Scope sc(h, s, name, 2.0 * rows * (double)p.N * D, ((double)rows * D + (double)p.N * D + (double)rows * p.N) * 4);
+        const int rc = gemm_launch(PLIPMI_F32, EPI_SCALE, p.N % 256 == 0 && rows > 128 ? -1 : 1, p, s, &name);
+        sc.rename(name);
+        if (rc != 0) return fail(PLIPMI_ERR_HIP, "similarity gemm failed: %s", hipGetErrorString((hipError_t)rc)); }
+      { Scope sc(h, s, "topk_merge", 0, (double)rows * cols * 4);
+        HIP_TRY(launch_topk_merge(scores, (size_t)PB, rows, cols, (int64_t)p0, k, v, ix, s)); }
+    }
+    HIP_TRY(launch_topk_finish(ix, (size_t)rows * k, s));
+  }
   return PLIPMI_OK;
 }
 

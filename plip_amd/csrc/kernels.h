@@ -46,6 +46,14 @@ hipError_t launch_logits(const float* img, int Ni, const float* txt, int Nt, int
 
 hipError_t launch_topk(const float* scores, int N, int M, int k, int64_t* idx, hipStream_t s);
 
+// streaming top-k: fold the panel scores[rows, 0:ncols] (row stride ld, global column offset col0) into the running
+// per-row lists vals/idx [rows, k] (descending; ties: lower index first); init before the first panel, finish after the last
+constexpr int kTopkMaxK = 1024;
+hipError_t launch_topk_init(float* vals, int64_t* idx, size_t n, hipStream_t s);
+hipError_t launch_topk_merge(const float* scores, size_t ld, int rows, int ncols, int64_t col0, int k, float* vals,
+                             int64_t* idx, hipStream_t s);
+hipError_t launch_topk_finish(int64_t* idx, size_t n, hipStream_t s);
+
 // dst[r, 0:cols] = (T)(scale * src[r, 0:cols]), dst[r, cols:dst_ld] = 0   (weight packing)
 hipError_t launch_convert(const float* src, void* dst, int dst_dtype, int rows, int cols, int dst_ld, float scale,
                           hipStream_t s);

@@ -509,6 +509,115 @@ hipError_t launch_topk(const float* scores, int N, int M, int k, int64_t* idx, h
 }
 
 // ---------------------------------------------------------------------------------
+// Streaming top-k (fused similarity + top-k head, plipmi_similarity_topk).
+// The score matrix is produced panel by panel ([rows, <=8192] fp32, never the full [Nq, Ns]); this kernel folds
+// one panel into each row's running top-k list.  One wavefront per query row; the list (k <= 1024 entries,
+// descending, ties: lower global index first) lives in LDS.  A column only costs an LDS insertion if it beats
+// the row's current k-th best, which after the first panel is rare (k ln(N/k) insertions per row in total), so
+// the scan runs at streaming rate: 16 B per lane per step, one ballot per component.
+// Order: (v, i) is better than (w, j) iff v > w or (v == w and i < j); NaN scores count as -inf.
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ bool topk_better(float v, long long i, float w, long long j) {
+  return v > w || (v == w && i < j);
+}
+
+__global__ __launch_bounds__(256) void topk_merge_kernel(const float* __restrict__ scores, size_t ld, int rows,
+                                                         int ncols, long long col0, int k, float* __restrict__ vals,
+                                                         long long* __restrict__ idx) {
+  extern __shared__ __attribute__((aligned(16))) char topk_smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + wave;
+  if (row >= rows) return;  // whole wave; no workgroup barrier below
+  long long* si = reinterpret_cast<long long*>(topk_smem) + (size_t)wave * k;
+  float* sv = reinterpret_cast<float*>(topk_smem + (size_t)4 * k * sizeof(long long)) + (size_t)wave * k;
+  float* gv = vals + (size_t)row * k;
+  long long* gi = idx + (size_t)row * k;
+  for (int e = lane; e < k; e += 64) { sv[e] = gv[e]; si[e] = gi[e]; }
+  float tv = sv[k - 1];
+  long long ti = si[k - 1];
+  const float* sr = scores + (size_t)row * ld;
+  for (int j0 = 0; j0 < ncols; j0 += 256) {
+    const int j = j0 + lane * 4;
+    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (j + 3 < ncols) q = *reinterpret_cast<const float4*>(sr + j);
+    else {
+      if (j < ncols) q.x = sr[j];
+      if (j + 1 < ncols) q.y = sr[j + 1];
+      if (j + 2 < ncols) q.z = sr[j + 2];
+    }
+    const float comp[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float v = comp[c];
+      if (!(v == v)) v = -INFINITY;
+      const long long g = col0 + j + c;
+      unsigned long long mask = __ballot(j + c < ncols && topk_better(v, g, tv, ti));
+      while (mask) {
+        const int l = __builtin_ctzll(mask);
+        mask &= mask - 1;
+        const float vv = __shfl(v, l, 64);
+        const long long ii = __shfl(g, l, 64);
+        if (!topk_better(vv, ii, tv, ti)) continue;  // the k-th best moved since the ballot (wave-uniform)
+        int pos = 0;
+        for (int e0 = 0; e0 < k; e0 += 64) {
+          const int e = e0 + lane;
+          pos += __popcll(__ballot(e < k && topk_better(sv[e], si[e], vv, ii)));
+        }
+        // entries [pos, k-2] move down one slot, highest chunk first; inside a chunk every lane reads before any writes
+        for (int e0 = ((k - 1) >> 6) << 6; e0 >= 0; e0 -= 64) {
+          const int e = e0 + lane;
+          const bool mv = e > pos && e < k;
+          const float mvv = mv ? sv[e - 1] : 0.f;
+          const long long mvi = mv ? si[e - 1] : 0;
+          __builtin_amdgcn_wave_barrier();
+          if (mv) { sv[e] = mvv; si[e] = mvi; }
+          __builtin_amdgcn_wave_barrier();
+        }
+        if (lane == 0) { sv[pos] = vv; si[pos] = ii; }
+        __builtin_amdgcn_wave_barrier();
+        tv = sv[k - 1];
+        ti = si[k - 1];
+      }
+    }
+  }
+  for (int e = lane; e < k; e += 64) { gv[e] = sv[e]; gi[e] = si[e]; }
+}
+
+__global__ void topk_init_kernel(float* __restrict__ vals, long long* __restrict__ idx, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    vals[i] = -INFINITY;
+    idx[i] = LLONG_MAX;  // an empty slot loses every tie
+  }
+}
+// empty slots (fewer than k finite candidates cannot happen for k <= Ns, but keep the contract of launch_topk) -> -1
+__global__ void topk_finish_kernel(long long* __restrict__ idx, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    if (idx[i] == LLONG_MAX) idx[i] = -1;
+}
+
+hipError_t launch_topk_init(float* vals, int64_t* idx, size_t n, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+  hipLaunchKernelGGL(topk_init_kernel, dim3(grid), dim3(256), 0, s, vals, reinterpret_cast<long long*>(idx), n);
+  return hipGetLastError();
+}
+hipError_t launch_topk_finish(int64_t* idx, size_t n, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+  hipLaunchKernelGGL(topk_finish_kernel, dim3(grid), dim3(256), 0, s, reinterpret_cast<long long*>(idx), n);
+  return hipGetLastError();
+}
+hipError_t launch_topk_merge(const float* scores, size_t ld, int rows, int ncols, int64_t col0, int k, float* vals,
+                             int64_t* idx, hipStream_t s) {
+  if (rows <= 0 || ncols <= 0) return hipSuccess;
+  if (k <= 0 || k > kTopkMaxK || (ld & 3)) return hipErrorInvalidValue;
+  const size_t smem = (size_t)4 * k * (sizeof(long long) + sizeof(float));
+  hipLaunchKernelGGL(topk_merge_kernel, dim3((rows + 3) / 4), dim3(256), smem, s, scores, ld, rows, ncols,
+                     (long long)col0, k, vals, reinterpret_cast<long long*>(idx));
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------
 // weight packing (plipmi_create)
 // ---------------------------------------------------------------------------------
 template <typename T>

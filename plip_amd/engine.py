@@ -216,6 +216,21 @@ class Engine:
                                             self._stream()), "plipmi_topk")
         return idx
 
+    def similarity_topk(self, keys: torch.Tensor, space: torch.Tensor, k: int, return_values: bool = False):
+        """Top-k rows of ``space`` by dot product for every row of ``keys`` -- ``(keys @ space.T).argsort()[:, -k:][:, ::-1]``
+        (plip.py:83-84, retrieval.py:13-16) without the [Nq, Ns] matrix: scores exist only as [<=4096, <=8192] panels."""
+        with torch.cuda.device(self.device):
+            q = keys.to(device=self.device, dtype=torch.float32).contiguous()
+            sp = space.to(device=self.device, dtype=torch.float32).contiguous()
+            if q.dim() != 2 or sp.dim() != 2 or q.shape[1] != sp.shape[1]:
+                raise ValueError("keys [Nq,D] and space [Ns,D] must share D")
+            idx = torch.empty((q.shape[0], int(k)), dtype=torch.int64, device=self.device)
+            vals = torch.empty((q.shape[0], int(k)), dtype=torch.float32, device=self.device) if return_values else None
+            _lib.check(self.lib.plipmi_similarity_topk(self._h, _ptr(q), q.shape[0], _ptr(sp), sp.shape[0], q.shape[1],
+                                                       int(k), _ptr(idx), _ptr(vals) if vals is not None else None,
+                                                       self._stream()), "plipmi_similarity_topk")
+        return (idx, vals) if return_values else idx
+
     def hidden(self, tower: str, layer: int, inp: torch.Tensor) -> torch.Tensor:
         """HF ``hidden_states[layer]`` of a tower (parity tests)."""
         cfg = self.cfg
@@ -309,3 +324,19 @@ def gemm_variants():
             return names
         names.append(n.decode())
         i += 1
+
+
+_HEADS = {}
+
+
+def heads_engine(device="cuda:0") -> Engine:
+    """A handle for callers that only need the evaluation heads (l2_normalize / logits / topk / similarity_topk on
+    embeddings they already hold -- reproducibility.evaluation): those entry points use no tower weights, so a
+    minimal synthetic configuration is enough to own the scratch memory and the stream plumbing."""
+    key = str(torch.device(device))
+    if key not in _HEADS:
+        from . import weights as W
+        from .config import get_config
+        cfg = get_config("tiny")
+        _HEADS[key] = Engine(cfg, W.synthetic_state_dict(cfg, 0), device=device, dtype="f32", max_batch=1)
+    return _HEADS[key]

@@ -112,10 +112,17 @@ class PLIP:
 
     # -- plip.py:78-87 -----------------------------------------------------------
     def _nearest_neighbours(self, k, key_vectors, space_vectors, normalize=True, debug=False):
-        key_vectors, space_vectors = np.asarray(key_vectors), np.asarray(space_vectors)
         eng = self.model.engine
-        sim = torch.as_tensor(self._cosine_similarity(key_vectors, space_vectors, normalize=normalize))
-        return eng.topk(sim, k).cpu().numpy()
+        kv = torch.as_tensor(np.ascontiguousarray(key_vectors, dtype=np.float32)).to(eng.device)
+        sv = torch.as_tensor(np.ascontiguousarray(space_vectors, dtype=np.float32)).to(eng.device)
+        if normalize:
+            kv = eng.l2_normalize_(kv.clone())          # only the key side, as the reference does (plip.py:74-76)
+        if debug:
+            print(self._cosine_similarity(key_vectors, space_vectors, normalize=normalize))
+        if kv.shape[1] % 32 == 0 and k <= 1024:
+            return eng.similarity_topk(kv, sv, k).cpu().numpy()     # fused: no [Nq, Ns] matrix
+        lpi, _, _ = eng.logits(kv, sv, scale=1.0, want_text=False)
+        return eng.topk(lpi, k).cpu().numpy()
 
     # -- plip.py:89-103 ----------------------------------------------------------
     def zero_shot_classification(self, images, text_labels: List[str], debug=False):

@@ -105,6 +105,122 @@ def test_logits_heads_and_topk(engines):
     assert (y - x / x.norm(dim=-1, keepdim=True)).abs().max().item() < 1e-6
 
 
+def _check_topk(idx, vals, q, sp, k):
+    """idx/vals must be a valid descending top-k of q @ sp.T: exact-score comparison with an fp32-ulp allowance
+    (the GPU sums the 512 products in MFMA order, numpy in BLAS order, so near-ties may legally swap)."""
+    ref = q.astype(np.float64) @ sp.astype(np.float64).T
+    got = np.take_along_axis(ref, idx, axis=1)
+    want = -np.sort(-ref, axis=1)[:, :k]
+    tol = 1e-5 * max(1.0, float(np.abs(ref).max()))
+    assert np.abs(got - want).max() < tol                                   # same score profile as the true top-k
+    assert (np.diff(got, axis=1) <= tol).all()                              # descending
+    assert all(len(set(r)) == k for r in idx.tolist())                      # no duplicates
+    assert idx.min() >= 0 and idx.max() < sp.shape[0]
+    if vals is not None:
+        assert np.abs(vals - got).max() < tol
+
+
+@pytest.mark.parametrize("nq,ns,d,k", [(7, 10, 64, 3), (130, 300, 64, 50), (33, 8192 + 777, 64, 50),
+                                        (4100, 20000, 512, 10), (5, 9000, 512, 1024)])
+def test_similarity_topk_streaming(engines, nq, ns, d, k):
+    """Fused similarity + top-k (retrieval.py:13-18, plip.py:78-87) without the [Nq,Ns] matrix: several panels,
+    ragged tail panel, more queries than one query block, k up to the list capacity."""
+    model, *_ = engines("tiny_b6", "f32")
+    eng = model.engine
+    rng = np.random.RandomState(nq + ns)
+    q = rng.randn(nq, d).astype(np.float32)
+    sp = rng.randn(ns, d).astype(np.float32)
+    idx, vals = eng.similarity_topk(torch.from_numpy(q), torch.from_numpy(sp), k, return_values=True)
+    _check_topk(idx.cpu().numpy(), vals.cpu().numpy(), q, sp, k)
+    idx2 = eng.similarity_topk(torch.from_numpy(q), torch.from_numpy(sp), k)
+    assert torch.equal(idx, idx2)                                           # deterministic, vals optional
+
+
+def test_similarity_topk_ties_and_errors(engines):
+    model, *_ = engines("tiny_b6", "f32")
+    eng = model.engine
+    sp = np.zeros((600, 64), np.float32)
+    sp[:, 0] = 1.0                                                          # every score identical -> index order
+    sp[500, 0] = 2.0
+    q = np.zeros((3, 64), np.float32)
+    q[:, 0] = 1.0
+    idx = eng.similarity_topk(torch.from_numpy(q), torch.from_numpy(sp), 5).cpu().numpy()
+    np.testing.assert_array_equal(idx, np.tile(np.array([500, 0, 1, 2, 3]), (3, 1)))
+    sp[7] = np.nan                                                          # NaN scores sort last
+    idx = eng.similarity_topk(torch.from_numpy(q), torch.from_numpy(sp), 600).cpu().numpy()
+    assert idx[0, -1] == 7 and idx[0, 0] == 500
+    from plip_amd._lib import PlipmiError
+    with pytest.raises(PlipmiError):
+        eng.similarity_topk(torch.from_numpy(q), torch.from_numpy(sp), 601)    # k > Ns
+    with pytest.raises(PlipmiError):
+        eng.similarity_topk(torch.zeros(2, 48), torch.zeros(9, 48), 2)         # D % 32
+    assert eng.similarity_topk(torch.zeros(0, 64), torch.from_numpy(sp), 4).shape == (0, 4)
+
+
+def test_clip_embedder_cache_and_eval_heads(engines, tmp_path, monkeypatch):
+    """reproducibility/embedders/plip.py + evaluation heads on the engine: normalised rows, both cache schemes,
+    zero-shot arg-max and retrieval top-50 equal to the reference's numpy formulation on the oracle's embeddings."""
+    import argparse
+    from oracle import clip_oracle as O
+    from plip_amd import weights as W
+    from plip_amd.reproducibility import CLIPEmbedder, EmbedderFactory, ImageRetrieval, ZeroShotClassifier
+    model, cfg, sd, px, ids, mask = engines("tiny_b5_zero_pad_ln100", "f32")
+    monkeypatch.setenv("PC_CACHE_FOLDER", str(tmp_path))
+    emb = CLIPEmbedder(model, None, "plip", "/ckpts/tiny.pt")
+    img = emb.image_embedder(px, batch_size=2, additional_cache_name="unit_test.csv")     # NCHW float array input
+    txt = emb.text_embedder(ids, batch_size=3)                                             # token ids (0-padded)
+    want_img = O.l2_normalize(O.vision_tower(px, sd, cfg))
+    want_txt = O.l2_normalize(O.text_tower(ids, sd, cfg))
+    assert img.dtype == np.float32 and np.abs(img - want_img).max() < 1e-5 and np.abs(txt - want_txt).max() < 1e-5
+    assert (tmp_path / "unit_test" / "plip" / "tiny.pt").exists()
+    emb.model = None                                                                        # second call must be a cache hit
+    np.testing.assert_array_equal(emb.image_embedder(px, additional_cache_name="unit_test.csv"), img)
+    np.testing.assert_array_equal(emb.text_embedder(ids), txt)
+    with pytest.raises(RuntimeError):
+        CLIPEmbedder(model).embed_text(["a caption"])                                       # strings need a tokenizer
+    # PIL / uint8 HWC items go through the preprocess contract (transform.py:45-52)
+    u8 = np.random.RandomState(0).randint(0, 256, (3, cfg.image_size, cfg.image_size, 3), dtype=np.uint8)
+    from plip_amd.preprocess import preprocess_images
+    got = CLIPEmbedder(model).embed_images(list(u8), batch_size=2)
+    assert np.abs(got - O.l2_normalize(O.vision_tower(preprocess_images(list(u8), cfg.image_size), sd, cfg))).max() < 1e-5
+
+    # factory: OpenAI-format .pt on disk, arch from $PC_CLIP_ARCH (factory.py:21-25)
+    ck = tmp_path / "tiny_openai.pt"
+    torch.save({k: torch.from_numpy(np.asarray(v)) for k, v in W.to_openai_state_dict(sd, cfg).items()}, ck)
+    monkeypatch.setenv("PC_CLIP_ARCH", "tiny")
+    e2 = EmbedderFactory().factory(argparse.Namespace(model_name="plip", backbone=str(ck), dtype="fp32", max_batch=8))
+    assert np.abs(e2.embed_images(px) - want_img).max() < 1e-5 and e2.backbone == str(ck)
+    e2.model.engine.close()
+    with pytest.raises(FileNotFoundError):
+        EmbedderFactory().factory(argparse.Namespace(model_name="clip", backbone=str(tmp_path / "missing.pt")))
+    with pytest.raises(NotImplementedError):
+        EmbedderFactory().factory(argparse.Namespace(model_name="mudipath", backbone=None))
+
+    # evaluation heads
+    rng = np.random.RandomState(5)
+    I = rng.randn(300, 512).astype(np.float32); I /= np.linalg.norm(I, axis=1, keepdims=True)
+    T = I + 0.4 * rng.randn(300, 512).astype(np.float32); T /= np.linalg.norm(T, axis=1, keepdims=True)
+    labels = ["adipose", "lymphocytes", "mucus", "tumor"]
+    C = T[:4]
+    zs = ZeroShotClassifier()
+    pred = zs.predict(I, C, labels)
+    assert pred == [labels[int(np.argmax(r))] for r in I.dot(C.T)]                         # zero_shot.py:12-13
+    target = [labels[i % 4] for i in range(300)]
+    tr, te = zs.zero_shot_classification(I, C, labels, target, pickle_path=str(tmp_path / "pickle.pkl"))
+    assert tr["split"] == "train" and te["split"] == "test" and te["instances"] == 300
+    assert abs(te["Accuracy"] - np.mean([a == b for a, b in zip(pred, target)])) < 1e-12
+    import pickle
+    assert pickle.load(open(tmp_path / "pickle.pkl", "rb"))["predictions"] == pred
+    ir = ImageRetrieval()
+    best = ir.best_scores(I, T)
+    ref_best = np.stack([t.dot(I.T).argsort()[-50:][::-1] for t in T])                    # retrieval.py:13-16
+    _check_topk(best, None, T, I, 50)
+    assert (best[:, 0] == ref_best[:, 0]).mean() > 0.99
+    tr, te = ir.retrieval(I, T)
+    p10 = np.mean([i in ref_best[i, :10] for i in range(300)]); p50 = np.mean([i in ref_best[i] for i in range(300)])
+    assert abs(te["p@10"] - p10) < 1e-9 and abs(te["p@50"] - p50) < 1e-9 and tr["split"] == "train"
+
+
 def test_error_behaviour(engines):
     model, cfg, sd, px, ids, mask = engines("tiny_b6", "f32")
     with pytest.raises(ValueError):                                         # HF raises ValueError on a wrong image size

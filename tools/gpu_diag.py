@@ -179,6 +179,29 @@ def sec_gemmbench():
             print(f"{name:8s} {M:6d}x{N:5d}x{K:5d} epi{epi}: " + " ".join(row))
 
 
+def sec_libgemm():
+    """Calibration only (never used by the product): what the vendor GEMM library (hipBLASLt/rocBLAS behind
+    torch.nn.functional.linear) reaches on the production shapes -- an external yardstick for gemm_nt."""
+    import torch.nn.functional as F
+    shapes = [("v.qkv", 12800, 2304, 768), ("v.out", 12800, 768, 768), ("v.fc1", 12800, 3072, 768),
+              ("v.fc2", 12800, 768, 3072), ("t.qkv", 19712, 1536, 512), ("t.out", 19712, 512, 512),
+              ("t.fc1", 19712, 2048, 512), ("t.fc2", 19712, 512, 2048), ("big", 8192, 8192, 8192)]
+    g = torch.Generator().manual_seed(0)
+    for name, M, N, K in shapes:
+        a = torch.randn(M, K, generator=g).to(dev).to(torch.bfloat16)
+        w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev).to(torch.bfloat16)
+        bias = torch.randn(N, generator=g).to(dev).to(torch.bfloat16)
+        out = torch.zeros(M, N, device=dev, dtype=torch.bfloat16)
+        ms_lib = _time(lambda: F.linear(a, w, bias), iters=20)
+        ms_mm = _time(lambda: torch.mm(a, w.t(), out=out), iters=20)
+        if K % 64 == 0 and N % 256 == 0:
+            ms_own = _time(lambda: gemm_nt(a, w, bias.float(), epilogue=0, out=out), iters=20)
+        else:
+            ms_own = float("nan")
+        f = 2.0 * M * N * K / 1e9
+        print(f"{name:6s} {M:6d}x{N:5d}x{K:5d}: F.linear+bias {f / ms_lib:7.1f} TF/s   torch.mm {f / ms_mm:7.1f} TF/s   gemm_nt(bias) {f / ms_own:7.1f} TF/s")
+
+
 def sec_ldpad():
     """Does padding the leading dimension (rows no longer a multiple of 2 KB apart) change the fill rate?"""
     from plip_amd.engine import gemm_nt_ld
@@ -320,6 +343,35 @@ def sec_overlap():
         for ov in (False, True):
             ms = _time(lambda: sharded_pair_logits(model, px, ids, mask, overlap=ov), iters=20, warm=3)
             print(f"overlap={ov}: {ms:.3f} ms/step  {B / ms * 1e3:.0f} pairs/s")
+    # experiment: more kernel-level blending -- two engines, each on half the batch
+    m2 = PlipModel(cfg, sd, dtype="bf16", max_batch=B)
+    sA, sB = torch.cuda.Stream(), torch.cuda.Stream()
+    h = B // 2
+
+    def four_streams():
+        main = torch.cuda.current_stream()
+        sA.wait_stream(main); sB.wait_stream(main)
+        with torch.cuda.stream(sA):
+            model.engine.encode_pair(px[:h], ids[:h], mask[:h])
+        with torch.cuda.stream(sB):
+            m2.engine.encode_pair(px[h:], ids[h:], mask[h:])
+        main.wait_stream(sA); main.wait_stream(sB)
+
+    def two_streams_swapped():
+        main = torch.cuda.current_stream()
+        sA.wait_stream(main); sB.wait_stream(main)
+        model.engine.lib.plipmi_set_gemm_policy(1)
+        with torch.cuda.stream(sA):
+            model.engine.encode_image(px[:h]); model.engine.encode_text(ids[:h], mask[:h])
+        with torch.cuda.stream(sB):
+            m2.engine.encode_text(ids[h:], mask[h:]); m2.engine.encode_image(px[h:])
+        model.engine.lib.plipmi_set_gemm_policy(0)
+        main.wait_stream(sA); main.wait_stream(sB)
+
+    for rep in range(2):
+        for name, fn in (("four streams (2 engines x half batch)", four_streams), ("two streams, half batches, swapped tower order", two_streams_swapped)):
+            ms = _time(fn, iters=20, warm=3)
+            print(f"{name}: {ms:.3f} ms/step  {B / ms * 1e3:.0f} pairs/s")
     a = sharded_pair_logits(model, px, ids, mask, overlap=False)[0]
     b = sharded_pair_logits(model, px, ids, mask, overlap=True)[0]
     torch.cuda.synchronize()
@@ -355,6 +407,6 @@ def sec_e2e():
 
 if __name__ == "__main__":
     t0 = time.time()
-    {"gemm": sec_gemm, "attn": sec_attn, "tiny": sec_tiny, "vitb32": sec_vitb32, "gemmbench": sec_gemmbench, "e2e": sec_e2e, "gemmone": sec_gemmone, "policy": sec_policy, "ldpad": sec_ldpad, "gemmtrace": sec_gemmtrace,
+    {"gemm": sec_gemm, "attn": sec_attn, "tiny": sec_tiny, "vitb32": sec_vitb32, "gemmbench": sec_gemmbench, "libgemm": sec_libgemm, "e2e": sec_e2e, "gemmone": sec_gemmone, "policy": sec_policy, "ldpad": sec_ldpad, "gemmtrace": sec_gemmtrace,
      "overlap": sec_overlap}[sys.argv[1]]()
     print(f"[{sys.argv[1]} done in {time.time() - t0:.1f} s]")
