@@ -1,6 +1,7 @@
-// attention_mfma.hip -- bf16 MFMA attention for the short CLIP sequences (S <= 128:
-// 50 vision tokens, 77 text tokens), one workgroup per (image|caption, head), one
-// wavefront per block of 32 queries, v_mfma_f32_32x32x16_bf16 for both products.
+// attention_mfma.hip -- bf16 MFMA attention.  Short CLIP sequences (S <= 128: 50 vision tokens, 77 text tokens)
+// take the single-pass kernel: one workgroup per (image|caption, head), one wavefront per block of 32 queries,
+// v_mfma_f32_32x32x16_bf16 for both products.  Longer ones (ViT-B/16, ViT-L/14[@336]) take the chunked
+// online-softmax kernel further down, built from the same pieces.
 //
 //   scores^T = K Q^T   (operands swapped): a lane owns ONE query column (lane&31) and
 //                      16 keys per 32-key tile, so the softmax row reductions are a
@@ -10,8 +11,8 @@
 //                      permutation that the QK^T accumulator layout already has
 //                      (slot jj of lane group g  <->  key (jj&3) + 4g + 8(jj>>2) + 16s)
 //                      makes the P operand a plain register pack: no cross-lane shuffle.
-//                      V^T comes from an LDS copy of V transposed at staging time
-//                      (row stride S_pad+4 bf16 -> conflict-free ds_read_b64).
+//                      V^T comes from a row-major LDS copy of V through the hardware transpose read
+//                      ds_read_b64_tr_b16 (two [keys][32] images with 64-byte rows -> conflict-free).
 //   Softmax statistics, the running sum and the 1/l normalisation are fp32
 //   (modeling_clip.py:271); P is rounded to bf16 only as the MFMA operand.
 #include "kernels.h"
@@ -20,20 +21,37 @@ namespace plipmi {
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+typedef __attribute__((ext_vector_type(4))) short i16x4;
+
+// V stays row-major in LDS (whole 16-byte pieces straight from the global rows) as two [keys][32 columns] images,
+// one per 32-wide head-dim tile, 64-byte rows.  ds_read_b64_tr_b16 then hands lane (d = lane&31, g = lane>>5) the
+// four keys k0+4g .. k0+4g+3 of column d -- exactly one half of the V^T MFMA fragment under the key permutation
+// described above -- with every 32-lane half of the instruction touching each of the 64 banks once (4 rows x 64 B).
+// Per-lane byte offset inside an image; the (tile, sub-block, image) terms are compile-time immediates.
+__device__ __forceinline__ int vtr_lane_offset(int lrow, int hi) {
+  return (((lrow & 15) >> 2) + 4 * hi) * 64 + ((lrow & 3) * 4 + (lrow >> 4) * 16) * 2;
+}
+__device__ __forceinline__ bf16x8 vtr_fragment(const char* vs, int byte_off) {
+  typedef __attribute__((address_space(3))) i16x4* lds_ptr;
+  const i16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(vs + byte_off));
+  const i16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(vs + byte_off + 8 * 64));  // keys +8
+  typedef __attribute__((ext_vector_type(8))) short i16x8;
+  const i16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
 
 template <int KT>  // 32-key tiles: S <= 32*KT
 __global__ __launch_bounds__(64 * KT) void attention_mfma_kernel(const bf16_t* __restrict__ qkv,
                                                                  bf16_t* __restrict__ out, int S, int H, int causal,
                                                                  const int64_t* __restrict__ key_mask) {
   constexpr int SP = 32 * KT;   // padded sequence
-  constexpr int VLD = SP + 4;   // Vt row stride (bf16): (SP/2 + 2) dwords, odd multiple of 2 -> all 64 banks
   // Q and K rows are staged through LDS in whole 128-byte lines (8 lanes x 16 B per row) instead of being loaded
   // fragment-shaped (16 B from each of 32 rows per instruction, which costs the texture-address unit 2x the
   // time for the same bytes); the LDS image uses the GEMM's XOR swizzle so the fragment ds_read_b128 are
-  // conflict-free.  V is transposed on the way in.
+  // conflict-free.  V keeps its row-major form (two [SP][32] images) and is transposed by the LDS read itself.
   __shared__ __attribute__((aligned(16))) char Qs[SP * 128];
   __shared__ __attribute__((aligned(16))) char Ks[SP * 128];
-  __shared__ __attribute__((aligned(16))) bf16_t Vt[64 * VLD];
+  __shared__ __attribute__((aligned(16))) char Vs[2 * SP * 64];
   __shared__ unsigned long long mk[4];
 
   const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
@@ -55,12 +73,11 @@ __global__ __launch_bounds__(64 * KT) void attention_mfma_kernel(const bf16_t* _
     const bf16_t* src = base + (size_t)rg * ld + c * 8;
     const u32x4 q16 = *reinterpret_cast<const u32x4*>(src);
     const u32x4 k16 = *reinterpret_cast<const u32x4*>(src + D);
-    const bf16x8 v8 = *reinterpret_cast<const bf16x8*>(src + 2 * D);
+    const u32x4 v16 = *reinterpret_cast<const u32x4*>(src + 2 * D);
     const int off = row * 128 + ((c ^ ((row >> 1) & 7)) << 4);
     *reinterpret_cast<u32x4*>(Qs + off) = q16;
     *reinterpret_cast<u32x4*>(Ks + off) = k16;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) Vt[(c * 8 + i) * VLD + row] = v8[i];
+    *reinterpret_cast<u32x4*>(Vs + (c >> 2) * (SP * 64) + row * 64 + (c & 3) * 16) = v16;
   }
   __syncthreads();
 
@@ -120,6 +137,7 @@ __global__ __launch_bounds__(64 * KT) void attention_mfma_kernel(const bf16_t* _
   for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[dt][r] = 0.f;
+  const char* vlane = Vs + vtr_lane_offset(lrow, hi);
 #pragma unroll
   for (int t = 0; t < KT; ++t) {
     if (causal && 32 * t > q0 + 31) continue;
@@ -130,11 +148,8 @@ __global__ __launch_bounds__(64 * KT) void attention_mfma_kernel(const bf16_t* _
       for (int jj = 0; jj < 8; ++jj) pf[jj] = (bf16_t)sc[t][8 * s2 + jj];
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
-        const bf16_t* vr = Vt + (dt * 32 + lrow) * VLD + 32 * t + 16 * s2 + 4 * hi;
-        const u32x2 v0 = *reinterpret_cast<const u32x2*>(vr);
-        const u32x2 v1 = *reinterpret_cast<const u32x2*>(vr + 8);
-        const u32x4 vf = {v0[0], v0[1], v1[0], v1[1]};
-        acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf), pf, acc[dt], 0, 0, 0);
+        const bf16x8 vf = vtr_fragment(vlane, dt * (SP * 64) + (32 * t + 16 * s2) * 64);
+        acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, acc[dt], 0, 0, 0);
       }
     }
   }
@@ -165,9 +180,184 @@ __global__ __launch_bounds__(64 * KT) void attention_mfma_kernel(const bf16_t* _
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// S > 128 (ViT-B/16: 197 tokens, ViT-L/14: 257, ViT-L/14@336: 577): the same two MFMA products, streamed over
+// 128-key chunks with an online softmax.  One workgroup = 128 queries of one (sample, head) (4 waves x 32), grid
+// (B*H, ceil(S/128)).  Because a lane owns one query column in BOTH accumulator layouts (scores^T and O^T), the
+// running max / running sum / rescale of the online softmax are per-lane scalars: no cross-lane traffic beyond the
+// one lane^32 exchange per chunk.  K and V^T chunks are staged through LDS exactly like the short-sequence kernel.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void attention_flash_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                              int S, int H, int causal,
+                                                              const int64_t* __restrict__ key_mask) {
+  constexpr int SP = 128;
+  __shared__ __attribute__((aligned(16))) char Qs[SP * 128];
+  __shared__ __attribute__((aligned(16))) char Ks[SP * 128];
+  __shared__ __attribute__((aligned(16))) char Vs[2 * SP * 64];
+  __shared__ unsigned long long mk[2];
+
+  const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
+  const int qbase = blockIdx.y * SP;
+  const int D = H * 64, ld = 3 * D;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bf16_t* base = qkv + (size_t)b * S * ld + h * 64;
+
+  const int qrows = min(SP, (S - qbase + 31) & ~31);  // 32-row tiles that hold at least one real query
+  for (int e = tid; e < qrows * 8; e += 256) {  // the query block, whole 128-byte lines, GEMM swizzle
+    const int row = e >> 3, c = e & 7;
+    const int rg = qbase + row < S ? qbase + row : S - 1;
+    const u32x4 q16 = *reinterpret_cast<const u32x4*>(base + (size_t)rg * ld + c * 8);
+    *reinterpret_cast<u32x4*>(Qs + row * 128 + ((c ^ ((row >> 1) & 7)) << 4)) = q16;
+  }
+
+  const int q0 = wave * 32;  // inside the block
+  const bool active = qbase + q0 < S;
+  const int lrow = lane & 31, hi = lane >> 5;
+  const int qidx = qbase + q0 + lrow;
+  const int lsw = (lrow >> 1) & 7;
+
+  const char* vlane = Vs + vtr_lane_offset(lrow, hi);
+  u32x4 qf[4];
+  f32x16 acc[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[dt][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;  // l_run: this lane's half of the row sum
+
+  int nchunks = (S + SP - 1) / SP;
+  if (causal) nchunks = min(nchunks, (qbase + SP - 1) / SP + 1);  // chunks entirely above the diagonal
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const int kbase = ch * SP;
+    __syncthreads();  // everyone is done reading the previous chunk
+    if (tid < SP) {
+      const int key = kbase + tid;
+      const bool ok = key < S && (key_mask == nullptr || key_mask[(size_t)b * S + key] != 0);
+      const unsigned long long bits = __ballot(ok);
+      if (lane == 0) mk[wave] = bits;
+    }
+    const int krows = min(SP, (S - kbase + 31) & ~31);  // key tiles past the sequence end are never read
+    for (int e = tid; e < krows * 8; e += 256) {
+      const int row = e >> 3, c = e & 7;
+      const int rg = kbase + row < S ? kbase + row : S - 1;
+      const bf16_t* src = base + (size_t)rg * ld + c * 8 + D;
+      const u32x4 k16 = *reinterpret_cast<const u32x4*>(src);
+      const u32x4 v16 = *reinterpret_cast<const u32x4*>(src + D);
+      *reinterpret_cast<u32x4*>(Ks + row * 128 + ((c ^ ((row >> 1) & 7)) << 4)) = k16;
+      *reinterpret_cast<u32x4*>(Vs + (c >> 2) * (SP * 64) + row * 64 + (c & 3) * 16) = v16;
+    }
+    __syncthreads();
+    if (!active) continue;
+    if (ch == 0) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+        qf[ks] = *reinterpret_cast<const u32x4*>(Qs + (q0 + lrow) * 128 + (((ks * 2 + hi) ^ lsw) << 4));
+    }
+    // two 64-key halves per staged chunk: 32 score registers live instead of 64 (3 waves/SIMD), one online-softmax
+    // update per half.  Validity bits of the half, pre-shifted so that bit (r&3)+8(r>>2) of tile t's word is
+    // this lane's key slot r.
+    const unsigned long long mhalf[2] = {mk[0], mk[1]};
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      if (kbase + 64 * hf >= S) break;                           // wave-uniform: past the sequence end
+      if (causal && kbase + 64 * hf > qbase + q0 + 31) break;  // wave-uniform: the rest is above the diagonal
+      const unsigned vw[2] = {(unsigned)(mhalf[hf] & 0xffffffffull) >> (4 * hi), (unsigned)(mhalf[hf] >> 32) >> (4 * hi)};
+      f32x16 sc[2];
+      float cmax = -INFINITY;
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        const int t = 2 * hf + tt;
+        const bool live = kbase + 32 * t < S && !(causal && kbase + 32 * t > qbase + q0 + 31);  // wave-uniform
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sc[tt][r] = 0.f;
+        if (live) {
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) {
+            const u32x4 kf = *reinterpret_cast<const u32x4*>(Ks + (32 * t + lrow) * 128 + (((ks * 2 + hi) ^ lsw) << 4));
+            sc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf),
+                                                             __builtin_bit_cast(bf16x8, qf[ks]), sc[tt], 0, 0, 0);
+          }
+        }
+        const int kfirst = kbase + 32 * t + 4 * hi;  // key of slot 0
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int slot = (r & 3) + 8 * (r >> 2);
+          const bool ok = live && ((vw[tt] >> slot) & 1u) && (!causal || kfirst + slot <= qidx);
+          sc[tt][r] = ok ? sc[tt][r] : -INFINITY;
+          cmax = fmaxf(cmax, sc[tt][r]);
+        }
+      }
+      cmax = fmaxf(cmax, __shfl_xor(cmax, 32, 64));
+      const float m_new = fmaxf(m_run, cmax);
+      const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+      const float scale = (m_run == -INFINITY) ? 0.f : __expf(m_run - m_use);  // acc, l_run are 0 while m_run = -inf
+      m_run = m_new;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[dt][r] *= scale;
+      float csum = 0.f;
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        const int t = 2 * hf + tt;
+        if (kbase + 32 * t >= S || (causal && kbase + 32 * t > qbase + q0 + 31)) continue;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          bf16x8 pf;
+#pragma unroll
+          for (int jj = 0; jj < 8; ++jj) {
+            const float pv = __expf(sc[tt][8 * s2 + jj] - m_use);
+            csum += pv;
+            pf[jj] = (bf16_t)pv;
+          }
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) {
+            const bf16x8 vf = vtr_fragment(vlane, dt * (SP * 64) + (32 * t + 16 * s2) * 64);
+            acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, acc[dt], 0, 0, 0);
+          }
+        }
+      }
+      l_run = l_run * scale + csum;
+    }
+  }
+  if (!active) return;  // no workgroup barrier below
+  {
+    const float rsum = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / rsum;
+    char* orow_lds = Qs + (q0 + lrow) * 128;  // this wave's own Q rows: consumed into qf long ago
+    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const int d = dt * 32 + 8 * q4 + 4 * hi;
+        const int c = d >> 3;
+        const bf16x4 v = {(bf16_t)(acc[dt][4 * q4 + 0] * inv), (bf16_t)(acc[dt][4 * q4 + 1] * inv),
+                          (bf16_t)(acc[dt][4 * q4 + 2] * inv), (bf16_t)(acc[dt][4 * q4 + 3] * inv)};
+        *reinterpret_cast<bf16x4*>(orow_lds + ((c ^ lsw) << 4) + (d & 4) * 2) = v;
+      }
+    __builtin_amdgcn_wave_barrier();
+    const int c = lane & 7;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int rl = q0 + it * 8 + (lane >> 3);
+      const int r = qbase + rl;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(Qs + rl * 128 + ((c ^ ((rl >> 1) & 7)) << 4));
+      if (r < S) *reinterpret_cast<u32x4*>(out + ((size_t)b * S + r) * D + h * 64 + c * 8) = v;
+    }
+  }
+}
+
 hipError_t launch_attention_mfma(const void* qkv, void* out, int B, int S, int H, int causal, const int64_t* key_mask,
                                  hipStream_t s) {
-  if (S > 128 || S <= 0) return hipErrorNotSupported;
+  if (S <= 0) return hipErrorInvalidValue;
+  if (S > 128) {
+    hipLaunchKernelGGL(attention_flash_kernel, dim3(B * H, (S + 127) / 128), dim3(256), 0, s, (const bf16_t*)qkv,
+                       (bf16_t*)out, S, H, causal, key_mask);
+    return hipGetLastError();
+  }
   const int KT = (S + 31) / 32;
   const dim3 grid(B * H), block(64 * KT);
 #define PLIPMI_ATT(K) \

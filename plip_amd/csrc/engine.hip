@@ -334,8 +334,8 @@ int plipmi_create(const plipmi_config* cfg, const plipmi_weights* w, void* strea
   const char* ai = getenv("PLIPMI_ATTENTION");
   e->attn_impl = ai ? atoi(ai) : PLIPMI_DEFAULT_ATTENTION;
   if (e->dtype != PLIPMI_BF16) e->attn_impl = 0;
-  e->attn_impl_txt = (e->attn_impl && g.context_length <= 128) ? 1 : 0;
-  e->attn_impl_vis = (e->attn_impl && tokens <= 128) ? 1 : 0;
+  e->attn_impl_txt = e->attn_impl ? 1 : 0;  // S <= 128: single-pass MFMA kernel, longer: chunked online softmax
+  e->attn_impl_vis = e->attn_impl ? 1 : 0;
 
   Carver sizing;
   carve(e, sizing);

@@ -24,7 +24,10 @@ def _ref(qkv, B, S, H, causal, mask):
 
 
 CASES = [(3, 50, 12, False, False), (4, 77, 8, True, True), (2, 77, 8, True, False), (2, 1, 2, False, False),
-         (2, 33, 2, True, True), (1, 128, 2, False, False), (2, 97, 2, True, True), (1, 64, 3, True, False)]
+         (2, 33, 2, True, True), (1, 128, 2, False, False), (2, 97, 2, True, True), (1, 64, 3, True, False),
+         # S > 128: chunked online-softmax MFMA kernel (ViT-B/16 197, ViT-L/14 257, ViT-L/14@336 577 tokens)
+         (2, 129, 2, False, False), (2, 197, 12, False, False), (2, 257, 16, False, True), (1, 577, 16, False, False),
+         (2, 300, 2, True, True), (1, 256, 1, True, False), (1, 1000, 1, False, True)]
 
 
 @pytest.mark.parametrize("B,S,H,causal,use_mask", CASES)
@@ -51,11 +54,32 @@ def test_attention_kernels(B, S, H, causal, use_mask, mode):
     assert err < tol, f"{mode} B{B} S{S} H{H} causal={causal} mask={use_mask}: max err {err:.3e}"
 
 
-def test_mfma_attention_rejects_long_sequences():
+def test_attention_argument_checks():
     from plip_amd._lib import PlipmiError
     from plip_amd.engine import attention
-    qkv = torch.zeros(200, 3 * 64, device="cuda:0", dtype=torch.bfloat16)
+    qkv = torch.zeros(200, 3 * 64, device="cuda:0", dtype=torch.float32)
     with pytest.raises(PlipmiError):
-        attention(qkv, 1, 200, 1, impl=1)
+        attention(qkv, 1, 200, 1, impl=1)            # the MFMA kernels are bf16-only
     out = attention(qkv, 1, 200, 1, impl=0)          # the exact kernel takes any S <= 1024
     assert out.shape == (200, 64)
+    long = torch.zeros(2000, 3 * 64, device="cuda:0", dtype=torch.bfloat16)
+    with pytest.raises(PlipmiError):
+        attention(long, 1, 2000, 1, impl=0)
+    assert attention(long, 1, 2000, 1, impl=1).shape == (2000, 64)   # the chunked MFMA kernel has no length limit
+
+
+def test_fully_masked_tail_chunks_do_not_disturb_the_running_softmax():
+    """Keys 0..9 valid, everything after (two whole chunks) masked: the online softmax must equal the 10-key one."""
+    from plip_amd.engine import attention
+    g = torch.Generator().manual_seed(9)
+    S, H = 300, 2
+    qkv = torch.randn(S, 3 * H * 64, generator=g).to("cuda:0").to(torch.bfloat16)
+    mask = (torch.arange(S)[None, :] < 10).long().to("cuda:0")
+    out = attention(qkv, 1, S, H, False, mask, impl=1)
+    ref = _ref(qkv, 1, S, H, False, mask)
+    assert (out.double() - ref).abs().max().item() < 3e-2
+    # and the mirrored case: only the LAST chunk has valid keys (first chunks contribute nothing, m stays -inf)
+    mask2 = (torch.arange(S)[None, :] >= 290).long().to("cuda:0")
+    out2 = attention(qkv, 1, S, H, False, mask2, impl=1)
+    assert torch.isfinite(out2).all()
+    assert (out2.double() - _ref(qkv, 1, S, H, False, mask2)).abs().max().item() < 3e-2

@@ -182,3 +182,30 @@ def test_batch_edge_cases(engines):
     t_full = model.get_text_features(input_ids=tids)
     assert torch.equal(model.get_text_features(input_ids=tids[5:6]), t_full[5:6])
     assert model.get_text_features(input_ids=tids[:0]).shape == (0, cfg.projection_dim)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_long_sequence_vision_tower(dtype):
+    """A ViT with 257 tokens (patch 4 on 64x64, the ViT-L/14 token count): the bf16 engine runs the chunked
+    online-softmax MFMA attention, the fp32 engine the exact kernel; both against the CPU oracle."""
+    import dataclasses
+    from plip_amd import weights as W
+    from plip_amd.config import get_config
+    from plip_amd.model import PlipModel
+    cfg = dataclasses.replace(get_config("tiny"), patch_size=4)
+    assert cfg.v_tokens == 257
+    sd = W.synthetic_state_dict(cfg, 3)
+    px = W.synthetic_pixels(cfg, 3, 4)
+    model = PlipModel(cfg, sd, dtype=dtype, max_batch=4)
+    try:
+        want_h = O.vision_tower(px, sd, cfg, return_hidden=True)
+        t = TINY_BF16 if dtype == "bf16" else TOL["f32"]
+        for layer in (1, cfg.v_layers):
+            h = model.engine.hidden("vision", layer, torch.from_numpy(px)).cpu().numpy()
+            assert np.abs(h - want_h[1][layer]).max() < t["hidden"], f"layer {layer}"
+        img = model.get_image_features(pixel_values=torch.from_numpy(px)).cpu().numpy()
+        assert np.abs(img - want_h[0]).max() < t["feat"]
+        emb = model.engine.encode_image(torch.from_numpy(px), normalize=True).cpu().numpy()
+        assert np.abs(emb - O.l2_normalize(want_h[0])).max() < t["emb"]
+    finally:
+        model.engine.close()

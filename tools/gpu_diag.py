@@ -134,7 +134,7 @@ def sec_attn():
                 except Exception as e:
                     print(f"attn {mode} B{B} S{S}: EXC {e}")
     # timing at production shapes
-    for (B, S, H, causal) in ((256, 50, 12, False), (256, 77, 8, True)):
+    for (B, S, H, causal) in ((256, 50, 12, False), (256, 77, 8, True), (256, 197, 12, False), (128, 257, 16, False), (64, 577, 16, False)):
         qd = torch.randn(B * S, 3 * H * 64, generator=g).to(dev).to(torch.bfloat16)
         for impl in (0, 1):
             ms = _time(lambda: attention(qd, B, S, H, causal, None, impl=impl), iters=20)
@@ -200,6 +200,32 @@ def sec_libgemm():
             ms_own = float("nan")
         f = 2.0 * M * N * K / 1e9
         print(f"{name:6s} {M:6d}x{N:5d}x{K:5d}: F.linear+bias {f / ms_lib:7.1f} TF/s   torch.mm {f / ms_mm:7.1f} TF/s   gemm_nt(bias) {f / ms_own:7.1f} TF/s")
+
+
+def sec_towerswap():
+    """BASELINE configs[4] tower swap: ViT-B/16, ViT-L/14 and ViT-L/14@336 (synthetic weights, bf16)."""
+    for arch, B in (("ViT-B/16", 128), ("ViT-L/14", 64), ("ViT-L/14@336px", 32)):
+        cfg = get_config(arch)
+        sd = W.synthetic_state_dict(cfg, 0)
+        model = PlipModel(cfg, sd, dtype="bf16", max_batch=B)
+        px = torch.from_numpy(W.synthetic_pixels(cfg, B, 1)).to(dev)
+        ids_np, mask_np = W.synthetic_ids(cfg, B, 2)
+        ids = torch.from_numpy(ids_np).to(dev)
+        ms_i = _time(lambda: model.engine.encode_image(px), iters=5, warm=2)
+        ms_t = _time(lambda: model.engine.encode_text(ids, None), iters=5, warm=2)
+        fi, ft = cfg.image_flops() * B, cfg.text_flops() * B
+        print(f"{arch:16s} B={B}: image {ms_i:8.2f} ms ({B / ms_i * 1e3:8.0f} img/s, {fi / ms_i / 1e9:6.1f} TF/s)   "
+              f"text {ms_t:7.2f} ms ({B / ms_t * 1e3:8.0f} cap/s, {ft / ms_t / 1e9:6.1f} TF/s)")
+        rows = []
+        with model.engine.profile(rows):
+            model.engine.encode_image(px)
+            torch.cuda.synchronize()
+        tot = sum(r["total_ms"] for r in rows)
+        for r in sorted(rows, key=lambda r: -r["total_ms"])[:6]:
+            print(f"      {r['name']:52s} {r['total_ms']:8.3f} ms {100 * r['total_ms'] / tot:5.1f}%")
+        model.engine.close()
+        del model
+        torch.cuda.empty_cache()
 
 
 def sec_ldpad():
@@ -407,6 +433,6 @@ def sec_e2e():
 
 if __name__ == "__main__":
     t0 = time.time()
-    {"gemm": sec_gemm, "attn": sec_attn, "tiny": sec_tiny, "vitb32": sec_vitb32, "gemmbench": sec_gemmbench, "libgemm": sec_libgemm, "e2e": sec_e2e, "gemmone": sec_gemmone, "policy": sec_policy, "ldpad": sec_ldpad, "gemmtrace": sec_gemmtrace,
+    {"gemm": sec_gemm, "attn": sec_attn, "tiny": sec_tiny, "vitb32": sec_vitb32, "gemmbench": sec_gemmbench, "libgemm": sec_libgemm, "towerswap": sec_towerswap, "e2e": sec_e2e, "gemmone": sec_gemmone, "policy": sec_policy, "ldpad": sec_ldpad, "gemmtrace": sec_gemmtrace,
      "overlap": sec_overlap}[sys.argv[1]]()
     print(f"[{sys.argv[1]} done in {time.time() - t0:.1f} s]")
