@@ -293,6 +293,27 @@ void gemm_nt_kernel(const GemmParams p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+  // epilogue operands in the row-contiguous layout of the transposed store (16 lanes x 16 B per output row)
+  // Register budget (256 per lane at two waves per SIMD): accumulators + K-loop fragments + one operand block must
+  // fit for the early request, accumulators + two operand blocks + the transposed values for the double buffer;
+  // the 192x256 tile affords both, 320x256 and the 4x2-wave 256x256 tile neither (they would spill).
+  constexpr int kAccRegs = MI * NI * 16, kBlkRegs = (NI / 2) * 32;
+  constexpr bool kRowOperand = (EPI == EPI_BIAS_RESID || EPI == EPI_PATCH) && NSTAGE == 2 && sizeof(T) == 2 &&
+                               kAccRegs + 2 * (MI + NI) * 4 + kBlkRegs + 24 <= 256;
+  constexpr int kAddBufs = (kAccRegs + 2 * kBlkRegs + 32 + 24 <= 256) ? 2 : 1;
+  const int rd_row = lane >> 4, rd_col = (lane & 15) * 4;
+  float4 add[kAddBufs][NI / 2][8];
+  bool add_ready = false;
+  auto load_block = [&](int i, float4 (&dst)[NI / 2][8]) {
+#pragma unroll
+    for (int jp = 0; jp < NI / 2; ++jp)
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int m = m0 + wm * TM + i * 32 + it * 4 + rd_row;
+        dst[jp][it] = EpilogueOp<T, EPI>::load(p, m < p.M ? m : p.M - 1, n0 + wn * TN + jp * 64 + rd_col);
+      }
+  };
+
   auto compute = [&](int buf, int fill_buf) {
     const char* sb = smem + buf * STAGE;
     // fragments of K-step ks+1 are fetched from LDS before the MFMAs of step ks issue
@@ -431,6 +452,11 @@ void gemm_nt_kernel(const GemmParams p) {
     }
     __syncthreads();
   }
+  if constexpr (kRowOperand) {  // the residual / position rows of the first 32-row block travel during the last K step
+    load_block(0, add[0]);
+    add_ready = true;
+    __builtin_amdgcn_sched_barrier(0);
+  }
   if (!(p.ablate & 2)) compute((KT - 1) & 1, -1);
   if constexpr (L2PF > 0) {
     wait_vm0();
@@ -453,19 +479,69 @@ void gemm_nt_kernel(const GemmParams p) {
   __syncthreads();  // every wave is done reading the last K tile: the staging LDS can be reused
   if (p.ablate & 4) return;
   char* slab = smem + wave * SLAB_BYTES;
-  const int rd_row = lane >> 4, rd_col = (lane & 15) * 4;
+  if constexpr (sizeof(T) == 2 && (EPI == EPI_BIAS || EPI == EPI_BIAS_QGELU)) {
+    // bf16 outputs whose epilogue is column-wise (bias, QuickGELU): finish the arithmetic in the ACCUMULATOR layout
+    // -- the bias of a lane's 4 x 4 columns per MFMA tile is loaded once per tile column, not once per output row --
+    // round to bf16 there, and transpose HALF the bytes: 8 ds_write_b64 + 4 ds_read_b128 + 4 16-byte global stores
+    // per 32 x 64 slab instead of 8 ds_write_b128 + 8 ds_read_b128 + 8 bias loads + 8 8-byte stores.
+    constexpr int HP = 64 * 2 + 16;  // bf16 slab row pitch: 16-byte aligned rows for the ds_read_b128
+    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+    float4 bq[NI][4];
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        bq[j][q] = *reinterpret_cast<const float4*>(p.bias + n0 + wn * TN + j * 32 + 8 * q + 4 * lgrp);
+    const int hr_row = lane >> 3, hr_chunk = lane & 7;  // 8 lanes x 16 B = one 128-byte output row piece
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int jp = 0; jp < NI / 2; ++jp) {
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int j = 2 * jp + jj;
+            float v0 = acc[i][j][4 * q + 0] + bq[j][q].x, v1 = acc[i][j][4 * q + 1] + bq[j][q].y;
+            float v2 = acc[i][j][4 * q + 2] + bq[j][q].z, v3 = acc[i][j][4 * q + 3] + bq[j][q].w;
+            if constexpr (EPI == EPI_BIAS_QGELU) {
+              v0 = quick_gelu<false>(v0); v1 = quick_gelu<false>(v1);
+              v2 = quick_gelu<false>(v2); v3 = quick_gelu<false>(v3);
+            }
+            const bf16x4 pk = {(bf16_t)v0, (bf16_t)v1, (bf16_t)v2, (bf16_t)v3};
+            *reinterpret_cast<bf16x4*>(slab + lrow * HP + (jj * 32 + 8 * q + 4 * lgrp) * 2) = pk;
+          }
+        __builtin_amdgcn_wave_barrier();
+        u32x4 o[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+          o[it] = *reinterpret_cast<const u32x4*>(slab + (it * 8 + hr_row) * HP + hr_chunk * 16);
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          int m = m0 + wm * TM + i * 32 + it * 8 + hr_row;
+          const bool in_range = m < p.M;
+          if (p.ablate & 32) m &= 255;  // timeline experiment: every tile stores to the same 256 rows (L2-resident)
+          if (in_range)
+            *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(p.C) + (size_t)m * p.ldc + n0 + wn * TN + jp * 64 + hr_chunk * 8) = o[it];
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    if (trace) {
+      __builtin_amdgcn_s_waitcnt(0);
+      if (tid == 0) trace[3] = __builtin_amdgcn_s_memtime();
+    }
+    return;
+  }
+  // every bias / residual / position row a 32-row block needs is requested one block ahead (block 0 before the last
+  // K step), so the memory latency of the residual stream (MALL/HBM) is covered by the previous block's transpose
+  if (!add_ready) load_block(0, add[0]);
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
-    // every bias / residual / position row this 32-row block needs is requested up front, so the wave pays
-    // ONE memory latency per row block instead of one per slab (the residual rows come from MALL/HBM)
-    float4 add[NI / 2][8];
-#pragma unroll
-    for (int jp = 0; jp < NI / 2; ++jp)
-#pragma unroll
-      for (int it = 0; it < 8; ++it) {
-        const int m = m0 + wm * TM + i * 32 + it * 4 + rd_row;
-        add[jp][it] = EpilogueOp<T, EPI>::load(p, m < p.M ? m : p.M - 1, n0 + wn * TN + jp * 64 + rd_col);
-      }
+    if constexpr (kAddBufs == 2) {
+      if (i + 1 < MI) load_block(i + 1, add[(i + 1) & 1]);
+    } else {
+      if (i > 0) load_block(i, add[0]);
+    }
 #pragma unroll
     for (int jp = 0; jp < NI / 2; ++jp) {
 #pragma unroll
@@ -484,8 +560,10 @@ void gemm_nt_kernel(const GemmParams p) {
         v[it] = *reinterpret_cast<const f32x4*>(slab + (it * 4 + rd_row) * SLAB_PITCH + rd_col * 4);
 #pragma unroll
       for (int it = 0; it < 8; ++it) {
-        const int m = m0 + wm * TM + i * 32 + it * 4 + rd_row;
-        if (m < p.M) EpilogueOp<T, EPI>::store(p, m, n, v[it][0], v[it][1], v[it][2], v[it][3], add[jp][it]);
+        int m = m0 + wm * TM + i * 32 + it * 4 + rd_row;
+        const bool in_range = m < p.M;
+        if (p.ablate & 32) m &= 255;  // timeline experiment: every tile stores to the same 256 rows (L2-resident)
+        if (in_range) EpilogueOp<T, EPI>::store(p, m, n, v[it][0], v[it][1], v[it][2], v[it][3], add[kAddBufs == 2 ? (i & 1) : 0][jp][it]);
       }
       __builtin_amdgcn_wave_barrier();
     }
@@ -525,7 +603,7 @@ const GemmVariant& gemm_variant(int v);
 // dtype: 0 fp32, 1 bf16.  variant -1 = auto, -2 = naive.  Returns hipError_t as int; *kernel_name (optional)
 // receives a static string naming the kernel that ran.
 int gemm_launch(int dtype, int epi, int variant, const GemmParams& p, hipStream_t stream, const char** kernel_name);
-int gemm_default_variant(int dtype, int M, int N, int K);
+int gemm_default_variant(int dtype, int M, int N, int K, int epi = -1);
 void gemm_set_default_override(int variant);  // PLIPMI_GEMM_VARIANT / tests
 void gemm_set_policy(int policy);             // 0: wave-quantisation cost model (one stream), 1: co-scheduled streams
 

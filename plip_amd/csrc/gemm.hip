@@ -46,7 +46,7 @@ void gemm_set_default_override(int variant) { g_override = variant; }
 static int g_policy = 0;
 void gemm_set_policy(int policy) { g_policy = policy; }
 
-int gemm_default_variant(int dtype, int M, int N, int K) {
+int gemm_default_variant(int dtype, int M, int N, int K, int epi) {
   if (g_override == -100) {
     const char* e = getenv("PLIPMI_GEMM_VARIANT");
     g_override = e ? atoi(e) : -1;
@@ -67,6 +67,9 @@ int gemm_default_variant(int dtype, int M, int N, int K) {
   // the other tower's kernels, so quantisation stops mattering and the tile with the fewest L2->LDS bytes per FLOP
   // wins (in-process A/B, profiles/r01_gemm_policy_ab.txt: 5.69 ms/step vs 6.04 ms with the cost model).
   if (g_policy == 1 && dtype == 1 && N % 256 == 0) return 25;
+  // Policy 2: as 1, but the fp32 residual epilogues take the 192x256 tile, whose register budget lets it request the
+  // residual rows one block ahead (gemm.h kRowOperand).
+  if (g_policy == 2 && dtype == 1 && N % 256 == 0) return (epi == EPI_BIAS_RESID || epi == EPI_PATCH) ? 23 : 25;
   const int cus = gemm_num_cus();
   struct Cand { int variant, bm, bn, per_cu; double rel; };
   const Cand cands_bf16[] = {{16, 256, 256, 1, 1.00}, {25, 320, 256, 1, 1.00}, {23, 192, 256, 1, 1.05}, {8, 128, 128, 2, 1.21}};
@@ -91,7 +94,7 @@ int gemm_default_variant(int dtype, int M, int N, int K) {
 static const char* kEpiNames[EPI_COUNT] = {"bias", "bias_qgelu", "bias_resid", "scale", "patch"};
 
 int gemm_launch(int dtype, int epi, int variant, const GemmParams& p, hipStream_t stream, const char** kernel_name) {
-  if (variant == -1) variant = gemm_default_variant(dtype, p.M, p.N, p.K);
+  if (variant == -1) variant = gemm_default_variant(dtype, p.M, p.N, p.K, epi);
   if (p.M <= 0) return 0;
   const int bk = dtype == 1 ? 64 : 32;
   if (variant >= 0) {
