@@ -238,8 +238,11 @@ void gemm_nt_kernel(const GemmParams p) {
   };
   // the same fill cut in 4 parts (one per K step of the MFMA block): SCHED 3 spreads the LDS-DMA issue over the
   // iteration instead of queueing all PA+PW requests of every wave on the texture-address unit right after the barrier
+  // SCHED 5 / 6: the same requests packed into the first 2 / 3 K steps, so the last one has most of the iteration
+  // (not a quarter of it) to land before the end-of-iteration wait
+  constexpr int kFillParts = SCHED == 5 ? 2 : SCHED == 6 ? 3 : 4;
   auto stage_issue_part = [&](int buf, int part) {
-    constexpr int PER = (PA + PW + 3) / 4;
+    constexpr int PER = (PA + PW + kFillParts - 1) / kFillParts;
     const unsigned base = lds0 + buf * STAGE + wave * 1024;
 #pragma unroll
     for (int e = 0; e < PER; ++e) {
@@ -332,8 +335,8 @@ void gemm_nt_kernel(const GemmParams p) {
         for (int j = 0; j < NI; ++j)
           wf[(ks + 1) & 1][j] = *reinterpret_cast<const u32x4*>(sb + w_tile + j * 32 * 128 + foff[ks + 1]);
       }
-      if constexpr (SCHED == 3 && GLDS) {
-        if (fill_buf >= 0) stage_issue_part(fill_buf, ks);
+      if constexpr ((SCHED == 3 || SCHED == 5 || SCHED == 6) && GLDS) {
+        if (fill_buf >= 0 && ks < kFillParts) stage_issue_part(fill_buf, ks);
       }
       if constexpr (SCHED >= 1) __builtin_amdgcn_sched_barrier(0);
       if constexpr (SCHED == 2) __builtin_amdgcn_s_setprio(1);
@@ -435,7 +438,7 @@ void gemm_nt_kernel(const GemmParams p) {
   if (trace && tid == 0) trace[1] = __builtin_amdgcn_s_memtime();
   for (int kt = 0; kt < KT - 1; ++kt) {
     const int cur = kt & 1;
-    if constexpr (!(SCHED == 3 && GLDS)) {
+    if constexpr (!((SCHED == 3 || SCHED == 5 || SCHED == 6) && GLDS)) {
       if (!(p.ablate & 1)) stage_issue(cur ^ 1);
     }
     bool touched = false;

@@ -70,7 +70,7 @@ int launch_naive(const GemmParams& p, hipStream_t stream) {
   return (int)hipGetLastError();
 }
 
-constexpr int kNumVariants = 29;
+constexpr int kNumVariants = 35;
 
 // table[variant][epilogue]
 template <typename T>
@@ -107,6 +107,12 @@ struct GemmTable {
       case 26: return launch_tiled<T, 320, 256, 2, 4, EPI, true, 0>;
       case 27: return launch_tiled<T, 256, 256, 2, 2, EPI, true, 1>;
       case 28: return launch_tiled<T, 256, 256, 2, 2, EPI, true, 3>;
+      case 29: return launch_tiled<T, 256, 256, 4, 2, EPI, true, 5>;
+      case 30: return launch_tiled<T, 320, 256, 2, 4, EPI, true, 5>;
+      case 31: return launch_tiled<T, 192, 256, 2, 4, EPI, true, 5>;
+      case 32: return launch_tiled<T, 256, 256, 4, 2, EPI, true, 6>;
+      case 33: return launch_tiled<T, 320, 256, 2, 4, EPI, true, 6>;
+      case 34: return launch_tiled<T, 192, 256, 2, 4, EPI, true, 6>;
       case -2: return launch_naive<T, EPI>;
       default: return nullptr;
     }

@@ -338,7 +338,7 @@ def sec_policy():
     ids_np, mask_np = W.synthetic_ids(cfg, B, 2)
     ids, mask = torch.from_numpy(ids_np).to(dev), torch.from_numpy(mask_np).to(dev)
     model = PlipModel(cfg, sd, dtype="bf16", max_batch=B)
-    pols = [-1, -12, 16, 25, 10]            # -1: cost model / pair policy 1, -12: cost model / pair policy 2 (hybrid)
+    pols = [-1, -12, 25, 33, 34]            # -1: cost model / pair policy 1, -12: cost model / pair policy 2 (hybrid)
     res = {(p, ov): [] for p in pols for ov in (False, True)}
     for rep in range(4):
         for pol in pols:
