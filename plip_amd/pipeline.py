@@ -1,0 +1,77 @@
+"""Host side of ``encode_images``: keep the GPU fed.
+
+The reference's loop (plip.py:41-52) decodes a batch with PIL on the main thread, copies it to the device, runs the
+tower and copies the features back -- every step waits for the previous one; ``CLIPEmbedder`` hides the decode behind
+``DataLoader(num_workers=...)`` worker processes (reproducibility/embedders/plip.py:41-42).  Here:
+
+* items of batch k+1 are decoded / resized by a thread pool (PIL releases the GIL in its C loops) while batch k is
+  on the GPU -- ``num_workers`` keeps the reference's meaning;
+* the prepared batch goes through one of two pinned staging buffers and an H2D copy on a dedicated copy stream, so
+  the transfer of batch k+1 overlaps the towers of batch k (uint8 tiles: 38.5 MB per 256 images, ~0.6 ms on PCIe
+  Gen5; fp32 pixels are 4x that);
+* features stay on the GPU until the end (one D2H copy), instead of one synchronising ``.cpu()`` per batch.
+"""
+from __future__ import annotations
+
+from concurrent.futures import ThreadPoolExecutor
+from typing import Callable, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+
+def _prepare_batch(items: Sequence, prepare_item: Callable, pool: Optional[ThreadPoolExecutor]) -> np.ndarray:
+    arrs = list(pool.map(prepare_item, items)) if pool is not None and len(items) > 1 else [prepare_item(i) for i in items]
+    return np.stack(arrs)
+
+
+def run_batches(items: Sequence, batch_size: int, prepare_item: Callable, consume: Callable[[torch.Tensor], torch.Tensor],
+                device: Optional[torch.device] = None, num_workers: int = 1) -> List[torch.Tensor]:
+    """``consume(batch_on_device)`` for consecutive batches of ``prepare_item(item)`` arrays, order preserved.
+
+    ``device=None`` (CPU-side tests) skips the pinned / copy-stream part and hands host tensors to ``consume``."""
+    n = len(items)
+    if n == 0:
+        return []
+    bounds = [(s, min(s + batch_size, n)) for s in range(0, n, batch_size)]
+    workers = max(0, int(num_workers))
+    pool = ThreadPoolExecutor(max_workers=workers) if workers > 1 else None
+    # one extra single-thread executor runs "prepare batch k+1" concurrently with the GPU work on batch k
+    ahead = ThreadPoolExecutor(max_workers=1)
+    outs: List[torch.Tensor] = []
+    try:
+        fut = ahead.submit(_prepare_batch, items[bounds[0][0]:bounds[0][1]], prepare_item, pool)
+        use_gpu = device is not None and torch.device(device).type == "cuda"
+        if use_gpu:
+            copy_stream = torch.cuda.Stream(device=device)
+            staging = [None, None]
+            copied = [torch.cuda.Event(), torch.cuda.Event()]
+            consumed = [None, None]
+        for k, (lo, hi) in enumerate(bounds):
+            host = fut.result()
+            if k + 1 < len(bounds):
+                nlo, nhi = bounds[k + 1]
+                fut = ahead.submit(_prepare_batch, items[nlo:nhi], prepare_item, pool)
+            if not use_gpu:
+                outs.append(consume(torch.from_numpy(host)))
+                continue
+            slot = k & 1
+            if consumed[slot] is not None:
+                consumed[slot].synchronize()            # the tower that read this slot's device copy has finished
+            if staging[slot] is None or staging[slot].shape != host.shape or staging[slot].dtype != torch.from_numpy(host).dtype:
+                staging[slot] = torch.empty(host.shape, dtype=torch.from_numpy(host).dtype).pin_memory()
+            staging[slot].copy_(torch.from_numpy(host))
+            main = torch.cuda.current_stream(device)
+            with torch.cuda.stream(copy_stream):
+                dev = staging[slot].to(device, non_blocking=True)
+                copied[slot].record(copy_stream)
+            main.wait_event(copied[slot])
+            dev.record_stream(main)
+            outs.append(consume(dev))
+            consumed[slot] = torch.cuda.Event()
+            consumed[slot].record(main)
+    finally:
+        ahead.shutdown(wait=True)
+        if pool is not None:
+            pool.shutdown(wait=True)
+    return outs

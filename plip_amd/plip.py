@@ -60,8 +60,13 @@ class PLIP:
         self.image_vectors = None
 
     # -- plip.py:31-53 -------------------------------------------------------
-    def encode_images(self, images: Union[List[str], list, np.ndarray, torch.Tensor], batch_size: int):
+    def encode_images(self, images: Union[List[str], list, np.ndarray, torch.Tensor], batch_size: int,
+                      num_workers: int = 0):
+        """``num_workers > 0`` (extension): decode / resize with a thread pool and stream batches through pinned
+        double buffers so host work and H2D overlap the towers (plip_amd/pipeline.py); results are identical."""
         n_px = self.model.config.image_size
+        if num_workers > 0 and not torch.is_tensor(images) and not isinstance(images, np.ndarray) and len(images):
+            return self._encode_images_pipelined(list(images), batch_size, num_workers)
         outs = []
         with torch.no_grad():
             for s in range(0, len(images), batch_size):
@@ -79,6 +84,25 @@ class PLIP:
                 outs.append(self.model.get_image_features(pixel_values=px))
         if not outs:
             return np.zeros((0, self.model.config.projection_dim), np.float32)
+        return torch.cat(outs).detach().cpu().numpy()
+
+    def _encode_images_pipelined(self, images: list, batch_size: int, num_workers: int):
+        from .pipeline import run_batches
+        from .preprocess import preprocess_image
+        n_px = self.model.config.image_size
+        eng = self.model.engine
+        native = _native_u8_tiles(images[:1], n_px) is not None and all(
+            (isinstance(im, np.ndarray) and im.dtype == np.uint8 and im.shape == (n_px, n_px, 3)) or
+            (hasattr(im, "size") and hasattr(im, "mode") and im.size == (n_px, n_px)) for im in images)
+        if native:          # raw tiles travel as uint8 (a quarter of the fp32 bytes); normalisation is fused on the GPU
+            prep = lambda im: np.asarray(im.convert("RGB") if hasattr(im, "convert") else im, dtype=np.uint8)
+            consume = lambda t: eng.encode_image_u8(t)
+        else:
+            prep = lambda im: preprocess_image(im, n_px)
+            consume = lambda t: self.model.get_image_features(pixel_values=t)
+        bs = min(int(batch_size), eng.max_batch)
+        with torch.no_grad():
+            outs = run_batches(images, bs, prep, consume, device=eng.device, num_workers=num_workers)
         return torch.cat(outs).detach().cpu().numpy()
 
     # -- plip.py:55-71 ---------------------------------------------------------

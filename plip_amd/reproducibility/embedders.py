@@ -57,6 +57,13 @@ class CLIPEmbedder:
     @torch.no_grad()
     def embed_images(self, list_of_images, device="cuda", num_workers=1, batch_size=32) -> np.ndarray:
         eng = self.model.engine
+        if num_workers and num_workers > 1 and not torch.is_tensor(list_of_images) and not (
+                isinstance(list_of_images, np.ndarray) and list_of_images.dtype != object and list_of_images.ndim == 4):
+            from ..pipeline import run_batches          # decode on a thread pool, H2D on a copy stream
+            step = max(1, min(int(batch_size), eng.max_batch))
+            outs = run_batches(list(list_of_images), step, lambda i: np.asarray(self.preprocess(i), dtype=np.float32),
+                               lambda t: eng.encode_image(t, normalize=True), device=eng.device, num_workers=num_workers)
+            return torch.cat(outs).cpu().numpy() if outs else np.zeros((0, self.model.config.projection_dim), np.float32)
         out = []
         for a, b in self._chunks(len(list_of_images), batch_size):
             items = list_of_images[a:b]

@@ -52,6 +52,25 @@ def test_plip_class_matches_oracle(engines):
     np.testing.assert_array_equal(nn, want_nn)
 
 
+def test_pipelined_encode_images_is_identical(engines):
+    """num_workers > 0: thread-pool decode + pinned double buffers + copy stream must not change a single bit."""
+    from PIL import Image
+    from plip_amd.plip import PLIP
+    from plip_amd.reproducibility import CLIPEmbedder
+    model, cfg, *_ = engines("tiny_b6", "f32")
+    plip = PLIP(model=model, tokenizer=fake_tokenizer(cfg))
+    rs = np.random.RandomState(11)
+    native = [rs.randint(0, 256, size=(cfg.image_size, cfg.image_size, 3), dtype=np.uint8) for _ in range(13)]
+    odd = [Image.fromarray(rs.randint(0, 256, size=(80 + 3 * i, 100, 3), dtype=np.uint8)) for i in range(9)]   # need resize + crop
+    for imgs in (native, [Image.fromarray(t) for t in native], odd):
+        a = plip.encode_images(imgs, batch_size=4)
+        b = plip.encode_images(imgs, batch_size=4, num_workers=3)
+        np.testing.assert_array_equal(a, b)
+    emb = CLIPEmbedder(model)
+    np.testing.assert_array_equal(emb.embed_images(odd, batch_size=4, num_workers=1),
+                                  emb.embed_images(odd, batch_size=4, num_workers=4))
+
+
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_fused_u8_preprocessing_matches_processor_path(dtype, engines):
     """plipmi_encode_image_u8 == CLIPImageProcessor arithmetic on native tiles + plipmi_encode_image."""

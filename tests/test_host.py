@@ -154,3 +154,29 @@ def test_preprocess_matches_hf_image_processor():
     proc = tr.CLIPImageProcessor()
     want = proc(images=Image.fromarray(tile), return_tensors="np")["pixel_values"][0]
     np.testing.assert_allclose(preprocess_image(tile), want, rtol=0, atol=1e-6)
+
+
+def test_host_pipeline_order_and_errors():
+    """plip_amd.pipeline.run_batches: batches arrive in order whatever the decode timing; decode errors propagate."""
+    import time
+    import torch
+    from plip_amd.pipeline import run_batches
+    items = list(range(23))
+
+    def prep(i):
+        time.sleep(0.001 * (i % 3))
+        return np.full((2, 2), i, np.float32)
+
+    for workers in (0, 1, 4):
+        outs = run_batches(items, 5, prep, lambda t: t.sum(dim=(1, 2)), device=None, num_workers=workers)
+        assert [o.shape[0] for o in outs] == [5, 5, 5, 5, 3]
+        assert torch.cat(outs).tolist() == [4.0 * i for i in items]
+    assert run_batches([], 5, prep, lambda t: t) == []
+
+    def bad(i):
+        if i == 7:
+            raise OSError("truncated image")
+        return prep(i)
+
+    with pytest.raises(OSError):
+        run_batches(items, 5, bad, lambda t: t, device=None, num_workers=2)

@@ -32,7 +32,10 @@ VARIANTS = {("128", "128", "0", "0", "0", "2"): "128x128_w2x2_regstage", ("128",
             ("128", "128", "1", "1", "0", "2"): "128x128_w2x2_glds_fragpipe", ("256", "128", "1", "1", "0", "2"): "256x128_w4x2_glds_fragpipe",
             ("256", "256", "1", "3", "0", "2"): "256x256_w4x2_glds_spreadfill", ("128", "128", "1", "3", "0", "2"): "128x128_w2x2_glds_spreadfill",
             ("192", "256", "1", "3", "0", "2"): "192x256_w2x4_glds_spreadfill", ("192", "256", "1", "1", "0", "2"): "192x256_w2x4_glds_fragpipe",
-            ("320", "256", "1", "3", "0", "2"): "320x256_w2x4_glds_spreadfill", ("320", "256", "1", "0", "0", "2"): "320x256_w2x4_glds"}
+            ("320", "256", "1", "3", "0", "2"): "320x256_w2x4_glds_spreadfill", ("320", "256", "1", "0", "0", "2"): "320x256_w2x4_glds",
+            ("256", "256", "1", "5", "0", "2"): "256x256_w4x2_glds_fill2", ("320", "256", "1", "5", "0", "2"): "320x256_w2x4_glds_fill2",
+            ("192", "256", "1", "5", "0", "2"): "192x256_w2x4_glds_fill2", ("256", "256", "1", "6", "0", "2"): "256x256_w4x2_glds_fill3",
+            ("320", "256", "1", "6", "0", "2"): "320x256_w2x4_glds_fill3", ("192", "256", "1", "6", "0", "2"): "192x256_w2x4_glds_fill3"}
 
 
 def main():
