@@ -80,6 +80,26 @@ __device__ __forceinline__ void glds16(const char* gsrc, unsigned lds_wave_base)
       : "v"(gsrc), "s"(lds_wave_base)
       : "memory");
 }
+// The same LDS-DMA through the buffer path: a 128-bit resource descriptor in SGPRs (base, size) plus ONE 32-bit
+// per-lane byte offset instead of a 64-bit per-lane address (ADDR = 1 kernels).
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+__device__ __forceinline__ i32x4 make_buffer_rsrc(const void* base) {
+  const unsigned long long a = (unsigned long long)base;
+  i32x4 r;
+  r[0] = __builtin_amdgcn_readfirstlane((int)(a & 0xffffffffull));
+  r[1] = __builtin_amdgcn_readfirstlane((int)((a >> 32) & 0xffffull));  // stride 0: raw buffer
+  r[2] = -1;                                                              // num_records: whole address range
+  r[3] = 0x00020000;                                                      // gfx9-family raw dword buffer
+  return r;
+}
+__device__ __forceinline__ void glds16_buf(const i32x4 rsrc, unsigned voff, unsigned lds_wave_base) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(rsrc), "s"(lds_wave_base)
+      : "memory");
+}
 __device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // One 16-byte chunk of K per lane -> one (bf16) or four (fp32) MFMAs.
@@ -159,7 +179,7 @@ struct EpilogueOp {
 template <int BM, int BN, int WM, int WN>
 constexpr int gemm_waves_per_simd() { return (WM * WN == 4 && BM * BN >= 256 * 256) ? 1 : 2; }
 
-template <typename T, int BM, int BN, int WM, int WN, int EPI, bool GLDS, int SCHED = 0, int L2PF = 0, int NSTAGE = 2>
+template <typename T, int BM, int BN, int WM, int WN, int EPI, bool GLDS, int SCHED = 0, int L2PF = 0, int NSTAGE = 2, int ADDR = 0>
 __global__ __launch_bounds__(WM* WN * 64)
 __attribute__((amdgpu_waves_per_eu(gemm_waves_per_simd<BM, BN, WM, WN>(), gemm_waves_per_simd<BM, BN, WM, WN>())))
 void gemm_nt_kernel(const GemmParams p) {
@@ -212,6 +232,25 @@ void gemm_nt_kernel(const GemmParams p) {
   }
   const unsigned lds0 =
       __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem);
+  static_assert(ADDR == 0 || (GLDS && L2PF == 0), "buffer addressing is an LDS-DMA form");
+  i32x4 rs_a, rs_w;
+  unsigned a_off[PA], w_off[PW];
+  if constexpr (ADDR == 1) {
+    rs_a = make_buffer_rsrc(p.A);
+    rs_w = make_buffer_rsrc(p.W);
+#pragma unroll
+    for (int i = 0; i < PA; ++i) a_off[i] = (unsigned)(a_src[i] - reinterpret_cast<const char*>(p.A));
+#pragma unroll
+    for (int i = 0; i < PW; ++i) w_off[i] = (unsigned)(w_src[i] - reinterpret_cast<const char*>(p.W));
+  }
+  auto dma_a = [&](int i, unsigned lds) {
+    if constexpr (ADDR == 1) { glds16_buf(rs_a, a_off[i], lds); a_off[i] += 128; }
+    else { glds16(a_src[i], lds); a_src[i] += 128; }
+  };
+  auto dma_w = [&](int i, unsigned lds) {
+    if constexpr (ADDR == 1) { glds16_buf(rs_w, w_off[i], lds); w_off[i] += 128; }
+    else { glds16(w_src[i], lds); w_src[i] += 128; }
+  };
 
   u32x4 ra[GLDS ? 1 : PA], rw[GLDS ? 1 : PW];
 
@@ -219,9 +258,10 @@ void gemm_nt_kernel(const GemmParams p) {
     if constexpr (GLDS) {
       const unsigned base = lds0 + buf * STAGE + wave * 1024;
 #pragma unroll
-      for (int i = 0; i < PA; ++i) glds16(a_src[i], base + i * NT * 16);
+      for (int i = 0; i < PA; ++i) dma_a(i, base + i * NT * 16);
 #pragma unroll
-      for (int i = 0; i < PW; ++i) glds16(w_src[i], base + A_BYTES + i * NT * 16);
+      for (int i = 0; i < PW; ++i) dma_w(i, base + A_BYTES + i * NT * 16);
+      return;
     } else {
 #pragma unroll
       for (int i = 0; i < PA; ++i) ra[i] = *reinterpret_cast<const u32x4*>(a_src[i]);
@@ -247,8 +287,8 @@ void gemm_nt_kernel(const GemmParams p) {
 #pragma unroll
     for (int e = 0; e < PER; ++e) {
       const int idx = part * PER + e;  // compile-time after unrolling
-      if (idx < PA) { glds16(a_src[idx], base + idx * NT * 16); a_src[idx] += 128; }
-      else if (idx < PA + PW) { glds16(w_src[idx - PA], base + A_BYTES + (idx - PA) * NT * 16); w_src[idx - PA] += 128; }
+      if (idx < PA) dma_a(idx, base + idx * NT * 16);
+      else if (idx < PA + PW) dma_w(idx - PA, base + A_BYTES + (idx - PA) * NT * 16);
     }
   };
   auto stage_commit = [&](int buf) {  // make the staged tile visible in LDS buffer `buf`

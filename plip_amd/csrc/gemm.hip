@@ -28,6 +28,10 @@ static const GemmVariant kVariants[kNumVariants] = {
     {"192x256_w2x4_glds_fill2", 192, 256, 512, true},
     {"256x256_w4x2_glds_fill3", 256, 256, 512, true}, {"320x256_w2x4_glds_fill3", 320, 256, 512, true},
     {"192x256_w2x4_glds_fill3", 192, 256, 512, true},
+    {"256x256_w4x2_bufdma_fill3", 256, 256, 512, true}, {"320x256_w2x4_bufdma_fill3", 320, 256, 512, true},
+    {"192x256_w2x4_bufdma_fill3", 192, 256, 512, true},
+    {"256x256_w4x2_bufdma_fragpipe", 256, 256, 512, true}, {"320x256_w2x4_bufdma", 320, 256, 512, true},
+    {"192x256_w2x4_bufdma_fragpipe", 192, 256, 512, true}, {"128x128_w2x2_bufdma_fragpipe", 128, 128, 256, true},
 };
 
 int gemm_num_cus() {
@@ -70,16 +74,16 @@ int gemm_default_variant(int dtype, int M, int N, int K, int epi) {
   // Policy 1 = the two towers are co-scheduled on two streams: CUs a partial round would leave idle are taken by
   // the other tower's kernels, so quantisation stops mattering and the tile with the fewest L2->LDS bytes per FLOP
   // wins (in-process A/B, profiles/r01_gemm_policy_ab.txt: 5.69 ms/step vs 6.04 ms with the cost model).
-  if (g_policy == 1 && dtype == 1 && N % 256 == 0) return 33;
+  if (g_policy == 1 && dtype == 1 && N % 256 == 0) return 36;
   // Policy 2: as 1, but the fp32 residual epilogues take the 192x256 tile, whose register budget lets it request the
   // residual rows one block ahead (gemm.h kRowOperand).
-  if (g_policy == 2 && dtype == 1 && N % 256 == 0) return (epi == EPI_BIAS_RESID || epi == EPI_PATCH) ? 34 : 33;
+  if (g_policy == 2 && dtype == 1 && N % 256 == 0) return (epi == EPI_BIAS_RESID || epi == EPI_PATCH) ? 37 : 36;
   const int cus = gemm_num_cus();
   struct Cand { int variant, bm, bn, per_cu; double rel; };
-  const Cand cands_bf16[] = {{16, 256, 256, 1, 1.00}, {33, 320, 256, 1, 1.00}, {34, 192, 256, 1, 1.05}, {8, 128, 128, 2, 1.21}};
-  const Cand cands_f32[] = {{6, 256, 256, 1, 1.00}, {26, 320, 256, 1, 1.00}, {24, 192, 256, 1, 1.05}, {8, 128, 128, 2, 1.21}};
+  const Cand cands_bf16[] = {{35, 256, 256, 1, 1.00}, {36, 320, 256, 1, 1.00}, {37, 192, 256, 1, 1.05}, {41, 128, 128, 2, 1.21}};
+  const Cand cands_f32[] = {{38, 256, 256, 1, 1.00}, {39, 320, 256, 1, 1.00}, {40, 192, 256, 1, 1.05}, {41, 128, 128, 2, 1.21}};
   const Cand* cands = dtype == 1 ? cands_bf16 : cands_f32;
-  int best = 8;
+  int best = 41;
   double best_cost = 1e300;
   for (int i = 0; i < 4; ++i) {
     const Cand& c = cands[i];

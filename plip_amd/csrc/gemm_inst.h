@@ -9,11 +9,11 @@ namespace plipmi {
 
 typedef int (*GemmLaunchFn)(const GemmParams&, hipStream_t);
 
-template <typename T, int BM, int BN, int WM, int WN, int EPI, bool GLDS, int SCHED = 0, int L2PF = 0, int NSTAGE = 2>
+template <typename T, int BM, int BN, int WM, int WN, int EPI, bool GLDS, int SCHED = 0, int L2PF = 0, int NSTAGE = 2, int ADDR = 0>
 int launch_tiled(const GemmParams& p, hipStream_t stream) {
   constexpr int NT = WM * WN * 64;
   constexpr int LDS = NSTAGE * (BM + BN) * 128;
-  auto kern = gemm_nt_kernel<T, BM, BN, WM, WN, EPI, GLDS, SCHED, L2PF, NSTAGE>;
+  auto kern = gemm_nt_kernel<T, BM, BN, WM, WN, EPI, GLDS, SCHED, L2PF, NSTAGE, ADDR>;
   static bool attr_set = false;  // one handle per process; set once per instantiation
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -70,7 +70,7 @@ int launch_naive(const GemmParams& p, hipStream_t stream) {
   return (int)hipGetLastError();
 }
 
-constexpr int kNumVariants = 35;
+constexpr int kNumVariants = 42;
 
 // table[variant][epilogue]
 template <typename T>
@@ -113,6 +113,13 @@ struct GemmTable {
       case 32: return launch_tiled<T, 256, 256, 4, 2, EPI, true, 6>;
       case 33: return launch_tiled<T, 320, 256, 2, 4, EPI, true, 6>;
       case 34: return launch_tiled<T, 192, 256, 2, 4, EPI, true, 6>;
+      case 35: return launch_tiled<T, 256, 256, 4, 2, EPI, true, 6, 0, 2, 1>;
+      case 36: return launch_tiled<T, 320, 256, 2, 4, EPI, true, 6, 0, 2, 1>;
+      case 37: return launch_tiled<T, 192, 256, 2, 4, EPI, true, 6, 0, 2, 1>;
+      case 38: return launch_tiled<T, 256, 256, 4, 2, EPI, true, 1, 0, 2, 1>;
+      case 39: return launch_tiled<T, 320, 256, 2, 4, EPI, true, 0, 0, 2, 1>;
+      case 40: return launch_tiled<T, 192, 256, 2, 4, EPI, true, 1, 0, 2, 1>;
+      case 41: return launch_tiled<T, 128, 128, 2, 2, EPI, true, 1, 0, 2, 1>;
       case -2: return launch_naive<T, EPI>;
       default: return nullptr;
     }

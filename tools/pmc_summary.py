@@ -16,14 +16,17 @@ EPI = {"0": "bias", "1": "bias_qgelu", "2": "bias_resid", "3": "scale", "4": "pa
 
 
 def pretty(sym, variants):
-    m = re.search(r"gemm_nt_kernelI(DF16b|f)Li(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELb([01])(?:ELi(\d+))?(?:ELi(\d+))?(?:ELi(\d+))?", sym)
+    m = re.search(r"gemm_nt_kernelI(DF16b|f)Li(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELb([01])(?:ELi(\d+))?(?:ELi(\d+))?(?:ELi(\d+))?(?:ELi(\d+))?", sym)
     if not m:
         return sym
     dt = "bf16" if m.group(1) == "DF16b" else "f32"
     bm, bn, wm, wn, epi, glds = m.group(2), m.group(3), m.group(4), m.group(5), m.group(6), m.group(7)
     sched, l2pf, nst = m.group(8) or "0", m.group(9) or "0", m.group(10) or "2"
+    addr = m.group(11) or "0"
     key = (bm, bn, glds, sched, l2pf, nst)
     tile = variants.get(key, f"{bm}x{bn}_w{wm}x{wn}_g{glds}s{sched}p{l2pf}n{nst}")
+    if addr == "1":
+        tile = tile.replace("_glds", "_bufdma")
     return f"gemm_nt<{dt},{tile},{EPI.get(epi, epi)}>"
 
 
