@@ -26,6 +26,7 @@
 //     XCDs, so block b is given logical tile (b%8)*ceil(n/8)+b/8 (bijective form)
 //     and each XCD's private L2 sees a contiguous strip of M tiles sweeping N.
 #pragma once
+#include <type_traits>
 #include "common.h"
 
 namespace plipmi {
@@ -92,13 +93,55 @@ __device__ __forceinline__ i32x4 make_buffer_rsrc(const void* base) {
   r[3] = 0x00020000;                                                      // gfx9-family raw dword buffer
   return r;
 }
-__device__ __forceinline__ void glds16_buf(const i32x4 rsrc, unsigned voff, unsigned lds_wave_base) {
+// soff: wave-uniform byte offset (the K position) in an SGPR -- the per-lane offsets never change inside the K loop
+__device__ __forceinline__ void glds16_buf(const i32x4 rsrc, unsigned voff, unsigned soff, unsigned lds_wave_base) {
   unsigned keep;
   asm volatile(
-      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
       : "=&s"(keep)
-      : "v"(voff), "s"(rsrc), "s"(lds_wave_base)
+      : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_wave_base)
       : "memory");
+}
+// N pieces under ONE M0 save/restore; the LDS destination of piece e is lds_base + OFFe (compile-time), formed by
+// the s_add that writes M0.  Operand order per piece: resource, lane offset.
+template <int N, int OFF0, int OFF1 = 0, int OFF2 = 0, int OFF3 = 0>
+__device__ __forceinline__ void glds16_buf_n(unsigned lds_base, unsigned soff, const i32x4 r0, unsigned v0,
+                                             const i32x4 r1, unsigned v1, const i32x4 r2, unsigned v2,
+                                             const i32x4 r3, unsigned v3) {
+  unsigned keep;
+  if constexpr (N == 1) {
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_add_u32 m0, %1, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %2, %5 offen lds\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_base), "s"(r0), "v"(v0), "i"(OFF0), "s"(soff) : "memory", "scc");
+  } else if constexpr (N == 2) {
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_add_u32 m0, %1, %6\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %2, %8 offen lds\n\t"
+                 "s_add_u32 m0, %1, %7\n\ts_nop 0\n\tbuffer_load_dwordx4 %5, %4, %8 offen lds\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_base), "s"(r0), "v"(v0), "s"(r1), "v"(v1), "i"(OFF0), "i"(OFF1), "s"(soff)
+                 : "memory", "scc");
+  } else if constexpr (N == 3) {
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_add_u32 m0, %1, %8\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %2, %11 offen lds\n\t"
+                 "s_add_u32 m0, %1, %9\n\ts_nop 0\n\tbuffer_load_dwordx4 %5, %4, %11 offen lds\n\t"
+                 "s_add_u32 m0, %1, %10\n\ts_nop 0\n\tbuffer_load_dwordx4 %7, %6, %11 offen lds\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "s"(lds_base), "s"(r0), "v"(v0), "s"(r1), "v"(v1), "s"(r2), "v"(v2), "i"(OFF0), "i"(OFF1), "i"(OFF2), "s"(soff)
+                 : "memory", "scc");
+  } else {
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_add_u32 m0, %1, %10\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %2, %14 offen lds\n\t"
+                 "s_add_u32 m0, %1, %11\n\ts_nop 0\n\tbuffer_load_dwordx4 %5, %4, %14 offen lds\n\t"
+                 "s_add_u32 m0, %1, %12\n\ts_nop 0\n\tbuffer_load_dwordx4 %7, %6, %14 offen lds\n\t"
+                 "s_add_u32 m0, %1, %13\n\ts_nop 0\n\tbuffer_load_dwordx4 %9, %8, %14 offen lds\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "s"(lds_base), "s"(r0), "v"(v0), "s"(r1), "v"(v1), "s"(r2), "v"(v2), "s"(r3), "v"(v3), "i"(OFF0), "i"(OFF1),
+                   "i"(OFF2), "i"(OFF3), "s"(soff)
+                 : "memory", "scc");
+  }
 }
 __device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
@@ -243,13 +286,15 @@ void gemm_nt_kernel(const GemmParams p) {
 #pragma unroll
     for (int i = 0; i < PW; ++i) w_off[i] = (unsigned)(w_src[i] - reinterpret_cast<const char*>(p.W));
   }
+  unsigned koff = 0;  // ADDR 1: K byte offset of the tile being fetched (SGPR); advanced when its last piece is out
   auto dma_a = [&](int i, unsigned lds) {
-    if constexpr (ADDR == 1) { glds16_buf(rs_a, a_off[i], lds); a_off[i] += 128; }
+    if constexpr (ADDR == 1) glds16_buf(rs_a, a_off[i], koff, lds);
     else { glds16(a_src[i], lds); a_src[i] += 128; }
   };
   auto dma_w = [&](int i, unsigned lds) {
-    if constexpr (ADDR == 1) { glds16_buf(rs_w, w_off[i], lds); w_off[i] += 128; }
+    if constexpr (ADDR == 1) glds16_buf(rs_w, w_off[i], koff, lds);
     else { glds16(w_src[i], lds); w_src[i] += 128; }
+    if constexpr (ADDR == 1) { if (i == PW - 1) koff += 128; }  // W pieces follow the A pieces: PW-1 is a tile's last
   };
 
   u32x4 ra[GLDS ? 1 : PA], rw[GLDS ? 1 : PW];
@@ -284,6 +329,28 @@ void gemm_nt_kernel(const GemmParams p) {
   auto stage_issue_part = [&](int buf, int part) {
     constexpr int PER = (PA + PW + kFillParts - 1) / kFillParts;
     const unsigned base = lds0 + buf * STAGE + wave * 1024;
+    if constexpr (ADDR == 1) {
+      // piece idx of the tile: resource, lane offset and (compile-time) LDS offset
+      auto RS = [&](int idx) -> const i32x4& { return idx < PA ? rs_a : rs_w; };
+      auto VO = [&](int idx) { return idx < PA ? a_off[idx < PA ? idx : 0] : w_off[idx - PA < PW ? (idx >= PA ? idx - PA : 0) : 0]; };
+      constexpr auto LO = [](int idx) constexpr { return idx < PA ? idx * NT * 16 : A_BYTES + (idx - PA) * NT * 16; };
+      auto go = [&](auto part_c) {
+        constexpr int P0 = decltype(part_c)::value * PER;
+        constexpr int N = (P0 + PER <= PA + PW) ? PER : (PA + PW - P0 > 0 ? PA + PW - P0 : 0);
+        if constexpr (N > 0) {
+          constexpr int I0 = P0, I1 = P0 + (N > 1 ? 1 : 0), I2 = P0 + (N > 2 ? 2 : 0), I3 = P0 + (N > 3 ? 3 : 0);
+          glds16_buf_n<N, LO(I0), LO(I1), LO(I2), LO(I3)>(base, koff, RS(I0), VO(I0), RS(I1), VO(I1), RS(I2), VO(I2),
+                                                            RS(I3), VO(I3));
+          if constexpr (P0 + N == PA + PW) koff += 128;
+        }
+      };
+      static_assert(PER <= 4, "glds16_buf_n batches at most four pieces");
+      if (part == 0) go(std::integral_constant<int, 0>{});
+      else if (part == 1) go(std::integral_constant<int, 1>{});
+      else if (part == 2) go(std::integral_constant<int, 2>{});
+      else go(std::integral_constant<int, 3>{});
+      return;
+    }
 #pragma unroll
     for (int e = 0; e < PER; ++e) {
       const int idx = part * PER + e;  // compile-time after unrolling
