@@ -12,6 +12,7 @@
  *   plipmi_encode_image   <- self.model.get_image_features(**batch)           plip.py:50
  *                            self.model.encode_image(images)                  reproducibility/embedders/plip.py:48
  *   plipmi_encode_image_u8<- self.preprocess(images=...) + get_image_features           plip.py:32-35,50
+ *   plipmi_resize_crop_u8 <- Resize(n_px, bicubic) + CenterCrop(n_px)                  reproducibility/embedders/transform.py:45-48
  *   plipmi_encode_text    <- self.model.get_text_features(**batch)            plip.py:68
  *                            self.model.encode_text(clip.tokenize(...))       reproducibility/embedders/plip.py:65-66
  *   plipmi_l2_normalize   <- x / np.linalg.norm(x, axis=-1, keepdims=True)    plip.py:75, embedders/plip.py:53,73
@@ -154,6 +155,18 @@ int plipmi_logits(plipmi_handle h, const float* img, int Ni, const float* txt, i
 /* top-k columns of each row of scores [N,M], descending (ties: lower index first);
  * idx int64 [N,k].  Replaces argsort()[:, -k:][:, ::-1] (plip.py:84). */
 int plipmi_topk(plipmi_handle h, const float* scores, int N, int M, int k, int64_t* idx, void* stream);
+
+/* Resize (Pillow-exact 8-bit bicubic) + centre crop on the GPU, the step in front of plipmi_encode_image_u8:
+ * replaces the host-side `_transform` Resize/CenterCrop (reproducibility/embedders/transform.py:45-48) and the
+ * CLIPImageProcessor resize + center_crop behind `self.preprocess(images=...)` (plip.py:32-35) for batches of
+ * equally sized uint8 HWC images.  src [B,H,W,3] -> dst [B,n_px,n_px,3], bit-identical to
+ * Image.resize((nw,nh), BICUBIC).crop(...).  The caller supplies Pillow's fixed-point tables restricted to the crop
+ * window (plip_amd/preprocess.py:resize_crop_plan): x/ybounds int32 [n_px,2] = (first input index, taps),
+ * x/ycoef int32 [n_px,ksize]; a NULL pair means that axis already has the right size (crop only, at left/top).
+ * tmp [B,nrows,n_px,3] holds source rows row0..row0+nrows after the horizontal pass. */
+int plipmi_resize_crop_u8(plipmi_handle h, const uint8_t* src, int B, int H, int W, int n_px, const int32_t* xbounds,
+                          const int32_t* xcoef, int xksize, int left, const int32_t* ybounds, const int32_t* ycoef,
+                          int yksize, int top, int row0, int nrows, uint8_t* tmp, uint8_t* dst, void* stream);
 
 /* Fused similarity + top-k: for every row q of keys [Nq,D] the k rows j of space [Ns,D] with the largest <q, space_j>,
  * descending (ties: lower j first), WITHOUT materialising the [Nq,Ns] score matrix: scores are produced in

@@ -56,6 +56,7 @@ SYMBOLS = {
     "plipmi_l2_normalize": (_i, [_vp, _vp, _i, _i, _vp]),
     "plipmi_logits": (_i, [_vp, _vp, _i, _vp, _i, _i, _f, _vp, _vp, _vp, _vp]),
     "plipmi_topk": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "plipmi_resize_crop_u8": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "plipmi_similarity_topk": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "plipmi_debug_hidden": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp]),
     "plipmi_gemm_nt": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _f, _vp, _vp]),

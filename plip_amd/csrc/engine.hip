@@ -463,6 +463,24 @@ int plipmi_topk(plipmi_handle h, const float* scores, int N, int M, int k, int64
   return PLIPMI_OK;
 }
 
+int plipmi_resize_crop_u8(plipmi_handle h, const uint8_t* src, int B, int H, int W, int n_px, const int32_t* xbounds,
+                          const int32_t* xcoef, int xksize, int left, const int32_t* ybounds, const int32_t* ycoef,
+                          int yksize, int top, int row0, int nrows, uint8_t* tmp, uint8_t* dst, void* stream) {
+  if (!h || B < 0 || H <= 0 || W <= 0 || n_px <= 0) return fail(PLIPMI_ERR_INVALID, "bad argument");
+  if (B == 0) return PLIPMI_OK;
+  if (!src || !tmp || !dst) return fail(PLIPMI_ERR_INVALID, "null src/tmp/dst");
+  if ((xbounds == nullptr) != (xcoef == nullptr) || (ybounds == nullptr) != (ycoef == nullptr))
+    return fail(PLIPMI_ERR_INVALID, "bounds and coefficients come in pairs");
+  if (row0 < 0 || nrows <= 0 || row0 + nrows > H) return fail(PLIPMI_ERR_INVALID, "rows [%d, %d) outside the %d-row image", row0, row0 + nrows, H);
+  if (!xbounds && (left < 0 || left + n_px > W)) return fail(PLIPMI_ERR_INVALID, "crop columns outside the image");
+  if (!ybounds && (top < row0 || top + n_px > row0 + nrows)) return fail(PLIPMI_ERR_INVALID, "crop rows outside the staged rows");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  Scope sc(h, s, "resize_crop_u8", 0, (double)B * ((double)nrows * W * 3 + 2.0 * nrows * n_px * 3 + (double)n_px * n_px * 3));
+  HIP_TRY(launch_resize_crop_u8(src, B, H, W, n_px, xbounds, xcoef, xksize, left, ybounds, ycoef, yksize, top, row0, nrows,
+                                tmp, dst, s));
+  return PLIPMI_OK;
+}
+
 int plipmi_similarity_topk(plipmi_handle h, const float* keys, int Nq, const float* space, int Ns, int D, int k,
                            int64_t* idx, float* vals, void* stream) {
   if (!h || Nq < 0 || Ns <= 0 || D <= 0) return fail(PLIPMI_ERR_INVALID, "bad argument");

@@ -54,6 +54,12 @@ hipError_t launch_topk_merge(const float* scores, size_t ld, int rows, int ncols
                              int64_t* idx, hipStream_t s);
 hipError_t launch_topk_finish(int64_t* idx, size_t n, hipStream_t s);
 
+// Pillow-exact 8-bit bicubic resize + centre crop of uint8 HWC images (tables from plip_amd/preprocess.py):
+// src [B,H,W,3] -> tmp [B,R,n,3] (rows r0..r0+R of the source, horizontally resampled) -> dst [B,n,n,3]
+hipError_t launch_resize_crop_u8(const uint8_t* src, int B, int H, int W, int n, const int* xb, const int* xk, int xks,
+                                 int left, const int* yb, const int* yk, int yks, int top, int r0, int R,
+                                 uint8_t* tmp, uint8_t* dst, hipStream_t s);
+
 // dst[r, 0:cols] = (T)(scale * src[r, 0:cols]), dst[r, cols:dst_ld] = 0   (weight packing)
 hipError_t launch_convert(const float* src, void* dst, int dst_dtype, int rows, int cols, int dst_ld, float scale,
                           hipStream_t s);

@@ -618,6 +618,76 @@ hipError_t launch_topk_merge(const float* scores, size_t ld, int rows, int ncols
 }
 
 // ---------------------------------------------------------------------------------
+// Resize (8-bit bicubic, Pillow's integer arithmetic) + centre crop on uint8 HWC images: the step in front of
+// plipmi_encode_image_u8 (transform.py:45-52 / CLIPImageProcessor resize + center_crop).  The coefficient tables
+// come from the host (plip_amd/preprocess.py, float64 exactly as Pillow builds them); both passes are int32
+// accumulations from 2^21 with an arithmetic shift by 22 and a clamp, horizontal first, uint8 in between --
+// bit-identical to Image.resize(BICUBIC).crop(...).  Only the crop window is computed.
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ uint8_t clip8_fixed(int acc) {
+  const int v = acc >> 22;
+  return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+}
+__global__ __launch_bounds__(256) void resize_h_kernel(const uint8_t* __restrict__ src, int H, int W,
+                                                       const int* __restrict__ xb, const int* __restrict__ xk, int ks,
+                                                       int left, int r0, int R, int n, uint8_t* __restrict__ tmp,
+                                                       size_t total) {
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int x = (int)(idx % n);
+    const size_t t = idx / n;
+    const int y = (int)(t % R);
+    const size_t b = t / R;
+    const uint8_t* row = src + ((b * H + r0 + y) * (size_t)W) * 3;
+    uint8_t* o = tmp + idx * 3;
+    if (xb == nullptr) {  // width already right: this pass is only the crop
+      const uint8_t* px = row + (size_t)(left + x) * 3;
+      o[0] = px[0]; o[1] = px[1]; o[2] = px[2];
+      continue;
+    }
+    const int x0 = xb[2 * x], cnt = xb[2 * x + 1];
+    const int* k = xk + (size_t)x * ks;
+    int a0 = 1 << 21, a1 = 1 << 21, a2 = 1 << 21;
+    const uint8_t* px = row + (size_t)x0 * 3;
+    for (int i = 0; i < cnt; ++i) {
+      const int w = k[i];
+      a0 += px[3 * i + 0] * w; a1 += px[3 * i + 1] * w; a2 += px[3 * i + 2] * w;
+    }
+    o[0] = clip8_fixed(a0); o[1] = clip8_fixed(a1); o[2] = clip8_fixed(a2);
+  }
+}
+__global__ __launch_bounds__(256) void resize_v_kernel(const uint8_t* __restrict__ tmp, int R, int n,
+                                                       const int* __restrict__ yb, const int* __restrict__ yk, int ks,
+                                                       int r0, int top, uint8_t* __restrict__ dst, size_t total) {
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int xc = (int)(idx % (n * 3));  // (x, channel) flattened: rows of tmp are n*3 contiguous bytes
+    const size_t t = idx / (n * 3);
+    const int y = (int)(t % n);
+    const size_t b = t / n;
+    const uint8_t* img = tmp + b * (size_t)R * n * 3;
+    if (yb == nullptr) {
+      dst[idx] = img[(size_t)(top + y - r0) * n * 3 + xc];
+      continue;
+    }
+    const int y0 = yb[2 * y] - r0, cnt = yb[2 * y + 1];
+    const int* k = yk + (size_t)y * ks;
+    int a = 1 << 21;
+    for (int i = 0; i < cnt; ++i) a += img[(size_t)(y0 + i) * n * 3 + xc] * k[i];
+    dst[idx] = clip8_fixed(a);
+  }
+}
+hipError_t launch_resize_crop_u8(const uint8_t* src, int B, int H, int W, int n, const int* xb, const int* xk, int xks,
+                                 int left, const int* yb, const int* yk, int yks, int top, int r0, int R,
+                                 uint8_t* tmp, uint8_t* dst, hipStream_t s) {
+  if (B <= 0) return hipSuccess;
+  const size_t th = (size_t)B * R * n, tv = (size_t)B * n * n * 3;
+  const int gh = (int)((th + 255) / 256 < 65536 ? (th + 255) / 256 : 65536);
+  const int gv = (int)((tv + 255) / 256 < 65536 ? (tv + 255) / 256 : 65536);
+  hipLaunchKernelGGL(resize_h_kernel, dim3(gh), dim3(256), 0, s, src, H, W, xb, xk, xks, left, r0, R, n, tmp, th);
+  hipLaunchKernelGGL(resize_v_kernel, dim3(gv), dim3(256), 0, s, tmp, R, n, yb, yk, yks, r0, top, dst, tv);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------
 // weight packing (plipmi_create)
 // ---------------------------------------------------------------------------------
 template <typename T>

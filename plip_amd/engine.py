@@ -216,6 +216,36 @@ class Engine:
                                             self._stream()), "plipmi_topk")
         return idx
 
+    def resize_crop_u8(self, images_u8: torch.Tensor) -> torch.Tensor:
+        """uint8 [B,H,W,3] images of one size -> uint8 [B,n,n,3] tiles at the model resolution: Pillow-exact bicubic
+        resize (shortest edge -> n) + centre crop on the GPU; feed the result to :meth:`encode_image_u8`."""
+        from .preprocess import resize_crop_plan
+        n = self.cfg.image_size
+        if images_u8.dim() != 4 or images_u8.shape[-1] != 3 or images_u8.dtype != torch.uint8:
+            raise ValueError("expected uint8 [B,H,W,3]")
+        B, H, Wd = int(images_u8.shape[0]), int(images_u8.shape[1]), int(images_u8.shape[2])
+        cache = self.__dict__.setdefault("_resize_plans", {})
+        if (Wd, H) not in cache:
+            plan = resize_crop_plan(Wd, H, n)
+            dev = {k: (None if plan[k] is None else torch.from_numpy(plan[k]).to(self.device)) for k in ("xb", "xk", "yb", "yk")}
+            if plan["yb"] is not None:
+                r0 = int(plan["yb"][:, 0].min())
+                r1 = int((plan["yb"][:, 0] + plan["yb"][:, 1]).max())
+            else:
+                r0, r1 = plan["top"], plan["top"] + n
+            cache[(Wd, H)] = (plan, dev, r0, r1 - r0)
+        plan, dev, r0, R = cache[(Wd, H)]
+        with torch.cuda.device(self.device):
+            src = images_u8.to(self.device).contiguous()
+            tmp = torch.empty((B, R, n, 3), dtype=torch.uint8, device=self.device)
+            dst = torch.empty((B, n, n, 3), dtype=torch.uint8, device=self.device)
+            _lib.check(self.lib.plipmi_resize_crop_u8(
+                self._h, _ptr(src), B, H, Wd, n, _ptr(dev["xb"]), _ptr(dev["xk"]),
+                0 if plan["xk"] is None else plan["xk"].shape[1], plan["left"], _ptr(dev["yb"]), _ptr(dev["yk"]),
+                0 if plan["yk"] is None else plan["yk"].shape[1], plan["top"], r0, R, _ptr(tmp), _ptr(dst),
+                self._stream()), "plipmi_resize_crop_u8")
+        return dst
+
     def similarity_topk(self, keys: torch.Tensor, space: torch.Tensor, k: int, return_values: bool = False):
         """Top-k rows of ``space`` by dot product for every row of ``keys`` -- ``(keys @ space.T).argsort()[:, -k:][:, ::-1]``
         (plip.py:83-84, retrieval.py:13-16) without the [Nq, Ns] matrix: scores exist only as [<=4096, <=8192] panels."""

@@ -25,10 +25,13 @@ def _prepare_batch(items: Sequence, prepare_item: Callable, pool: Optional[Threa
     return np.stack(arrs)
 
 
-def run_batches(items: Sequence, batch_size: int, prepare_item: Callable, consume: Callable[[torch.Tensor], torch.Tensor],
-                device: Optional[torch.device] = None, num_workers: int = 1) -> List[torch.Tensor]:
+def run_batches(items: Sequence, batch_size: int, prepare_item: Optional[Callable], consume: Callable,
+                device: Optional[torch.device] = None, num_workers: int = 1,
+                prepare_batch: Optional[Callable] = None) -> List[torch.Tensor]:
     """``consume(batch_on_device)`` for consecutive batches of ``prepare_item(item)`` arrays, order preserved.
 
+    With ``prepare_batch(items, pool) -> (tag, ndarray)`` the caller prepares whole batches (and may route them:
+    raw tiles / to-be-resized images / host-preprocessed pixels) and ``consume(tag, batch_on_device)`` gets the tag.
     ``device=None`` (CPU-side tests) skips the pinned / copy-stream part and hands host tensors to ``consume``."""
     n = len(items)
     if n == 0:
@@ -39,8 +42,16 @@ def run_batches(items: Sequence, batch_size: int, prepare_item: Callable, consum
     # one extra single-thread executor runs "prepare batch k+1" concurrently with the GPU work on batch k
     ahead = ThreadPoolExecutor(max_workers=1)
     outs: List[torch.Tensor] = []
+    if prepare_batch is not None:
+        prep = lambda chunk: prepare_batch(chunk, pool)
+        eat = lambda tagged, t: consume(tagged[0], t)
+        arr = lambda tagged: tagged[1]
+    else:
+        prep = lambda chunk: _prepare_batch(chunk, prepare_item, pool)
+        eat = lambda host, t: consume(t)
+        arr = lambda host: host
     try:
-        fut = ahead.submit(_prepare_batch, items[bounds[0][0]:bounds[0][1]], prepare_item, pool)
+        fut = ahead.submit(prep, items[bounds[0][0]:bounds[0][1]])
         use_gpu = device is not None and torch.device(device).type == "cuda"
         if use_gpu:
             copy_stream = torch.cuda.Stream(device=device)
@@ -48,12 +59,13 @@ def run_batches(items: Sequence, batch_size: int, prepare_item: Callable, consum
             copied = [torch.cuda.Event(), torch.cuda.Event()]
             consumed = [None, None]
         for k, (lo, hi) in enumerate(bounds):
-            host = fut.result()
+            prepared = fut.result()
+            host = arr(prepared)
             if k + 1 < len(bounds):
                 nlo, nhi = bounds[k + 1]
-                fut = ahead.submit(_prepare_batch, items[nlo:nhi], prepare_item, pool)
+                fut = ahead.submit(prep, items[nlo:nhi])
             if not use_gpu:
-                outs.append(consume(torch.from_numpy(host)))
+                outs.append(eat(prepared, torch.from_numpy(host)))
                 continue
             slot = k & 1
             if consumed[slot] is not None:
@@ -67,7 +79,7 @@ def run_batches(items: Sequence, batch_size: int, prepare_item: Callable, consum
                 copied[slot].record(copy_stream)
             main.wait_event(copied[slot])
             dev.record_stream(main)
-            outs.append(consume(dev))
+            outs.append(eat(prepared, dev))
             consumed[slot] = torch.cuda.Event()
             consumed[slot].record(main)
     finally:

@@ -40,6 +40,26 @@ def _native_u8_tiles(chunk, n_px):
     return np.stack(arrs) if arrs else None
 
 
+def _uniform_u8_images(chunk, n_px):
+    """Equally sized uint8 RGB images (arrays or PIL) that still need resize/crop -> one [B,H,W,3] array, else None."""
+    if torch.is_tensor(chunk) or isinstance(chunk, np.ndarray) or len(chunk) == 0:
+        return None
+    arrs, shape = [], None
+    for im in chunk:
+        if isinstance(im, np.ndarray) and im.dtype == np.uint8 and im.ndim == 3 and im.shape[2] == 3:
+            a = im
+        elif hasattr(im, "size") and hasattr(im, "mode") and not isinstance(im, str):      # PIL image
+            a = np.asarray(im.convert("RGB"), dtype=np.uint8)
+        else:
+            return None
+        if shape is None:
+            shape = a.shape
+        if a.shape != shape or min(a.shape[:2]) < 8:
+            return None
+        arrs.append(a)
+    return np.stack(arrs)
+
+
 class PLIP:
     def __init__(self, model_name: str = None, auth_token=None, *, model: Optional[PlipModel] = None,
                  tokenizer: Optional[Callable] = None, dtype: str = "bf16", max_batch: int = 256,
@@ -71,9 +91,17 @@ class PLIP:
         with torch.no_grad():
             for s in range(0, len(images), batch_size):
                 chunk = images[s:s + batch_size]
+                if isinstance(chunk, (list, tuple)) and any(isinstance(c, str) for c in chunk):
+                    from PIL import Image                                  # plip.py:34 opens the paths of a batch
+                    chunk = [Image.open(c) if isinstance(c, str) else c for c in chunk]
                 tiles = _native_u8_tiles(chunk, n_px)
                 if tiles is not None:      # already n_px x n_px uint8: normalise on the GPU, fused into the unfold
                     outs.append(self.model.engine.encode_image_u8(torch.from_numpy(tiles)))
+                    continue
+                same = _uniform_u8_images(chunk, n_px)
+                if same is not None:       # one size, not the model's: Pillow-exact resize + crop on the GPU as well
+                    eng = self.model.engine
+                    outs.append(eng.encode_image_u8(eng.resize_crop_u8(torch.from_numpy(same))))
                     continue
                 if torch.is_tensor(chunk):
                     px = chunk
@@ -87,22 +115,42 @@ class PLIP:
         return torch.cat(outs).detach().cpu().numpy()
 
     def _encode_images_pipelined(self, images: list, batch_size: int, num_workers: int):
+        """Same routing per batch as the loop above (raw tiles / GPU resize / host Pillow), one batch ahead."""
         from .pipeline import run_batches
         from .preprocess import preprocess_image
         n_px = self.model.config.image_size
         eng = self.model.engine
-        native = _native_u8_tiles(images[:1], n_px) is not None and all(
-            (isinstance(im, np.ndarray) and im.dtype == np.uint8 and im.shape == (n_px, n_px, 3)) or
-            (hasattr(im, "size") and hasattr(im, "mode") and im.size == (n_px, n_px)) for im in images)
-        if native:          # raw tiles travel as uint8 (a quarter of the fp32 bytes); normalisation is fused on the GPU
-            prep = lambda im: np.asarray(im.convert("RGB") if hasattr(im, "convert") else im, dtype=np.uint8)
-            consume = lambda t: eng.encode_image_u8(t)
-        else:
-            prep = lambda im: preprocess_image(im, n_px)
-            consume = lambda t: self.model.get_image_features(pixel_values=t)
+
+        def decode(im):            # paths are opened here, i.e. on the worker threads
+            if isinstance(im, str):
+                from PIL import Image
+                im = Image.open(im)
+                im.load()
+            return im
+
+        def prepare_batch(chunk, pool):
+            chunk = list(pool.map(decode, chunk)) if pool is not None else [decode(c) for c in chunk]
+            tiles = _native_u8_tiles(chunk, n_px)
+            if tiles is not None:
+                return "tiles", tiles
+            same = _uniform_u8_images(chunk, n_px)
+            if same is not None:
+                return "resize", same
+            one = lambda im: preprocess_image(im, n_px)
+            arrs = list(pool.map(one, chunk)) if pool is not None else [one(c) for c in chunk]
+            return "pixels", np.stack(arrs)
+
+        def consume(tag, t):
+            if tag == "tiles":
+                return eng.encode_image_u8(t)
+            if tag == "resize":
+                return eng.encode_image_u8(eng.resize_crop_u8(t))
+            return self.model.get_image_features(pixel_values=t)
+
         bs = min(int(batch_size), eng.max_batch)
         with torch.no_grad():
-            outs = run_batches(images, bs, prep, consume, device=eng.device, num_workers=num_workers)
+            outs = run_batches(images, bs, None, consume, device=eng.device, num_workers=num_workers,
+                               prepare_batch=prepare_batch)
         return torch.cat(outs).detach().cpu().numpy()
 
     # -- plip.py:55-71 ---------------------------------------------------------

@@ -37,6 +37,93 @@ def preprocess_image(img, n_px: int = 224) -> np.ndarray:
     return np.ascontiguousarray(x.transpose(2, 0, 1))
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# GPU-side resize + centre crop.  Pillow's ``Image.resize(BICUBIC)`` on 8-bit images is
+# integer arithmetic once its coefficient tables exist (libImaging/Resample.c: precompute_coeffs,
+# normalize_coeffs_8bpc, ImagingResampleHorizontal_8bpc / Vertical_8bpc): per output pixel a window [xmin, xmin+n) of
+# input pixels, weights = bicubic(a = -0.5) sampled at the window's pixel centres, normalised, rounded to 22-bit fixed
+# point; each pass accumulates int32 from 2^21 and shifts right by 22 with a clamp to 0..255, horizontal pass first,
+# uint8 in between.  The tables are built here in float64 exactly as published; the two integer passes run in
+# libplipmi.so (plipmi_resize_crop_u8) and are therefore bit-identical to Pillow (tests/test_host.py emulates the
+# passes in numpy against Pillow itself, tests/test_gpu_api.py checks the kernel against Pillow).
+# ---------------------------------------------------------------------------------------------------------------
+_PRECISION_BITS = 32 - 8 - 2
+
+
+def _bicubic(x: np.ndarray) -> np.ndarray:
+    a = -0.5
+    x = np.abs(x)
+    return np.where(x < 1.0, ((a + 2.0) * x - (a + 3.0)) * x * x + 1.0,
+                    np.where(x < 2.0, (((x - 5.0) * x + 8.0) * x - 4.0) * a, 0.0))
+
+
+def resample_coeffs(in_size: int, out_size: int):
+    """Pillow's 8-bit bicubic tables for one axis: ``bounds`` int32 [out, 2] = (first input index, tap count) and
+    ``kk`` int32 [out, ksize] fixed-point weights (zero beyond the tap count)."""
+    scale = float(np.float32(in_size) - np.float32(0.0)) / out_size
+    filterscale = max(scale, 1.0)
+    support = 2.0 * filterscale
+    ksize = int(np.ceil(support)) * 2 + 1
+    bounds = np.zeros((out_size, 2), np.int32)
+    kk = np.zeros((out_size, ksize), np.int32)
+    ss = 1.0 / filterscale
+    for xx in range(out_size):
+        center = 0.0 + (xx + 0.5) * scale
+        xmin = max(int(center - support + 0.5), 0)           # C (int) cast: truncation of a non-negative value
+        xmax = min(int(center + support + 0.5), in_size) - xmin
+        w = _bicubic((np.arange(xmax, dtype=np.float64) + xmin - center + 0.5) * ss)
+        ww = w.sum()
+        if ww != 0.0:
+            w = w / ww
+        fixed = np.where(w < 0, -0.5 + w * (1 << _PRECISION_BITS), 0.5 + w * (1 << _PRECISION_BITS))
+        kk[xx, :xmax] = np.trunc(fixed).astype(np.int64).astype(np.int32)
+        bounds[xx] = (xmin, xmax)
+    return bounds, kk
+
+
+def resize_crop_plan(w: int, h: int, n_px: int = 224):
+    """Everything ``plipmi_resize_crop_u8`` needs for [h, w, 3] uint8 images: torchvision ``Resize(n_px)`` geometry
+    (shortest edge -> n_px, long edge ``int(n_px * long / short)``), centre-crop offsets, and the two coefficient
+    tables restricted to the crop window.  ``None`` entries mean that pass is an identity (Pillow skips it too)."""
+    short = min(w, h)
+    nw, nh = (n_px, int(n_px * h / w)) if w == short else (int(n_px * w / h), n_px)
+    if nw < n_px or nh < n_px:
+        raise ValueError(f"image {w}x{h} is too small to crop {n_px}x{n_px} after the resize")
+    left, top = int(round((nw - n_px) / 2.0)), int(round((nh - n_px) / 2.0))
+    plan = dict(w=w, h=h, n_px=n_px, nw=nw, nh=nh, left=left, top=top, xb=None, xk=None, yb=None, yk=None)
+    if nw != w:
+        b, k = resample_coeffs(w, nw)
+        plan["xb"], plan["xk"] = np.ascontiguousarray(b[left:left + n_px]), np.ascontiguousarray(k[left:left + n_px])
+    if nh != h:
+        b, k = resample_coeffs(h, nh)
+        plan["yb"], plan["yk"] = np.ascontiguousarray(b[top:top + n_px]), np.ascontiguousarray(k[top:top + n_px])
+    return plan
+
+
+def resize_crop_reference(img_u8: np.ndarray, plan) -> np.ndarray:
+    """numpy emulation of the two integer passes (what the HIP kernels do); [h, w, 3] uint8 -> [n, n, 3] uint8."""
+    n = plan["n_px"]
+    src = img_u8.astype(np.int64)
+    half = 1 << (_PRECISION_BITS - 1)
+    if plan["xb"] is not None:
+        tmp = np.empty((src.shape[0], n, 3), np.int64)
+        for x in range(n):
+            x0, cnt = plan["xb"][x]
+            acc = (src[:, x0:x0 + cnt, :] * plan["xk"][x, :cnt].astype(np.int64)[None, :, None]).sum(axis=1) + half
+            tmp[:, x, :] = np.clip(acc >> _PRECISION_BITS, 0, 255)
+    else:
+        tmp = src[:, plan["left"]:plan["left"] + n, :]
+    if plan["yb"] is not None:
+        out = np.empty((n, n, 3), np.int64)
+        for y in range(n):
+            y0, cnt = plan["yb"][y]
+            acc = (tmp[y0:y0 + cnt, :, :] * plan["yk"][y, :cnt].astype(np.int64)[:, None, None]).sum(axis=0) + half
+            out[y] = np.clip(acc >> _PRECISION_BITS, 0, 255)
+    else:
+        out = tmp[plan["top"]:plan["top"] + n]
+    return out.astype(np.uint8)
+
+
 def preprocess_images(images: Sequence, n_px: int = 224) -> np.ndarray:
     return np.stack([preprocess_image(i, n_px) for i in images]) if len(images) else \
         np.zeros((0, 3, n_px, n_px), np.float32)

@@ -52,6 +52,31 @@ def test_plip_class_matches_oracle(engines):
     np.testing.assert_array_equal(nn, want_nn)
 
 
+@pytest.mark.parametrize("h,w", [(300, 500), (512, 512), (64, 200), (96, 96), (71, 64), (1000, 700)])
+def test_gpu_resize_crop_is_pillow_exact(engines, h, w):
+    """plipmi_resize_crop_u8 == Image.resize(BICUBIC) + centre crop, bit for bit, and PLIP.encode_images takes that
+    route for equally sized images with the same embeddings as the host preprocessing path."""
+    from PIL import Image
+    from plip_amd.plip import PLIP
+    from plip_amd.preprocess import preprocess_images, resize_crop_plan
+    model, cfg, sd, *_ = engines("tiny_b6", "f32")
+    n = cfg.image_size
+    rs = np.random.RandomState(h + w)
+    imgs = rs.randint(0, 256, (5, h, w, 3), dtype=np.uint8)
+    got = model.engine.resize_crop_u8(torch.from_numpy(imgs)).cpu().numpy()
+    plan = resize_crop_plan(w, h, n)
+    for i in range(5):
+        im = Image.fromarray(imgs[i]).resize((plan["nw"], plan["nh"]), resample=Image.BICUBIC)
+        want = np.asarray(im.crop((plan["left"], plan["top"], plan["left"] + n, plan["top"] + n)))
+        np.testing.assert_array_equal(got[i], want)
+    plip = PLIP(model=model, tokenizer=fake_tokenizer(cfg))
+    a = plip.encode_images(list(imgs), batch_size=3)                                   # GPU resize + fused normalise
+    b = model.engine.encode_image(torch.from_numpy(preprocess_images(list(imgs), n))).cpu().numpy()   # host Pillow path
+    assert np.abs(a - b).max() < 2e-5
+    c = plip.encode_images([Image.fromarray(x) for x in imgs], batch_size=5)
+    np.testing.assert_array_equal(a, c)
+
+
 def test_pipelined_encode_images_is_identical(engines):
     """num_workers > 0: thread-pool decode + pinned double buffers + copy stream must not change a single bit."""
     from PIL import Image

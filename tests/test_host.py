@@ -180,3 +180,30 @@ def test_host_pipeline_order_and_errors():
 
     with pytest.raises(OSError):
         run_batches(items, 5, bad, lambda t: t, device=None, num_workers=2)
+
+
+@pytest.mark.parametrize("h,w,n", [(300, 500, 224), (512, 512, 224), (256, 256, 224), (224, 300, 224), (1000, 700, 224),
+                                   (100, 130, 64), (64, 200, 64), (233, 224, 224), (225, 225, 224), (96, 96, 224)])
+def test_resample_tables_reproduce_pillow_bit_for_bit(h, w, n):
+    """The fixed-point tables handed to plipmi_resize_crop_u8 + the two integer passes (numpy emulation of the
+    kernels) == Image.resize(BICUBIC) + centre crop, for down- and up-scaling, one or both axes."""
+    from PIL import Image
+    from plip_amd.preprocess import preprocess_image, resize_crop_plan, resize_crop_reference
+    img = np.random.RandomState(h * 7 + w).randint(0, 256, (h, w, 3), dtype=np.uint8)
+    plan = resize_crop_plan(w, h, n)
+    got = resize_crop_reference(img, plan)
+    im = Image.fromarray(img).resize((plan["nw"], plan["nh"]), resample=Image.BICUBIC)
+    want = np.asarray(im.crop((plan["left"], plan["top"], plan["left"] + n, plan["top"] + n)))
+    np.testing.assert_array_equal(got, want)
+    # and it is the geometry of the host preprocessing path (which is checked against HF's CLIPImageProcessor above)
+    px = preprocess_image(img, n)
+    from plip_amd.preprocess import CLIP_MEAN, CLIP_STD
+    ref = ((got.astype(np.float32) / np.float32(255.0) - np.asarray(CLIP_MEAN, np.float32)) / np.asarray(CLIP_STD, np.float32))
+    np.testing.assert_array_equal(px, ref.transpose(2, 0, 1))
+
+
+def test_resize_plan_rejects_images_that_cannot_be_cropped():
+    from plip_amd.preprocess import resize_crop_plan
+    plan = resize_crop_plan(640, 480, 224)
+    assert (plan["nw"], plan["nh"], plan["left"], plan["top"]) == (298, 224, 37, 0) and plan["yb"].shape == (224, 2)
+    assert resize_crop_plan(224, 224, 224)["xb"] is None and resize_crop_plan(224, 224, 224)["yb"] is None
