@@ -1,6 +1,7 @@
 // gemm.hip -- variant registry and dispatch for the NT GEMM (kernels live in gemm.h).
 #include <stdlib.h>
 
+#include <algorithm>
 #include "gemm_inst.h"
 
 namespace plipmi {
@@ -103,6 +104,17 @@ static const char* kEpiNames[EPI_COUNT] = {"bias", "bias_qgelu", "bias_resid", "
 
 int gemm_launch(int dtype, int epi, int variant, const GemmParams& p, hipStream_t stream, const char** kernel_name) {
   if (variant == -1) variant = gemm_default_variant(dtype, p.M, p.N, p.K, epi);
+  // the buffer-addressed kernels (35..41) carry 32-bit byte offsets: operands or outputs of 4 GiB and more take the
+  // 64-bit-address twins
+  if (variant >= 35 && variant <= 41) {
+    const size_t es = dtype == 1 ? 2 : 4;
+    const size_t out_rows = epi == EPI_PATCH ? (size_t)p.M + p.M / (p.np > 0 ? p.np : 1) + 1 : (size_t)p.M;
+    const size_t span = std::max(std::max((size_t)p.M * p.lda * es, (size_t)p.N * p.ldw * es), out_rows * p.ldc * 4);
+    if (span >= (1ull << 32)) {
+      static const int twin[7] = {32, 33, 34, 6, 26, 24, 8};
+      variant = twin[variant - 35];
+    }
+  }
   if (p.M <= 0) return 0;
   const int bk = dtype == 1 ? 64 : 32;
   if (variant >= 0) {
