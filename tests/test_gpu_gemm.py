@@ -69,3 +69,27 @@ def test_gemm_rejects_bad_shapes():
     w = torch.zeros(128, 48, device=dev)
     with pytest.raises(PlipmiError):
         gemm_nt(a, w, torch.zeros(128, device=dev), variant=1)      # K % 32 != 0
+
+
+def test_operands_of_four_gib_take_the_64bit_address_kernels():
+    """The buffer-DMA kernels carry 32-bit byte offsets; gemm_launch must route a 4 GiB A operand to their
+    global-address twins -- rows beyond the 4 GiB mark have to come out right."""
+    from plip_amd.engine import gemm_nt
+    dev = torch.device("cuda:0")
+    M, N, K = (1 << 20) + 37, 256, 2048                       # A = 4 GiB + 148 KiB of bf16
+    a = torch.empty(M, K, device=dev, dtype=torch.bfloat16)
+    g = torch.Generator(device=dev).manual_seed(5)
+    a[:4096].normal_(generator=g)
+    a[4096:-4096] = 0.0
+    a[-4096:].normal_(generator=g)
+    w = (torch.randn(N, K, device=dev, generator=g) / K ** 0.5).to(torch.bfloat16)
+    bias = torch.randn(N, device=dev, generator=g)
+    for variant in (35, -1):
+        y = gemm_nt(a, w, bias, epilogue=0, variant=variant)
+        torch.cuda.synchronize()
+        for sl in (slice(0, 300), slice(M - 300, M)):
+            ref = a[sl].double() @ w.double().T + bias.double()
+            assert (y[sl].double() - ref).abs().max().item() < 4e-3 * max(1.0, ref.abs().max().item())
+        assert y[5000:6000].float().sub(bias).abs().max().item() < 2e-2      # zero rows -> bias only
+    del a, y
+    torch.cuda.empty_cache()
