@@ -55,10 +55,64 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, size_t x
   }
 }
 
+// D == NV * 256 exactly (CLIP widths 512 / 768 / 1024): no per-chunk predicates, RPW rows per wave so that RPW * NV
+// 16-byte loads per lane are in flight before the first reduction starts, gamma / beta fetched once per wave.
+template <typename TOut, int NV, int RPW>
+__global__ __launch_bounds__(256) void layernorm_fixed_kernel(const float* x, size_t xs, const float* __restrict__ g,
+                                                              const float* __restrict__ b, TOut* y, int rows, float eps) {
+  constexpr int D = NV * 256;
+  const int lane = threadIdx.x & 63;
+  const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
+  if (row0 >= rows) return;
+  float4 v[RPW][NV];
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) {
+    const int row = row0 + r < rows ? row0 + r : rows - 1;
+#pragma unroll
+    for (int it = 0; it < NV; ++it) v[r][it] = *reinterpret_cast<const float4*>(x + (size_t)row * xs + it * 256 + lane * 4);
+  }
+  float4 gg[NV], bb[NV];
+#pragma unroll
+  for (int it = 0; it < NV; ++it) {
+    gg[it] = *reinterpret_cast<const float4*>(g + it * 256 + lane * 4);
+    bb[it] = *reinterpret_cast<const float4*>(b + it * 256 + lane * 4);
+  }
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) {
+    float s = 0.f;
+#pragma unroll
+    for (int it = 0; it < NV; ++it) s += (v[r][it].x + v[r][it].y) + (v[r][it].z + v[r][it].w);
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int it = 0; it < NV; ++it) {
+      const float a = v[r][it].x - mean, c = v[r][it].y - mean, d = v[r][it].z - mean, e = v[r][it].w - mean;
+      q += (a * a + c * c) + (d * d + e * e);
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+    if (row0 + r < rows) {
+      TOut* yr = y + (size_t)(row0 + r) * D;
+#pragma unroll
+      for (int it = 0; it < NV; ++it)
+        store4(yr + it * 256 + lane * 4, (v[r][it].x - mean) * rstd * gg[it].x + bb[it].x,
+               (v[r][it].y - mean) * rstd * gg[it].y + bb[it].y, (v[r][it].z - mean) * rstd * gg[it].z + bb[it].z,
+               (v[r][it].w - mean) * rstd * gg[it].w + bb[it].w);
+    }
+  }
+}
+
 hipError_t launch_layernorm(const float* x, size_t xs, const float* g, const float* b, void* y, int y_dtype, int rows,
                             int D, float eps, hipStream_t s) {
   if (rows <= 0) return hipSuccess;
   if (D % 4 || D > kLnMaxVec * 256) return hipErrorInvalidValue;
+  if (y_dtype == 1 && (D == 512 || D == 768 || D == 1024)) {  // one kernel for every batch size: batch invariance is bitwise
+    constexpr int RPW = 2;
+    const dim3 grid((rows + 4 * RPW - 1) / (4 * RPW)), block(256);
+    if (D == 512) hipLaunchKernelGGL((layernorm_fixed_kernel<bf16_t, 2, RPW>), grid, block, 0, s, x, xs, g, b, (bf16_t*)y, rows, eps);
+    else if (D == 768) hipLaunchKernelGGL((layernorm_fixed_kernel<bf16_t, 3, RPW>), grid, block, 0, s, x, xs, g, b, (bf16_t*)y, rows, eps);
+    else hipLaunchKernelGGL((layernorm_fixed_kernel<bf16_t, 4, RPW>), grid, block, 0, s, x, xs, g, b, (bf16_t*)y, rows, eps);
+    return hipGetLastError();
+  }
   const dim3 grid((rows + 3) / 4), block(256);
   if (y_dtype == 1)
     hipLaunchKernelGGL(layernorm_kernel<bf16_t>, grid, block, 0, s, x, xs, g, b, (bf16_t*)y, rows, D, eps);
