@@ -594,7 +594,11 @@ void gemm_nt_kernel(const GemmParams p) {
     // -- the bias of a lane's 4 x 4 columns per MFMA tile is loaded once per tile column, not once per output row --
     // round to bf16 there, and transpose HALF the bytes: 8 ds_write_b64 + 4 ds_read_b128 + 4 16-byte global stores
     // per 32 x 64 slab instead of 8 ds_write_b128 + 8 ds_read_b128 + 8 bias loads + 8 8-byte stores.
-    constexpr int HP = 64 * 2 + 16;  // bf16 slab row pitch: 16-byte aligned rows for the ds_read_b128
+    // bf16 slab: 32 rows x 128 B, no padding.  16-byte chunk c of row r sits in slot c ^ (r & 7) and, for rows with
+    // bit 3 set, its two 8-byte halves are swapped: the transposing ds_write_b64 (16 consecutive rows, same column)
+    // then covers all 32 write banks once, the row-contiguous ds_read_b128 all 64 read banks once
+    // (SQ_LDS_BANK_CONFLICT = 0); the half swap is undone in registers, statically per store iteration.
+    constexpr int HP = 128;
     typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
     float4 bq[NI][4];
 #pragma unroll
@@ -619,13 +623,16 @@ void gemm_nt_kernel(const GemmParams p) {
               v2 = quick_gelu<false>(v2); v3 = quick_gelu<false>(v3);
             }
             const bf16x4 pk = {(bf16_t)v0, (bf16_t)v1, (bf16_t)v2, (bf16_t)v3};
-            *reinterpret_cast<bf16x4*>(slab + lrow * HP + (jj * 32 + 8 * q + 4 * lgrp) * 2) = pk;
+            *reinterpret_cast<bf16x4*>(slab + lrow * HP + (((jj * 4 + q) ^ (lrow & 7)) << 4) +
+                                       ((lgrp ^ ((lrow >> 3) & 1)) << 3)) = pk;
           }
         __builtin_amdgcn_wave_barrier();
         u32x4 o[4];
 #pragma unroll
-        for (int it = 0; it < 4; ++it)
-          o[it] = *reinterpret_cast<const u32x4*>(slab + (it * 8 + hr_row) * HP + hr_chunk * 16);
+        for (int it = 0; it < 4; ++it) {
+          const u32x4 raw = *reinterpret_cast<const u32x4*>(slab + (it * 8 + hr_row) * HP + ((hr_chunk ^ hr_row) << 4));
+          o[it] = (it & 1) ? u32x4{raw[2], raw[3], raw[0], raw[1]} : raw;  // rows 8..15, 24..31: halves were swapped
+        }
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
           int m = m0 + wm * TM + i * 32 + it * 8 + hr_row;
