@@ -260,6 +260,14 @@ int text_embed(plipmi_engine* e, const int64_t* ids, int B, hipStream_t s) {
 int run_head(plipmi_engine* e, Tower& t, const int64_t* ids, int eos_id, const float* ln_w, const float* ln_b,
              const float* W, const float* Wt, float* pooled, float* out, int B, int normalize, hipStream_t s) {
   const int P = e->cfg.projection_dim, D = t.D;
+  if (P % 32 == 0 && D % 32 == 0) {
+    { Scope sc(e, s, "pool_layernorm", 0, (double)B * D * 8);
+      HIP_TRY(launch_pool_layernorm(t.x, t.S, D, ids, eos_id, ln_w, ln_b, e->cfg.layer_norm_eps, pooled, B, s)); }
+    { Scope sc(e, s, "head_gemm", 2.0 * B * P * (double)D, ((double)B * D + (double)P * D + (double)B * P) * 4);
+      HIP_TRY(launch_head_gemm(pooled, W, out, B, P, D, s)); }
+    if (normalize) { Scope sc(e, s, "l2_normalize", 0, (double)B * P * 8); HIP_TRY(launch_l2_normalize(out, B, P, s)); }
+    return PLIPMI_OK;
+  }
   if (P % 128 == 0) {
     { Scope sc(e, s, "pool_layernorm", 0, (double)B * D * 8);
       HIP_TRY(launch_pool_layernorm(t.x, t.S, D, ids, eos_id, ln_w, ln_b, e->cfg.layer_norm_eps, pooled, B, s)); }

@@ -39,6 +39,8 @@ hipError_t launch_pool_layernorm(const float* x, int S, int D, const int64_t* id
                                  const float* ln_b, float eps, float* out, int B, hipStream_t s);
 
 hipError_t launch_l2_normalize(float* x, int N, int D, hipStream_t s);
+// C[M,N] = A[M,K] . W[N,K]^T, exact fp32 MFMA, split-K over the four waves of a 32x32-tile workgroup (N, K % 32 == 0)
+hipError_t launch_head_gemm(const float* A, const float* W, float* C, int M, int N, int K, hipStream_t s);
 
 // logits_per_image[i,j] = scale*<img_i,txt_j>; optional transpose output and per-row first arg-max.
 hipError_t launch_logits(const float* img, int Ni, const float* txt, int Nt, int D, float scale, float* lpi,

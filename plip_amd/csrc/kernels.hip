@@ -563,6 +563,53 @@ hipError_t launch_topk(const float* scores, int N, int M, int k, int64_t* idx, h
 }
 
 // ---------------------------------------------------------------------------------
+// Projection head GEMM: out[B, P] = pooled[B, D] . W[P, D]^T in exact fp32 (modeling_clip.py:674-675,713,751).
+// 100 MFLOP on a 256 x 512 output: with the big-tile GEMM this was 8 workgroups walking 24 K tiles one after the
+// other (46 us, latency-bound, at the tail of each tower).  Here one workgroup owns a 32 x 32 output tile, its four
+// waves split K four ways (fp32 32x32x2 MFMA, operands straight from L2 as float4 per lane -- the k index inside an
+// MFMA may be permuted freely as long as both operands share the permutation), and the partial tiles are added
+// through LDS in a fixed order (deterministic, independent of the batch size).
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void head_gemm_kernel(const float* __restrict__ A, const float* __restrict__ W,
+                                                        float* __restrict__ C, int M, int N, int K) {
+  __shared__ __attribute__((aligned(16))) float part[4][16][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lrow = lane & 31, lgrp = lane >> 5;
+  const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
+  const int ar = m0 + lrow < M ? m0 + lrow : M - 1;
+  const int kq = K / 4;  // K % 32 == 0 -> a multiple of 8
+  const float* ap = A + (size_t)ar * K + wave * kq + 4 * lgrp;
+  const float* wp = W + (size_t)(n0 + lrow) * K + wave * kq + 4 * lgrp;
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  for (int kk = 0; kk < kq; kk += 8) {
+    const float4 a = *reinterpret_cast<const float4*>(ap + kk);
+    const float4 w = *reinterpret_cast<const float4*>(wp + kk);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, a.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, a.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, a.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, a.w, acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int e = 0; e < 16; ++e) part[wave][e][lane] = acc[e];
+  __syncthreads();
+  // wave q finishes accumulator quad q: C[m0 + lrow][n0 + 8q + 4*lgrp + e]
+  float4 o;
+  float* op = &o.x;
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    op[e] = ((part[0][4 * wave + e][lane] + part[1][4 * wave + e][lane]) + part[2][4 * wave + e][lane]) + part[3][4 * wave + e][lane];
+  if (m0 + lrow < M) *reinterpret_cast<float4*>(C + (size_t)(m0 + lrow) * N + n0 + 8 * wave + 4 * lgrp) = o;
+}
+hipError_t launch_head_gemm(const float* A, const float* W, float* C, int M, int N, int K, hipStream_t s) {
+  if (M <= 0) return hipSuccess;
+  if (N % 32 || K % 32) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(head_gemm_kernel, dim3(N / 32, (M + 31) / 32), dim3(256), 0, s, A, W, C, M, N, K);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------
 // Streaming top-k (fused similarity + top-k head, plipmi_similarity_topk).
 // The score matrix is produced panel by panel ([rows, <=8192] fp32, never the full [Nq, Ns]); this kernel folds
 // one panel into each row's running top-k list.  One wavefront per query row; the list (k <= 1024 entries,
