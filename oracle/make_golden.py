@@ -31,6 +31,7 @@ CASES = {
     "tiny_b5_zero_pad_ln100": ("tiny", 5, 3, 4, 5, "zero", LN100),
     "vitb32_b4": ("ViT-B/32", 4, 0, 1, 2, "eos", None),
     "vitb32_b3_zero_pad_ln100": ("ViT-B/32", 3, 7, 8, 9, "zero", LN100),
+    "tinyp4_b3": ("tiny-p4", 3, 11, 12, 13, "eos", None),          # 257 vision tokens: chunked online-softmax attention
 }
 
 
@@ -44,7 +45,7 @@ def fingerprint(sd) -> np.ndarray:
 def case_inputs(name):
     arch, B, ws, ps, is_, pad, ls = CASES[name]
     cfg = get_config(arch)
-    if arch != "tiny" and pad == "zero":
+    if not arch.startswith("tiny") and pad == "zero":
         cfg = cfg.replace(eos_token_id=2)       # OpenAI-clip / legacy-HF argmax pooling rule
     sd = W.synthetic_state_dict(cfg, ws, logit_scale=ls)
     px = W.synthetic_pixels(cfg, B, ps)
@@ -52,9 +53,9 @@ def case_inputs(name):
     return cfg, sd, px, ids, mask
 
 
-def main():
+def main(only=None):
     os.makedirs(GOLDEN_DIR, exist_ok=True)
-    for name in CASES:
+    for name in (only or CASES):
         cfg, sd, px, ids, mask = case_inputs(name)
         model = H.build_model(cfg, sd, "sdpa")
         # the OpenAI tokenizer gives no attention_mask: zero-pad cases run without one
@@ -64,7 +65,7 @@ def main():
                                     "logits_per_image", "logits_per_text")}
         # hidden states: all of them for tiny; CLS / first-EOS rows for the full model (small files)
         vh, th = out["vision_hidden"], out["text_hidden"]
-        if cfg.v_width <= 128:
+        if cfg.v_width <= 128 and cfg.v_tokens <= 64:
             save["vision_hidden"] = np.stack(vh)
             save["text_hidden"] = np.stack(th)
         else:
@@ -83,4 +84,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    main(sys.argv[1:] or None)

@@ -117,6 +117,8 @@ PRESETS = {
                        t_heads=2, t_mlp=256, projection_dim=64, eos_token_id=511,
                        bos_token_id=510),
 }
+# the tiny model with a 4-pixel patch: 257 vision tokens (the ViT-L/14 count) -> the long-sequence attention path
+PRESETS["tiny-p4"] = PRESETS["tiny"].replace(patch_size=4)
 
 
 def get_config(name: str = "ViT-B/32") -> PlipConfig:
