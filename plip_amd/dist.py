@@ -2,7 +2,8 @@
 
 The towers are embarrassingly parallel over samples (weights replicated, <=605 MB),
 so the only exchange step of the path is the all-gather of the L2-normalised
-embeddings ``[N/W, P]`` into ``[N, P]`` on every rank for the similarity product
+embeddings ``[N/W, P]`` into ``[N, P]`` on every rank for the similarity product (image and
+text matrices stacked into one buffer, so a step contains exactly one collective)
 (SURVEY.md section 8e).  ``torch.distributed`` backend "nccl" is RCCL over xGMI on the MI355X
 node; "gloo" runs the same code on CPU for the tests.  The reference has no
 distributed path at all (single process, plip.py:15).
@@ -70,8 +71,15 @@ def sharded_pair_logits(model, pixels_local: torch.Tensor, ids_local: torch.Tens
     else:
         img = eng.encode_image(pixels_local, normalize=True)
         txt = eng.encode_text(ids_local, attention_mask_local, normalize=True)
-    txt_all = all_gather_rows(txt, group, equal_shards)
-    img_all = all_gather_rows(img, group, equal_shards)
+    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    if equal_shards and world > 1 and img.shape == txt.shape:
+        # fixed per-rank batch: both embedding matrices travel in ONE all-gather ([2, n, P] per rank)
+        both = all_gather_rows(torch.stack((img, txt)).unsqueeze(0), group, True)     # [W, 2, n, P]
+        img_all = both[:, 0].reshape(-1, img.shape[1])
+        txt_all = both[:, 1].reshape(-1, txt.shape[1])
+    else:
+        txt_all = all_gather_rows(txt, group, equal_shards)
+        img_all = all_gather_rows(img, group, equal_shards)
     lpi, _, _ = eng.logits(img, txt_all, scale=eng.logit_scale_exp, want_text=False)
     return lpi, img_all, txt_all
 
