@@ -91,3 +91,16 @@ def sharded_zero_shot(model, pixels_local: torch.Tensor, class_text_embeds: torc
     img = eng.encode_image(pixels_local, normalize=True)
     _, _, pred = eng.logits(img, class_text_embeds, scale=1.0, want_text=False, want_argmax=True)
     return all_gather_rows(pred, group)
+
+
+def sharded_retrieval_topk(model, text_embeds_local: torch.Tensor, image_embeds_local: torch.Tensor, k: int = 50,
+                           group=None):
+    """Text-to-image retrieval over a corpus sharded by rank (reproducibility/evaluation/retrieval/retrieval.py:13-18
+    at corpus scale): the image embeddings are all-gathered once, every rank ranks ITS captions against the whole
+    corpus with the fused similarity + top-k head (no [N, N] matrix anywhere) and the [n_r, k] index blocks are
+    gathered in rank order.  Returns int64 [N_text, k] global image indices."""
+    eng = model.engine
+    img_all = all_gather_rows(image_embeds_local, group)
+    k = min(int(k), int(img_all.shape[0]))
+    best = eng.similarity_topk(text_embeds_local, img_all, k)
+    return all_gather_rows(best, group)

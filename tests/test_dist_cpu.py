@@ -10,7 +10,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from plip_amd.dist import all_gather_rows, shard_bounds, sharded_pair_logits, sharded_zero_shot
+from plip_amd.dist import (all_gather_rows, shard_bounds, sharded_pair_logits, sharded_retrieval_topk,
+                           sharded_zero_shot)
 
 
 def _free_port():
@@ -36,6 +37,9 @@ class _FakeEngine:
         e = ids.float()[:, :5] @ self.wt
         return e / e.norm(dim=-1, keepdim=True) if normalize else e
 
+    def similarity_topk(self, keys, space, k):
+        return torch.argsort(-(keys @ space.T), dim=1, stable=True)[:, :k]
+
     def logits(self, a, b, scale=1.0, want_text=True, want_argmax=False):
         l = scale * a @ b.T
         return l, (l.T.contiguous() if want_text else None), (l.argmax(1).int() if want_argmax else None)
@@ -59,10 +63,13 @@ def _worker(rank, world, port, n, q):
         cls = model.engine.encode_text(ids[:3], normalize=True)
         pred = sharded_zero_shot(model, px[lo:hi], cls)
         ragged = all_gather_rows(torch.full((rank + 1, 2), float(rank)))
+        img_l = model.engine.encode_image(px[lo:hi], normalize=True)
+        txt_l = model.engine.encode_text(ids[lo:hi], normalize=True)
+        best = sharded_retrieval_topk(model, txt_l, img_l, k=3)
         if n % world == 0:   # the fixed-batch fast path (no size exchange) must give the same matrix
             fast = sharded_pair_logits(model, px[lo:hi], ids[lo:hi], equal_shards=True)
             assert torch.equal(fast[0], rows) and torch.equal(fast[1], img_all) and torch.equal(fast[2], txt_all)
-        q.put((rank, lo, hi, rows.numpy(), img_all.numpy(), txt_all.numpy(), pred.numpy(), ragged.numpy()))
+        q.put((rank, lo, hi, rows.numpy(), img_all.numpy(), txt_all.numpy(), pred.numpy(), ragged.numpy(), best.numpy()))
     finally:
         dist.destroy_process_group()
 
@@ -90,7 +97,9 @@ def test_two_rank_shard_and_gather_matches_single_process(n):
     cls = eng.encode_text(ids[:3], normalize=True)
     pred = (img @ cls.T).argmax(1).numpy()
     covered = []
-    for rank, lo, hi, rows, img_all, txt_all, p, ragged in results:
+    want_best = torch.argsort(-(txt @ img.T), dim=1, stable=True)[:, :3].numpy()
+    for rank, lo, hi, rows, img_all, txt_all, p, ragged, best in results:
+        np.testing.assert_array_equal(best, want_best)                          # every rank: the full [N, k] ranking
         np.testing.assert_allclose(rows, full[lo:hi], rtol=1e-6, atol=1e-6)
         np.testing.assert_allclose(img_all, img.numpy(), rtol=1e-6, atol=1e-7)   # every rank holds the full matrix
         np.testing.assert_allclose(txt_all, txt.numpy(), rtol=1e-6, atol=1e-7)
