@@ -10,6 +10,10 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
+// OCP e4m3fn operand of the experimental fp8 GEMM (storage tag only: the arithmetic is the scaled f8f6f4 MFMA)
+struct fp8_t { unsigned char v; };
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+
 constexpr int kWave = 64;  // CDNA wavefront
 
 // ---- scalar conversions -------------------------------------------------

@@ -551,6 +551,18 @@ int plipmi_gemm_nt(int dtype, int epilogue, int variant, int M, int N, int K, co
 
 int plipmi_gemm_nt_traced(int dtype, int epilogue, int variant, int M, int N, int K, const void* A, const void* W,
                           const float* bias, float alpha, void* C, uint64_t* trace, void* stream) {
+  if (dtype == 2) {  // experimental: fp8 (e4m3fn) A and W, bf16 C, bias / bias+QuickGELU (gemm_fp8.hip)
+    if ((epilogue != EPI_BIAS && epilogue != EPI_BIAS_QGELU) || !bias || M < 0 || N <= 0 || K <= 0 || !A || !W || !C)
+      return fail(PLIPMI_ERR_INVALID, "fp8 gemm: bias / bias_qgelu epilogues only");
+    GemmParams p;
+    p.A = A; p.W = W; p.C = C; p.bias = bias; p.M = M; p.N = N; p.K = K; p.lda = K; p.ldw = K; p.ldc = N;
+    p.alpha = alpha; p.np = 1;
+    p.trace = reinterpret_cast<unsigned long long*>(trace);
+    const int rc = gemm_launch_fp8(epilogue, variant, p, reinterpret_cast<hipStream_t>(stream));
+    if (rc != 0) return fail(PLIPMI_ERR_HIP, "fp8 gemm launch failed (variant %d, M=%d N=%d K=%d): %s", variant, M, N, K,
+                             hipGetErrorString((hipError_t)rc));
+    return PLIPMI_OK;
+  }
   if (dtype != PLIPMI_F32 && dtype != PLIPMI_BF16) return fail(PLIPMI_ERR_INVALID, "bad dtype");
   if (epilogue < 0 || epilogue > EPI_SCALE) return fail(PLIPMI_ERR_INVALID, "epilogue must be 0..3");
   if (M < 0 || N <= 0 || K <= 0 || !A || !W || !C) return fail(PLIPMI_ERR_INVALID, "bad shape / null pointer");

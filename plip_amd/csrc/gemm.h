@@ -191,7 +191,8 @@ struct EpilogueOp {
         v0 = quick_gelu<kAccurate>(v0); v1 = quick_gelu<kAccurate>(v1);
         v2 = quick_gelu<kAccurate>(v2); v3 = quick_gelu<kAccurate>(v3);
       }
-      store4(reinterpret_cast<T*>(p.C) + (size_t)m * p.ldc + n0, v0, v1, v2, v3);
+      using OutT = std::conditional_t<sizeof(T) == 4, float, bf16_t>;
+      store4(reinterpret_cast<OutT*>(p.C) + (size_t)m * p.ldc + n0, v0, v1, v2, v3);
     } else if constexpr (EPI == EPI_BIAS_RESID) {
       store4(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n0, add.x + v0, add.y + v1, add.z + v2, add.w + v3);
     } else if constexpr (EPI == EPI_SCALE) {
@@ -230,6 +231,10 @@ void gemm_nt_kernel(const GemmParams p) {
   constexpr int TM = BM / WM, TN = BN / WN;
   constexpr int MI = TM / 32, NI = TN / 32;
   constexpr int ELEMS16 = 16 / sizeof(T);  // elements per 16-byte chunk
+  // fp8 operands (T = fp8_t, experimental): 128 K per 128-byte LDS row, bf16 outputs, v_mfma_scale_f32_32x32x64_f8f6f4
+  using OutT = std::conditional_t<sizeof(T) == 4, float, bf16_t>;
+  static_assert(sizeof(T) != 1 || ((EPI == EPI_BIAS || EPI == EPI_BIAS_QGELU) && GLDS && NSTAGE == 2 && L2PF == 0),
+                "the fp8 form exists for the bf16-output column-wise epilogues of the LDS-DMA kernels");
   constexpr int BK = 8 * ELEMS16;          // 128-byte rows
   constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, STAGE = A_BYTES + W_BYTES;
   constexpr int PA = BM * 8 / NT, PW = BN * 8 / NT;  // 16-byte chunks per thread per tile
@@ -426,6 +431,47 @@ void gemm_nt_kernel(const GemmParams p) {
 
   auto compute = [&](int buf, int fill_buf) {
     const char* sb = smem + buf * STAGE;
+    if constexpr (sizeof(T) == 1) {
+      // fp8: one MFMA consumes 64 K = 32 bytes per lane = the 16-byte pieces of K steps 2h and 2h+1 (any k permutation
+      // shared by both operands is valid); two MFMAs per accumulator tile per 128-K tile, at twice the bf16 rate
+      u32x4 xa[2][MI][2], wa[2][NI][2];
+      auto fetch = [&](int h, int set) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          xa[set][i][0] = *reinterpret_cast<const u32x4*>(sb + a_tile + i * 32 * 128 + foff[2 * h]);
+          xa[set][i][1] = *reinterpret_cast<const u32x4*>(sb + a_tile + i * 32 * 128 + foff[2 * h + 1]);
+        }
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          wa[set][j][0] = *reinterpret_cast<const u32x4*>(sb + w_tile + j * 32 * 128 + foff[2 * h]);
+          wa[set][j][1] = *reinterpret_cast<const u32x4*>(sb + w_tile + j * 32 * 128 + foff[2 * h + 1]);
+        }
+      };
+      fetch(0, 0);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        if (h == 0) fetch(1, 1);
+        if constexpr ((SCHED == 3 || SCHED == 5 || SCHED == 6) && GLDS) {
+          if (fill_buf >= 0) {
+            if (h == 0) { stage_issue_part(fill_buf, 0); if (kFillParts > 2) stage_issue_part(fill_buf, 1); }
+            else { stage_issue_part(fill_buf, kFillParts > 2 ? 2 : 1); if (kFillParts > 3) stage_issue_part(fill_buf, 3); }
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j) {
+            const i32x8 wv = {(int)wa[h][j][0][0], (int)wa[h][j][0][1], (int)wa[h][j][0][2], (int)wa[h][j][0][3],
+                              (int)wa[h][j][1][0], (int)wa[h][j][1][1], (int)wa[h][j][1][2], (int)wa[h][j][1][3]};
+            const i32x8 xv = {(int)xa[h][i][0][0], (int)xa[h][i][0][1], (int)xa[h][i][0][2], (int)xa[h][i][0][3],
+                              (int)xa[h][i][1][0], (int)xa[h][i][1][1], (int)xa[h][i][1][2], (int)xa[h][i][1][3]};
+            acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wv, xv, acc[i][j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+          }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      return;
+    }
     // fragments of K-step ks+1 are fetched from LDS before the MFMAs of step ks issue
     u32x4 xf[2][MI], wf[2][NI];
 #pragma unroll
@@ -450,7 +496,9 @@ void gemm_nt_kernel(const GemmParams p) {
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < NI; ++j) mma16<T>(acc[i][j], wf[ks & 1][j], xf[ks & 1][i]);
+        for (int j = 0; j < NI; ++j) {
+          if constexpr (sizeof(T) != 1) mma16<T>(acc[i][j], wf[ks & 1][j], xf[ks & 1][i]);
+        }
       if constexpr (SCHED == 2) __builtin_amdgcn_s_setprio(0);
       if constexpr (SCHED >= 1) __builtin_amdgcn_sched_barrier(0);
     }
@@ -476,7 +524,9 @@ void gemm_nt_kernel(const GemmParams p) {
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < NI; ++j) mma16<T>(acc[i][j], wfp[ks & 1][j], xfp[ks & 1][i]);
+        for (int j = 0; j < NI; ++j) {
+          if constexpr (sizeof(T) != 1) mma16<T>(acc[i][j], wfp[ks & 1][j], xfp[ks & 1][i]);
+        }
       __builtin_amdgcn_sched_barrier(0);
     }
   };
@@ -589,7 +639,7 @@ void gemm_nt_kernel(const GemmParams p) {
   __syncthreads();  // every wave is done reading the last K tile: the staging LDS can be reused
   if (p.ablate & 4) return;
   char* slab = smem + wave * SLAB_BYTES;
-  if constexpr (sizeof(T) == 2 && (EPI == EPI_BIAS || EPI == EPI_BIAS_QGELU)) {
+  if constexpr (sizeof(T) <= 2 && (EPI == EPI_BIAS || EPI == EPI_BIAS_QGELU)) {
     // bf16 outputs whose epilogue is column-wise (bias, QuickGELU): finish the arithmetic in the ACCUMULATOR layout
     // -- the bias of a lane's 4 x 4 columns per MFMA tile is loaded once per tile column, not once per output row --
     // round to bf16 there, and transpose HALF the bytes: 8 ds_write_b64 + 4 ds_read_b128 + 4 16-byte global stores
@@ -639,7 +689,7 @@ void gemm_nt_kernel(const GemmParams p) {
           const bool in_range = m < p.M;
           if (p.ablate & 32) m &= 255;  // timeline experiment: every tile stores to the same 256 rows (L2-resident)
           if (in_range)
-            *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(p.C) + (size_t)m * p.ldc + n0 + wn * TN + jp * 64 + hr_chunk * 8) = o[it];
+            *reinterpret_cast<u32x4*>(reinterpret_cast<OutT*>(p.C) + (size_t)m * p.ldc + n0 + wn * TN + jp * 64 + hr_chunk * 8) = o[it];
         }
         __builtin_amdgcn_wave_barrier();
       }
@@ -721,6 +771,7 @@ const GemmVariant& gemm_variant(int v);
 // receives a static string naming the kernel that ran.
 int gemm_launch(int dtype, int epi, int variant, const GemmParams& p, hipStream_t stream, const char** kernel_name);
 int gemm_default_variant(int dtype, int M, int N, int K, int epi = -1);
+int gemm_launch_fp8(int epi, int variant, const GemmParams& p, hipStream_t stream);  // experimental test hook
 void gemm_set_default_override(int variant);  // PLIPMI_GEMM_VARIANT / tests
 void gemm_set_policy(int policy);             // 0: wave-quantisation cost model (one stream), 1: co-scheduled streams
 

@@ -100,6 +100,28 @@ int gemm_default_variant(int dtype, int M, int N, int K, int epi) {
   return best;
 }
 
+// EXPERIMENTAL fp8 test hook (gemm_fp8.hip): variants 0..3, bias / bias_qgelu, N % 256 == 0, K % 128 == 0
+int gemm_launch_fp8(int epi, int variant, const GemmParams& p, hipStream_t stream) {
+  if (p.M <= 0) return 0;
+  if (p.N % 256 != 0 || p.K % 128 != 0) return (int)hipErrorInvalidValue;
+  if ((size_t)p.M * p.lda >= (1ull << 32) || (size_t)p.N * p.ldw >= (1ull << 32)) return (int)hipErrorInvalidValue;
+  GemmLaunchFn fn = gemm_get_fp8(variant < 0 ? 0 : variant, epi);
+  if (!fn) return (int)hipErrorInvalidValue;
+  GemmParams pr = p;
+  const int nbn = p.N / 256;
+  const double a_bytes = (double)p.M * p.K, w_bytes = (double)p.N * p.K;
+  int best_xn = 1;
+  double best = 1e300;
+  for (int xn = 1; xn <= 8; xn *= 2) {
+    if (nbn % xn) continue;
+    double cost = a_bytes * xn + w_bytes * (8.0 / xn);
+    if (w_bytes / xn > 2.5e6) cost += 4.0 * w_bytes * 8.0;
+    if (cost < best) { best = cost; best_xn = xn; }
+  }
+  pr.gw = nbn / best_xn;
+  return fn(pr, stream);
+}
+
 static const char* kEpiNames[EPI_COUNT] = {"bias", "bias_qgelu", "bias_resid", "scale", "patch"};
 
 int gemm_launch(int dtype, int epi, int variant, const GemmParams& p, hipStream_t stream, const char** kernel_name) {

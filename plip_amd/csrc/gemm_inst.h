@@ -138,5 +138,6 @@ struct GemmTable {
 
 GemmLaunchFn gemm_get_f32(int variant, int epi);
 GemmLaunchFn gemm_get_bf16(int variant, int epi);
+GemmLaunchFn gemm_get_fp8(int variant, int epi);   // experimental: variants 0..3, bias / bias_qgelu only
 
 }  // namespace plipmi

@@ -302,11 +302,12 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = Non
     """Kernel-level entry (tests / micro-bench): epilogue(A[M,K] @ W[N,K]^T); a, w fp32 or bf16 CUDA tensors."""
     lib = _lib.load()
     assert a.is_cuda and w.is_cuda and a.dtype == w.dtype and a.is_contiguous() and w.is_contiguous()
-    code = _lib.BF16 if a.dtype == torch.bfloat16 else _lib.F32
+    fp8 = a.dtype == torch.float8_e4m3fn            # experimental test hook: fp8 operands, bf16 output
+    code = 2 if fp8 else (_lib.BF16 if a.dtype == torch.bfloat16 else _lib.F32)
     M, K = a.shape
     N = w.shape[0]
     if out is None:
-        odt = a.dtype if epilogue in (0, 1) else torch.float32
+        odt = torch.bfloat16 if fp8 else (a.dtype if epilogue in (0, 1) else torch.float32)
         out = torch.zeros((M, N), dtype=odt, device=a.device)
     with torch.cuda.device(a.device):
         _lib.check(lib.plipmi_gemm_nt_traced(code, epilogue, variant, M, N, K, _ptr(a), _ptr(w), _ptr(bias), float(alpha),

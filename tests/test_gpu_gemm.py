@@ -93,3 +93,26 @@ def test_operands_of_four_gib_take_the_64bit_address_kernels():
         assert y[5000:6000].float().sub(bias).abs().max().item() < 2e-2      # zero rows -> bias only
     del a, y
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("variant", [0, 1, 3])
+@pytest.mark.parametrize("epi", [0, 1])
+def test_fp8_gemm_probe_is_exact_up_to_output_rounding(variant, epi):
+    """EXPERIMENTAL fp8 (e4m3fn) operands through v_mfma_scale_f32_32x32x64_f8f6f4 (the configs[4] headroom probe):
+    products of fp8 values are exact in fp32, so against an fp64 product of the SAME fp8 operands only fp32
+    accumulation noise and the bf16 output rounding (half an ulp = 2^-9 relative) remain."""
+    from plip_amd.engine import gemm_nt
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(77 + variant)
+    for (M, N, K) in ((1, 256, 128), (300, 256, 128), (515, 512, 768), (1000, 768, 3072)):
+        a = torch.randn(M, K, generator=g).to(dev).to(torch.float8_e4m3fn)
+        w = (torch.randn(N, K, generator=g) / K ** 0.5 * 4).to(dev).to(torch.float8_e4m3fn)
+        bias = torch.randn(N, generator=g).to(dev)
+        y = gemm_nt(a, w, bias, epilogue=epi, variant=variant)
+        torch.cuda.synchronize()
+        ref = a.float().double() @ w.float().double().T + bias.double()
+        if epi == 1:
+            ref = ref * torch.sigmoid(1.702 * ref)
+        assert y.dtype == torch.bfloat16
+        tol = 2.0 ** -8 * torch.clamp(ref.abs(), min=1.0) + 1e-3          # half a bf16 ulp, with slack for the epilogue
+        assert bool(((y.double() - ref).abs() <= tol).all()), f"variant {variant} epi {epi} {M}x{N}x{K}"

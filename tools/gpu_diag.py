@@ -228,6 +228,38 @@ def sec_towerswap():
         torch.cuda.empty_cache()
 
 
+def sec_fp8():
+    """EXPERIMENTAL fp8 (e4m3fn) GEMM test hook: exactness against fp64 of the same fp8 operands, then TFLOP/s on
+    the production QKV / fc1 shapes beside the bf16 kernels."""
+    g = torch.Generator().manual_seed(0)
+    for (M, N, K, epi) in ((300, 256, 128, 0), (515, 512, 768, 0), (1000, 768, 3072, 1)):
+        a = (torch.randn(M, K, generator=g)).to(dev).to(torch.float8_e4m3fn)
+        w = (torch.randn(N, K, generator=g) / K ** 0.5 * 4).to(dev).to(torch.float8_e4m3fn)
+        bias = torch.randn(N, generator=g).to(dev)
+        ref = a.float().double() @ w.float().double().T + bias.double()
+        if epi == 1:
+            ref = ref * torch.sigmoid(1.702 * ref)
+        for v in range(4):
+            y = gemm_nt(a, w, bias, epilogue=epi, variant=v)
+            torch.cuda.synchronize()
+            err = (y.double() - ref).abs().max().item()
+            print(f"fp8 check {M}x{N}x{K} epi{epi} variant {v}: max err {err:.3e} (|ref| max {ref.abs().max().item():.2f}, bf16 output rounding ~{ref.abs().max().item() * 2 ** -9:.1e})")
+    shapes = [("v.qkv", 12800, 2304, 768, 0), ("v.fc1", 12800, 3072, 768, 1), ("v.fc2*", 12800, 768, 3072, 0),
+              ("t.qkv", 19712, 1536, 512, 0), ("t.fc1", 19712, 2048, 512, 1), ("big", 8192, 8192, 8192, 0)]
+    for name, M, N, K, epi in shapes:
+        a8 = torch.randn(M, K, generator=g).to(dev).to(torch.float8_e4m3fn)
+        w8 = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev).to(torch.float8_e4m3fn)
+        a16, w16 = a8.to(torch.bfloat16), w8.to(torch.bfloat16)
+        bias = torch.randn(N, generator=g).to(dev)
+        out = torch.zeros(M, N, device=dev, dtype=torch.bfloat16)
+        row = []
+        for v in range(4):
+            ms = _time(lambda: gemm_nt(a8, w8, bias, epilogue=epi, variant=v, out=out), iters=20)
+            row.append(f"fp8 v{v} {2.0 * M * N * K / ms / 1e9:7.1f}")
+        ms = _time(lambda: gemm_nt(a16, w16, bias, epilogue=epi, out=out), iters=20)
+        print(f"{name:7s} {M}x{N}x{K} epi{epi}: " + "  ".join(row) + f"   bf16 auto {2.0 * M * N * K / ms / 1e9:7.1f} TFLOP/s")
+
+
 def sec_ldpad():
     """Does padding the leading dimension (rows no longer a multiple of 2 KB apart) change the fill rate?"""
     from plip_amd.engine import gemm_nt_ld
@@ -434,6 +466,6 @@ def sec_e2e():
 
 if __name__ == "__main__":
     t0 = time.time()
-    {"gemm": sec_gemm, "attn": sec_attn, "tiny": sec_tiny, "vitb32": sec_vitb32, "gemmbench": sec_gemmbench, "libgemm": sec_libgemm, "towerswap": sec_towerswap, "e2e": sec_e2e, "gemmone": sec_gemmone, "policy": sec_policy, "ldpad": sec_ldpad, "gemmtrace": sec_gemmtrace,
+    {"gemm": sec_gemm, "attn": sec_attn, "tiny": sec_tiny, "vitb32": sec_vitb32, "gemmbench": sec_gemmbench, "libgemm": sec_libgemm, "fp8": sec_fp8, "towerswap": sec_towerswap, "e2e": sec_e2e, "gemmone": sec_gemmone, "policy": sec_policy, "ldpad": sec_ldpad, "gemmtrace": sec_gemmtrace,
      "overlap": sec_overlap}[sys.argv[1]]()
     print(f"[{sys.argv[1]} done in {time.time() - t0:.1f} s]")
