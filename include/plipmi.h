@@ -46,7 +46,12 @@ extern "C" {
 
 /* arithmetic the towers' GEMMs and attention run in (accumulation, LayerNorm,
  * softmax statistics, residual stream, projections and logits are always fp32) */
-enum { PLIPMI_F32 = 0, PLIPMI_BF16 = 1 };
+enum { PLIPMI_F32 = 0, PLIPMI_BF16 = 1,
+       /* EXPERIMENTAL (BASELINE configs[4] "fp8 MFMA weights"): the bf16 engine whose QKV and fc1 projections run on
+        * fp8 e4m3fn weights (one scale per output channel, fixed at plipmi_create) and fp8 LayerNorm rows (one dynamic
+        * scale per row) through v_mfma_scale_f32_32x32x64_f8f6f4; fp32 accumulation, everything else as PLIPMI_BF16.
+        * Not within the 1e-3 cosine bar (see tests/test_gpu_parity.py for the stated tolerance). */
+       PLIPMI_FP8W = 2 };
 
 /* towers, for plipmi_debug_hidden */
 enum { PLIPMI_VISION = 0, PLIPMI_TEXT = 1 };
@@ -78,7 +83,7 @@ typedef struct plipmi_config {
   int32_t t_mlp;           /* 2048 */
   int32_t projection_dim;  /* 512 */
   float   layer_norm_eps;  /* 1e-5 */
-  int32_t compute_dtype;   /* PLIPMI_F32 | PLIPMI_BF16 */
+  int32_t compute_dtype;   /* PLIPMI_F32 | PLIPMI_BF16 | PLIPMI_FP8W */
   int32_t max_batch;       /* images (and captions) per encode call the workspace is sized for */
 } plipmi_config;
 

@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libplipmi.so")
 
-F32, BF16 = 0, 1
+F32, BF16, FP8W = 0, 1, 2
 VISION, TEXT = 0, 1
 
 

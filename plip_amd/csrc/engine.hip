@@ -47,6 +47,8 @@ namespace {
 
 struct LayerW {
   void *wqkv, *wo, *w1, *w2;
+  void *wqkv8 = nullptr, *w18 = nullptr;  // fp8-weights mode: e4m3fn copies of the QKV / fc1 weights ...
+  float *sqkv = nullptr, *s1 = nullptr;   // ... and their per-output-channel scales
   float *bqkv, *bo, *b1, *b2, *ln1w, *ln1b, *ln2w, *ln2b;
 };
 struct Tower {
@@ -55,6 +57,8 @@ struct Tower {
   // workspace
   float* x = nullptr;
   void *h = nullptr, *qkv = nullptr, *att = nullptr, *mlp = nullptr;
+  void* h8 = nullptr;   // fp8-weights mode: LayerNorm output as fp8 rows ...
+  float* hs = nullptr;  // ... with one dynamic scale per row
 };
 struct ProfRec {
   const char* name;
@@ -68,6 +72,7 @@ struct plipmi_engine {
   plipmi_config cfg;
   int dtype = 0;
   size_t esz = 4;
+  bool fp8w = false;  // compute_dtype PLIPMI_FP8W: the bf16 engine with fp8 QKV / fc1 projections
   int np = 0, kpad = 0;
   Tower vis, txt;
   void* patch_w = nullptr;  // [Dv, kpad]
@@ -150,14 +155,21 @@ void carve(plipmi_engine* e, Carver& c) {
     const size_t D = t->D, F = t->F;
     t->layers.resize(t->L);
     for (LayerW& w : t->layers) {
-      w.wqkv = c.take<void>(3 * D * D, es); w.wo = c.take<void>(D * D, es);
-      w.w1 = c.take<void>(F * D, es);       w.w2 = c.take<void>(D * F, es);
+      w.wo = c.take<void>(D * D, es); w.w2 = c.take<void>(D * F, es);
+      if (e->fp8w) {
+        w.wqkv = nullptr; w.w1 = nullptr;
+        w.wqkv8 = c.take<void>(3 * D * D, 1); w.w18 = c.take<void>(F * D, 1);
+        w.sqkv = c.take<float>(3 * D, 4);     w.s1 = c.take<float>(F, 4);
+      } else {
+        w.wqkv = c.take<void>(3 * D * D, es); w.w1 = c.take<void>(F * D, es);
+      }
       w.bqkv = c.take<float>(3 * D, 4); w.bo = c.take<float>(D, 4); w.b1 = c.take<float>(F, 4); w.b2 = c.take<float>(D, 4);
       w.ln1w = c.take<float>(D, 4); w.ln1b = c.take<float>(D, 4); w.ln2w = c.take<float>(D, 4); w.ln2b = c.take<float>(D, 4);
     }
     const size_t M = B * t->S;
     t->x = c.take<float>(M * D, 4);
     t->h = c.take<void>(M * D, es);
+    if (e->fp8w) { t->h8 = c.take<void>(M * D, 1); t->hs = c.take<float>(M, 4); }
     t->qkv = c.take<void>(M * 3 * D, es);
     t->att = c.take<void>(M * D, es);
     t->mlp = c.take<void>(M * F, es);
@@ -171,15 +183,23 @@ int pack_tower(plipmi_engine* e, Tower& t, const plipmi_layer_weights* src, hipS
   for (int l = 0; l < t.L; ++l) {
     const plipmi_layer_weights& w = src[l];
     LayerW& d = t.layers[l];
-    char* wq = reinterpret_cast<char*>(d.wqkv);
-    HIP_TRY(launch_convert(w.q_w, wq, dt, D, D, D, qscale, s));
-    HIP_TRY(launch_convert(w.k_w, wq + (size_t)D * D * e->esz, dt, D, D, D, 1.f, s));
-    HIP_TRY(launch_convert(w.v_w, wq + (size_t)2 * D * D * e->esz, dt, D, D, D, 1.f, s));
+    if (e->fp8w) {
+      char* wq8 = reinterpret_cast<char*>(d.wqkv8);
+      HIP_TRY(launch_quantize_rows_fp8(w.q_w, wq8, d.sqkv, D, D, qscale, s));
+      HIP_TRY(launch_quantize_rows_fp8(w.k_w, wq8 + (size_t)D * D, d.sqkv + D, D, D, 1.f, s));
+      HIP_TRY(launch_quantize_rows_fp8(w.v_w, wq8 + (size_t)2 * D * D, d.sqkv + 2 * D, D, D, 1.f, s));
+      HIP_TRY(launch_quantize_rows_fp8(w.fc1_w, d.w18, d.s1, F, D, 1.f, s));
+    } else {
+      char* wq = reinterpret_cast<char*>(d.wqkv);
+      HIP_TRY(launch_convert(w.q_w, wq, dt, D, D, D, qscale, s));
+      HIP_TRY(launch_convert(w.k_w, wq + (size_t)D * D * e->esz, dt, D, D, D, 1.f, s));
+      HIP_TRY(launch_convert(w.v_w, wq + (size_t)2 * D * D * e->esz, dt, D, D, D, 1.f, s));
+      HIP_TRY(launch_convert(w.fc1_w, d.w1, dt, F, D, D, 1.f, s));
+    }
     HIP_TRY(launch_scale_copy(w.q_b, d.bqkv, D, qscale, s));
     HIP_TRY(launch_scale_copy(w.k_b, d.bqkv + D, D, 1.f, s));
     HIP_TRY(launch_scale_copy(w.v_b, d.bqkv + 2 * D, D, 1.f, s));
     HIP_TRY(launch_convert(w.o_w, d.wo, dt, D, D, D, 1.f, s));
-    HIP_TRY(launch_convert(w.fc1_w, d.w1, dt, F, D, D, 1.f, s));
     HIP_TRY(launch_convert(w.fc2_w, d.w2, dt, D, F, F, 1.f, s));
     HIP_TRY(launch_scale_copy(w.o_b, d.bo, D, 1.f, s));
     HIP_TRY(launch_scale_copy(w.fc1_b, d.b1, F, 1.f, s));
@@ -206,6 +226,19 @@ int run_gemm(plipmi_engine* e, int epi, const void* A, const void* W, void* C, c
   return PLIPMI_OK;
 }
 
+// fp8-weights mode: C(bf16) = epilogue(A8[M,K] . W8[N,K]^T * row_scale[m] * col_scale[n] + bias)
+int run_gemm_fp8(plipmi_engine* e, int epi, const void* A8, const float* row_scale, const void* W8, const float* col_scale,
+                 void* C, const float* bias, int M, int N, int K, hipStream_t s) {
+  GemmParams p;
+  p.A = A8; p.W = W8; p.C = C; p.bias = bias; p.row_scale = row_scale; p.col_scale = col_scale;
+  p.M = M; p.N = N; p.K = K; p.lda = K; p.ldw = K; p.ldc = N; p.alpha = 1.f; p.np = 1;
+  Scope sc(e, s, epi == EPI_BIAS ? "gemm_nt<fp8,256x256_w4x2_bufdma_spreadfill,bias>" : "gemm_nt<fp8,256x256_w4x2_bufdma_spreadfill,bias_qgelu>",
+           2.0 * M * N * (double)K, (double)M * K + (double)N * K + (double)M * N * 2);
+  const int rc = gemm_launch_fp8(epi, 3, p, s);
+  if (rc != 0) return fail(PLIPMI_ERR_HIP, "fp8 gemm launch (M=%d N=%d K=%d) failed: %s", M, N, K, hipGetErrorString((hipError_t)rc));
+  return PLIPMI_OK;
+}
+
 #define RUN(expr) do { int rc_ = (expr); if (rc_ != PLIPMI_OK) return rc_; } while (0)
 
 // n_layers pre-LN residual blocks over the tower's residual stream x (CLIPEncoderLayer, modeling_clip.py:362-383)
@@ -214,17 +247,29 @@ int run_layers(plipmi_engine* e, Tower& t, int B, int n_layers, int causal, cons
   const float eps = e->cfg.layer_norm_eps;
   for (int l = 0; l < n_layers; ++l) {
     const LayerW& w = t.layers[l];
-    { Scope sc(e, s, "layernorm", 0, (double)M * D * (4 + e->esz));
-      HIP_TRY(launch_layernorm(t.x, D, w.ln1w, w.ln1b, t.h, e->dtype, M, D, eps, s)); }
-    RUN(run_gemm(e, EPI_BIAS, t.h, w.wqkv, t.qkv, w.bqkv, M, 3 * D, D, 3 * D, 0, s));
+    if (e->fp8w) {
+      { Scope sc(e, s, "layernorm_fp8", 0, (double)M * D * 5);
+        HIP_TRY(launch_layernorm_fp8(t.x, D, w.ln1w, w.ln1b, t.h8, t.hs, M, D, eps, s)); }
+      RUN(run_gemm_fp8(e, EPI_BIAS, t.h8, t.hs, w.wqkv8, w.sqkv, t.qkv, w.bqkv, M, 3 * D, D, s));
+    } else {
+      { Scope sc(e, s, "layernorm", 0, (double)M * D * (4 + e->esz));
+        HIP_TRY(launch_layernorm(t.x, D, w.ln1w, w.ln1b, t.h, e->dtype, M, D, eps, s)); }
+      RUN(run_gemm(e, EPI_BIAS, t.h, w.wqkv, t.qkv, w.bqkv, M, 3 * D, D, 3 * D, 0, s));
+    }
     { const int impl = (&t == &e->vis) ? e->attn_impl_vis : e->attn_impl_txt;
       Scope sc(e, s, impl ? "attention_mfma" : "attention_valu", 4.0 * B * t.H * (double)t.S * t.S * 64,
                (double)M * 4 * D * e->esz);
       HIP_TRY(launch_attention(t.qkv, t.att, e->dtype, B, t.S, t.H, causal, key_mask, impl, s)); }
     RUN(run_gemm(e, EPI_BIAS_RESID, t.att, w.wo, t.x, w.bo, M, D, D, D, 0, s));
-    { Scope sc(e, s, "layernorm", 0, (double)M * D * (4 + e->esz));
-      HIP_TRY(launch_layernorm(t.x, D, w.ln2w, w.ln2b, t.h, e->dtype, M, D, eps, s)); }
-    RUN(run_gemm(e, EPI_BIAS_QGELU, t.h, w.w1, t.mlp, w.b1, M, F, D, F, 0, s));
+    if (e->fp8w) {
+      { Scope sc(e, s, "layernorm_fp8", 0, (double)M * D * 5);
+        HIP_TRY(launch_layernorm_fp8(t.x, D, w.ln2w, w.ln2b, t.h8, t.hs, M, D, eps, s)); }
+      RUN(run_gemm_fp8(e, EPI_BIAS_QGELU, t.h8, t.hs, w.w18, w.s1, t.mlp, w.b1, M, F, D, s));
+    } else {
+      { Scope sc(e, s, "layernorm", 0, (double)M * D * (4 + e->esz));
+        HIP_TRY(launch_layernorm(t.x, D, w.ln2w, w.ln2b, t.h, e->dtype, M, D, eps, s)); }
+      RUN(run_gemm(e, EPI_BIAS_QGELU, t.h, w.w1, t.mlp, w.b1, M, F, D, F, 0, s));
+    }
     RUN(run_gemm(e, EPI_BIAS_RESID, t.mlp, w.w2, t.x, w.b2, M, D, F, D, 0, s));
   }
   return PLIPMI_OK;
@@ -306,8 +351,8 @@ int plipmi_create(const plipmi_config* cfg, const plipmi_weights* w, void* strea
   if (!cfg || !w || !out) return fail(PLIPMI_ERR_INVALID, "null argument");
   *out = nullptr;
   const plipmi_config& g = *cfg;
-  if (g.compute_dtype != PLIPMI_F32 && g.compute_dtype != PLIPMI_BF16)
-    return fail(PLIPMI_ERR_INVALID, "compute_dtype must be PLIPMI_F32 or PLIPMI_BF16");
+  if (g.compute_dtype != PLIPMI_F32 && g.compute_dtype != PLIPMI_BF16 && g.compute_dtype != PLIPMI_FP8W)
+    return fail(PLIPMI_ERR_INVALID, "compute_dtype must be PLIPMI_F32, PLIPMI_BF16 or PLIPMI_FP8W");
   if (g.v_heads <= 0 || g.t_heads <= 0 || g.v_width != g.v_heads * 64 || g.t_width != g.t_heads * 64)
     return fail(PLIPMI_ERR_INVALID, "head_dim must be 64 (v_width=%d/%d heads, t_width=%d/%d heads)", g.v_width,
                 g.v_heads, g.t_width, g.t_heads);
@@ -328,10 +373,16 @@ int plipmi_create(const plipmi_config* cfg, const plipmi_weights* w, void* strea
   if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
     return fail(PLIPMI_ERR_NODEVICE, "device %d is %s; libplipmi is built for gfx950 only", dev, prop.gcnArchName);
 
+  if (g.compute_dtype == PLIPMI_FP8W) {
+    // the fp8 GEMM tiles are 256 columns wide and 128 K deep
+    if (g.v_width % 128 || g.t_width % 128 || (3 * g.v_width) % 256 || (3 * g.t_width) % 256 || g.v_mlp % 256 || g.t_mlp % 256)
+      return fail(PLIPMI_ERR_INVALID, "fp8-weights mode needs widths that are multiples of 128 with 3*width and the MLP width multiples of 256");
+  }
   plipmi_engine* e = new plipmi_engine();
   e->cfg = g;
-  e->dtype = g.compute_dtype;
-  e->esz = g.compute_dtype == PLIPMI_BF16 ? 2 : 4;
+  e->fp8w = g.compute_dtype == PLIPMI_FP8W;
+  e->dtype = e->fp8w ? PLIPMI_BF16 : g.compute_dtype;
+  e->esz = e->dtype == PLIPMI_BF16 ? 2 : 4;
   e->np = tokens - 1;
   e->kpad = (int)align_up((size_t)3 * g.patch_size * g.patch_size, 64);
   snprintf(e->devname, sizeof(e->devname), "%s:%s", prop.gcnArchName, prop.name);

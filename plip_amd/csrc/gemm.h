@@ -52,6 +52,9 @@ struct GemmParams {
   int lda, ldw, ldc;  // in elements
   float alpha;
   int np;             // patches per image (EPI_PATCH)
+  // fp8 operands only: C = acc * row_scale[m] * col_scale[n] (+ bias ...); nullptr = 1
+  const float* row_scale = nullptr;
+  const float* col_scale = nullptr;
   // Tile raster: the N tiles are cut in column groups `gw` tiles wide; logical tile ids run group by group,
   // M-major inside a group.  An XCD's contiguous id range is then a compact (rows x gw) patch whose W panels
   // (gw*BN rows of W) stay resident in its 4 MiB L2 while the A row panels stream through once.
@@ -657,8 +660,23 @@ void gemm_nt_kernel(const GemmParams p) {
       for (int q = 0; q < 4; ++q)
         bq[j][q] = *reinterpret_cast<const float4*>(p.bias + n0 + wn * TN + j * 32 + 8 * q + 4 * lgrp);
     const int hr_row = lane >> 3, hr_chunk = lane & 7;  // 8 lanes x 16 B = one 128-byte output row piece
+    const bool scaled = sizeof(T) == 1 && p.row_scale != nullptr && p.col_scale != nullptr;
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+    for (int i = 0; i < MI; ++i) {
+      if constexpr (sizeof(T) == 1) {
+        if (scaled) {  // dequantise: one scale per output row (this lane's row of the block) x one per column
+          const int mr = m0 + wm * TM + i * 32 + lrow;
+          const float sa = p.row_scale[mr < p.M ? mr : p.M - 1];
+#pragma unroll
+          for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const float4 sw = *reinterpret_cast<const float4*>(p.col_scale + n0 + wn * TN + j * 32 + 8 * q + 4 * lgrp);
+              acc[i][j][4 * q + 0] *= sa * sw.x; acc[i][j][4 * q + 1] *= sa * sw.y;
+              acc[i][j][4 * q + 2] *= sa * sw.z; acc[i][j][4 * q + 3] *= sa * sw.w;
+            }
+        }
+      }
 #pragma unroll
       for (int jp = 0; jp < NI / 2; ++jp) {
 #pragma unroll
@@ -693,6 +711,7 @@ void gemm_nt_kernel(const GemmParams p) {
         }
         __builtin_amdgcn_wave_barrier();
       }
+    }
     if (trace) {
       __builtin_amdgcn_s_waitcnt(0);
       if (tid == 0) trace[3] = __builtin_amdgcn_s_memtime();

@@ -12,6 +12,12 @@ hipError_t launch_layernorm(const float* x, size_t x_row_stride, const float* g,
                             int rows, int D, float eps, hipStream_t s);
 
 // pixels fp32 [B,3,H,W] -> patch rows [B*np, Kpad] (dtype), column (c,u,v), zero padded to Kpad.
+// fp8-weights engine: LayerNorm output as fp8 rows + one dynamic scale per row; weight rows -> fp8 + scale per row
+hipError_t launch_layernorm_fp8(const float* x, size_t x_row_stride, const float* g, const float* b, void* y_fp8,
+                                float* row_scale, int rows, int D, float eps, hipStream_t s);
+hipError_t launch_quantize_rows_fp8(const float* src, void* dst_fp8, float* scale, int rows, int cols, float pre,
+                                    hipStream_t s);
+
 hipError_t launch_unfold_patches(const float* pixels, void* out, int out_dtype, int B, int image, int patch, int Kpad,
                                  hipStream_t s);
 

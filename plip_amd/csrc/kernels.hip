@@ -101,6 +101,110 @@ __global__ __launch_bounds__(256) void layernorm_fixed_kernel(const float* x, si
   }
 }
 
+// ---------------------------------------------------------------------------------
+// fp8 (OCP e4m3fn) operand producers of the fp8-weights engine (plipmi compute_dtype 2):
+//   * LayerNorm rows quantised with one dynamic scale per row (amax / 448), the A operand of the QKV / fc1 GEMMs;
+//   * Linear weights quantised once at plipmi_create with one scale per output channel.
+// The GEMM epilogue multiplies the fp32 accumulator by row_scale[m] * col_scale[n].
+// ---------------------------------------------------------------------------------
+constexpr float kFp8Max = 448.0f;
+__device__ __forceinline__ unsigned pack4_fp8(float a, float b, float c, float d) {
+  int w = 0;
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+  return (unsigned)w;
+}
+__global__ __launch_bounds__(256) void layernorm_fp8_kernel(const float* __restrict__ x, size_t xs,
+                                                            const float* __restrict__ g, const float* __restrict__ b,
+                                                            unsigned char* __restrict__ y, float* __restrict__ row_scale,
+                                                            int rows, int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + (size_t)row * xs;
+  float4 v[kLnMaxVec];
+  float s = 0.f;
+#pragma unroll
+  for (int it = 0; it < kLnMaxVec; ++it) {
+    const int idx = it * 256 + lane * 4;
+    if (idx < D) {
+      v[it] = *reinterpret_cast<const float4*>(xr + idx);
+      s += (v[it].x + v[it].y) + (v[it].z + v[it].w);
+    }
+  }
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int it = 0; it < kLnMaxVec; ++it) {
+    const int idx = it * 256 + lane * 4;
+    if (idx < D) {
+      const float a = v[it].x - mean, c = v[it].y - mean, d = v[it].z - mean, e = v[it].w - mean;
+      q += (a * a + c * c) + (d * d + e * e);
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+  float amax = 0.f;
+#pragma unroll
+  for (int it = 0; it < kLnMaxVec; ++it) {
+    const int idx = it * 256 + lane * 4;
+    if (idx < D) {
+      const float4 gg = *reinterpret_cast<const float4*>(g + idx);
+      const float4 bb = *reinterpret_cast<const float4*>(b + idx);
+      v[it].x = (v[it].x - mean) * rstd * gg.x + bb.x; v[it].y = (v[it].y - mean) * rstd * gg.y + bb.y;
+      v[it].z = (v[it].z - mean) * rstd * gg.z + bb.z; v[it].w = (v[it].w - mean) * rstd * gg.w + bb.w;
+      amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v[it].x), fabsf(v[it].y))), fmaxf(fabsf(v[it].z), fabsf(v[it].w)));
+    }
+  }
+  amax = wave_max(amax);
+  const float scale = amax > 0.f ? amax / kFp8Max : 1.0f;
+  const float inv = 1.0f / scale;
+  unsigned char* yr = y + (size_t)row * D;
+#pragma unroll
+  for (int it = 0; it < kLnMaxVec; ++it) {
+    const int idx = it * 256 + lane * 4;
+    if (idx < D)
+      *reinterpret_cast<unsigned*>(yr + idx) = pack4_fp8(v[it].x * inv, v[it].y * inv, v[it].z * inv, v[it].w * inv);
+  }
+  if (lane == 0) row_scale[row] = scale;
+}
+hipError_t launch_layernorm_fp8(const float* x, size_t xs, const float* g, const float* b, void* y, float* row_scale,
+                                int rows, int D, float eps, hipStream_t s) {
+  if (rows <= 0) return hipSuccess;
+  if (D % 4 || D > kLnMaxVec * 256) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(layernorm_fp8_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, xs, g, b, (unsigned char*)y,
+                     row_scale, rows, D, eps);
+  return hipGetLastError();
+}
+
+// dst[r, :] = fp8(pre * src[r, :] / scale_r), scale_r = pre * amax_r / 448 (one wave per weight row)
+__global__ __launch_bounds__(256) void quantize_rows_fp8_kernel(const float* __restrict__ src, unsigned char* __restrict__ dst,
+                                                                float* __restrict__ scale, int rows, int cols, float pre) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* sr = src + (size_t)row * cols;
+  float amax = 0.f;
+  for (int c = lane * 4; c < cols; c += 256) {
+    const float4 v = *reinterpret_cast<const float4*>(sr + c);
+    amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
+  amax = wave_max(amax) * fabsf(pre);
+  const float sc = amax > 0.f ? amax / kFp8Max : 1.0f;
+  const float inv = pre / sc;
+  for (int c = lane * 4; c < cols; c += 256) {
+    const float4 v = *reinterpret_cast<const float4*>(sr + c);
+    *reinterpret_cast<unsigned*>(dst + (size_t)row * cols + c) = pack4_fp8(v.x * inv, v.y * inv, v.z * inv, v.w * inv);
+  }
+  if (lane == 0) scale[row] = sc;
+}
+hipError_t launch_quantize_rows_fp8(const float* src, void* dst, float* scale, int rows, int cols, float pre, hipStream_t s) {
+  if (rows <= 0) return hipSuccess;
+  if (cols % 4) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(quantize_rows_fp8_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, src, (unsigned char*)dst, scale,
+                     rows, cols, pre);
+  return hipGetLastError();
+}
+
 hipError_t launch_layernorm(const float* x, size_t xs, const float* g, const float* b, void* y, int y_dtype, int rows,
                             int D, float eps, hipStream_t s) {
   if (rows <= 0) return hipSuccess;

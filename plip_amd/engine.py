@@ -14,7 +14,9 @@ from . import _lib
 from .config import PlipConfig
 
 _DTYPES = {"fp32": _lib.F32, "f32": _lib.F32, "float32": _lib.F32, torch.float32: _lib.F32,
-           "bf16": _lib.BF16, "bfloat16": _lib.BF16, torch.bfloat16: _lib.BF16}
+           "bf16": _lib.BF16, "bfloat16": _lib.BF16, torch.bfloat16: _lib.BF16,
+           # experimental: bf16 engine with fp8 (e4m3fn) QKV / fc1 projections -- BASELINE configs[4] "fp8 MFMA weights"
+           "fp8": _lib.FP8W, "fp8w": _lib.FP8W}
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -37,7 +39,7 @@ class Engine:
         if self.device.index is None:
             self.device = torch.device("cuda", torch.cuda.current_device())
         self.dtype_code = _DTYPES[dtype]
-        self.dtype_name = "bf16" if self.dtype_code == _lib.BF16 else "f32"
+        self.dtype_name = {_lib.BF16: "bf16", _lib.F32: "f32", _lib.FP8W: "fp8w"}[self.dtype_code]
         self.max_batch = int(max_batch)
         self.lib = _lib.load()
         self._h = C.c_void_p()

@@ -260,6 +260,50 @@ def sec_fp8():
         print(f"{name:7s} {M}x{N}x{K} epi{epi}: " + "  ".join(row) + f"   bf16 auto {2.0 * M * N * K / ms / 1e9:7.1f} TFLOP/s")
 
 
+def sec_fp8w():
+    """EXPERIMENTAL fp8-weights engine (QKV + fc1 in fp8): error against the CPU oracle and tower throughput."""
+    from oracle import clip_oracle as O
+    for arch, B in (("tiny-w256", 6), ("ViT-B/32", 4)):
+        cfg = get_config(arch)
+        sd = W.synthetic_state_dict(cfg, 0)
+        px = W.synthetic_pixels(cfg, B, 1)
+        ids, mask = W.synthetic_ids(cfg, B, 2)
+        ref = O.clip_forward(px, ids, sd, cfg, mask)
+        scale = float(np.exp(np.float64(sd["logit_scale"])))
+        for dtype in ("bf16", "fp8"):
+            model = PlipModel(cfg, sd, dtype=dtype, max_batch=8)
+            out = model(input_ids=torch.from_numpy(ids), pixel_values=torch.from_numpy(px), attention_mask=torch.from_numpy(mask))
+            cos = np.abs(out.logits_per_image.cpu().numpy() - ref["logits_per_image"]).max() / scale
+            emb = max(np.abs(out.image_embeds.cpu().numpy() - ref["image_embeds"]).max(),
+                      np.abs(out.text_embeds.cpu().numpy() - ref["text_embeds"]).max())
+            print(f"{arch:10s} {dtype:5s}: cosine-logit max-abs-err {cos:.3e}   embedding component max-abs-err {emb:.3e}")
+            model.engine.close()
+    for arch, B in (("ViT-B/32", 256), ("ViT-L/14@336px", 32)):
+        cfg = get_config(arch)
+        sd = W.synthetic_state_dict(cfg, 0)
+        px = torch.from_numpy(W.synthetic_pixels(cfg, B, 1)).to(dev)
+        ids_np, mask_np = W.synthetic_ids(cfg, B, 2)
+        ids = torch.from_numpy(ids_np).to(dev)
+        for dtype in ("bf16", "fp8"):
+            model = PlipModel(cfg, sd, dtype=dtype, max_batch=B)
+            ms_i = _time(lambda: model.engine.encode_image(px), iters=5, warm=2)
+            ms_t = _time(lambda: model.engine.encode_text(ids, None), iters=5, warm=2)
+            print(f"{arch:16s} B={B} {dtype:5s}: image {ms_i:7.2f} ms ({B / ms_i * 1e3:8.0f} img/s, {cfg.image_flops() * B / ms_i / 1e9:6.1f} TF/s)   "
+                  f"text {ms_t:6.2f} ms ({B / ms_t * 1e3:8.0f} cap/s)")
+            if dtype == "fp8":
+                rows = []
+                with model.engine.profile(rows):
+                    model.engine.encode_image(px)
+                    torch.cuda.synchronize()
+                tot = sum(r["total_ms"] for r in rows)
+                for r in sorted(rows, key=lambda r: -r["total_ms"])[:6]:
+                    tf = f"{r['flops'] / r['total_ms'] / 1e9:7.1f} TF/s" if r["flops"] else ""
+                    print(f"      {r['name']:58s} {r['total_ms']:8.3f} ms {100 * r['total_ms'] / tot:5.1f}%  {tf}")
+            model.engine.close()
+            del model
+            torch.cuda.empty_cache()
+
+
 def sec_ldpad():
     """Does padding the leading dimension (rows no longer a multiple of 2 KB apart) change the fill rate?"""
     from plip_amd.engine import gemm_nt_ld
@@ -466,6 +510,6 @@ def sec_e2e():
 
 if __name__ == "__main__":
     t0 = time.time()
-    {"gemm": sec_gemm, "attn": sec_attn, "tiny": sec_tiny, "vitb32": sec_vitb32, "gemmbench": sec_gemmbench, "libgemm": sec_libgemm, "fp8": sec_fp8, "towerswap": sec_towerswap, "e2e": sec_e2e, "gemmone": sec_gemmone, "policy": sec_policy, "ldpad": sec_ldpad, "gemmtrace": sec_gemmtrace,
+    {"gemm": sec_gemm, "attn": sec_attn, "tiny": sec_tiny, "vitb32": sec_vitb32, "gemmbench": sec_gemmbench, "libgemm": sec_libgemm, "fp8": sec_fp8, "fp8w": sec_fp8w, "towerswap": sec_towerswap, "e2e": sec_e2e, "gemmone": sec_gemmone, "policy": sec_policy, "ldpad": sec_ldpad, "gemmtrace": sec_gemmtrace,
      "overlap": sec_overlap}[sys.argv[1]]()
     print(f"[{sys.argv[1]} done in {time.time() - t0:.1f} s]")
