@@ -33,6 +33,7 @@ static const GemmVariant kVariants[kNumVariants] = {
     {"192x256_w2x4_bufdma_fill3", 192, 256, 512, true},
     {"256x256_w4x2_bufdma_fragpipe", 256, 256, 512, true}, {"320x256_w2x4_bufdma", 320, 256, 512, true},
     {"192x256_w2x4_bufdma_fragpipe", 192, 256, 512, true}, {"128x128_w2x2_bufdma_fragpipe", 128, 128, 256, true},
+    {"256x256_w4x2_bufdma_fill2", 256, 256, 512, true},
 };
 
 int gemm_num_cus() {
@@ -81,7 +82,7 @@ int gemm_default_variant(int dtype, int M, int N, int K, int epi) {
   if (g_policy == 2 && dtype == 1 && N % 256 == 0) return (epi == EPI_BIAS_RESID || epi == EPI_PATCH) ? 37 : 36;
   const int cus = gemm_num_cus();
   struct Cand { int variant, bm, bn, per_cu; double rel; };
-  const Cand cands_bf16[] = {{35, 256, 256, 1, 1.00}, {36, 320, 256, 1, 1.00}, {37, 192, 256, 1, 1.05}, {41, 128, 128, 2, 1.21}};
+  const Cand cands_bf16[] = {{42, 256, 256, 1, 1.00}, {36, 320, 256, 1, 1.00}, {37, 192, 256, 1, 1.05}, {41, 128, 128, 2, 1.21}};
   const Cand cands_f32[] = {{38, 256, 256, 1, 1.00}, {39, 320, 256, 1, 1.00}, {40, 192, 256, 1, 1.05}, {41, 128, 128, 2, 1.21}};
   const Cand* cands = dtype == 1 ? cands_bf16 : cands_f32;
   int best = 41;
@@ -128,12 +129,12 @@ int gemm_launch(int dtype, int epi, int variant, const GemmParams& p, hipStream_
   if (variant == -1) variant = gemm_default_variant(dtype, p.M, p.N, p.K, epi);
   // the buffer-addressed kernels (35..41) carry 32-bit byte offsets: operands or outputs of 4 GiB and more take the
   // 64-bit-address twins
-  if (variant >= 35 && variant <= 41) {
+  if ((variant >= 35 && variant <= 41) || variant == 42) {
     const size_t es = dtype == 1 ? 2 : 4;
     const size_t out_rows = epi == EPI_PATCH ? (size_t)p.M + p.M / (p.np > 0 ? p.np : 1) + 1 : (size_t)p.M;
     const size_t span = std::max(std::max((size_t)p.M * p.lda * es, (size_t)p.N * p.ldw * es), out_rows * p.ldc * 4);
     if (span >= (1ull << 32)) {
-      static const int twin[7] = {32, 33, 34, 6, 26, 24, 8};
+      static const int twin[8] = {32, 33, 34, 6, 26, 24, 8, 29};
       variant = twin[variant - 35];
     }
   }

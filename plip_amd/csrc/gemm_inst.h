@@ -70,7 +70,7 @@ int launch_naive(const GemmParams& p, hipStream_t stream) {
   return (int)hipGetLastError();
 }
 
-constexpr int kNumVariants = 42;
+constexpr int kNumVariants = 43;
 
 // table[variant][epilogue]
 template <typename T>
@@ -120,6 +120,7 @@ struct GemmTable {
       case 39: return launch_tiled<T, 320, 256, 2, 4, EPI, true, 0, 0, 2, 1>;
       case 40: return launch_tiled<T, 192, 256, 2, 4, EPI, true, 1, 0, 2, 1>;
       case 41: return launch_tiled<T, 128, 128, 2, 2, EPI, true, 1, 0, 2, 1>;
+      case 42: return launch_tiled<T, 256, 256, 4, 2, EPI, true, 5, 0, 2, 1>;
       case -2: return launch_naive<T, EPI>;
       default: return nullptr;
     }
