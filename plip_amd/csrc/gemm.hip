@@ -80,6 +80,9 @@ int gemm_default_variant(int dtype, int M, int N, int K, int epi) {
   // Policy 2: as 1, but the fp32 residual epilogues take the 192x256 tile, whose register budget lets it request the
   // residual rows one block ahead (gemm.h kRowOperand).
   if (g_policy == 2 && dtype == 1 && N % 256 == 0) return (epi == EPI_BIAS_RESID || epi == EPI_PATCH) ? 37 : 36;
+  // Policy 3: as 2, with the 256x256 fill2 tile for the bias-only (QKV) epilogue
+  if (g_policy == 3 && dtype == 1 && N % 256 == 0)
+    return (epi == EPI_BIAS_RESID || epi == EPI_PATCH) ? 37 : (epi == EPI_BIAS ? 42 : 36);
   const int cus = gemm_num_cus();
   struct Cand { int variant, bm, bn, per_cu; double rel; };
   const Cand cands_bf16[] = {{42, 256, 256, 1, 1.00}, {36, 320, 256, 1, 1.00}, {37, 192, 256, 1, 1.05}, {41, 128, 128, 2, 1.21}};

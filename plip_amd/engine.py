@@ -168,7 +168,7 @@ class Engine:
         if not overlap:
             self.lib.plipmi_set_gemm_policy(0)
             return self.encode_image(pixels, normalize), self.encode_text(input_ids, attention_mask, normalize)
-        self.lib.plipmi_set_gemm_policy(getattr(self, "pair_policy", 2))  # co-scheduled towers: tile choice by bytes/FLOP, not by wave quantisation
+        self.lib.plipmi_set_gemm_policy(getattr(self, "pair_policy", 3))  # co-scheduled towers: tile choice by bytes/FLOP, not by wave quantisation
         try:
             return self._encode_pair_two_streams(pixels, input_ids, attention_mask, normalize)
         finally:
