@@ -49,7 +49,6 @@ __global__ __launch_bounds__(64 * KT) void attention_mfma_kernel(const bf16_t* _
   // fragment-shaped (16 B from each of 32 rows per instruction, which costs the texture-address unit 2x the
   // time for the same bytes); the LDS image uses the GEMM's XOR swizzle so the fragment ds_read_b128 are
   // conflict-free.  V keeps its row-major form (two [SP][32] images) and is transposed by the LDS read itself.
-  __shared__ __attribute__((aligned(16))) char Qs[SP * 128];
   __shared__ __attribute__((aligned(16))) char Ks[SP * 128];
   __shared__ __attribute__((aligned(16))) char Vs[2 * SP * 64];
   __shared__ unsigned long long mk[4];
@@ -71,27 +70,27 @@ __global__ __launch_bounds__(64 * KT) void attention_mfma_kernel(const bf16_t* _
     const int row = e >> 3, c = e & 7;
     const int rg = row < S ? row : S - 1;
     const bf16_t* src = base + (size_t)rg * ld + c * 8;
-    const u32x4 q16 = *reinterpret_cast<const u32x4*>(src);
     const u32x4 k16 = *reinterpret_cast<const u32x4*>(src + D);
     const u32x4 v16 = *reinterpret_cast<const u32x4*>(src + 2 * D);
     const int off = row * 128 + ((c ^ ((row >> 1) & 7)) << 4);
-    *reinterpret_cast<u32x4*>(Qs + off) = q16;
     *reinterpret_cast<u32x4*>(Ks + off) = k16;
     *reinterpret_cast<u32x4*>(Vs + (c >> 2) * (SP * 64) + row * 64 + (c & 3) * 16) = v16;
   }
-  __syncthreads();
-
   const int q0 = wave * 32;
-  if (q0 >= S) return;
+  const bool active = q0 < S;
   const int lrow = lane & 31, hi = lane >> 5;
   const int qidx = q0 + lrow;
   const int lsw = (lrow >> 1) & 7;
 
-  // Q fragments (B operand): Q[query = lrow][d = 16ks + 8hi .. +7]
+  // Q fragments (B operand) straight from global memory: Q[query = lrow][d = 16ks + 8hi .. +7].  Only this wave reads
+  // these rows, so an LDS image of Q would only cost residency (8-16 KB per workgroup = a third of its LDS).
   u32x4 qf[4];
+  {
+    const bf16_t* qrow = base + (size_t)(qidx < S ? qidx : S - 1) * ld;
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks)
-    qf[ks] = *reinterpret_cast<const u32x4*>(Qs + (q0 + lrow) * 128 + (((ks * 2 + hi) ^ lsw) << 4));
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const u32x4*>(qrow + (ks * 2 + hi) * 8);
+  }
+  __syncthreads();
 
   // scores^T tiles
   f32x16 sc[KT];
@@ -119,6 +118,8 @@ __global__ __launch_bounds__(64 * KT) void attention_mfma_kernel(const bf16_t* _
       rmax = fmaxf(rmax, sc[t][r]);
     }
   }
+  __syncthreads();  // every wave has its scores: the K rows may now be reused as output staging
+  if (!active) return;
   rmax = fmaxf(rmax, __shfl_xor(rmax, 32, 64));
   const float m_use = (rmax == -INFINITY) ? 0.f : rmax;
   float rsum = 0.f;
@@ -154,10 +155,10 @@ __global__ __launch_bounds__(64 * KT) void attention_mfma_kernel(const bf16_t* _
     }
   }
   // The accumulator layout gives a lane one query ROW (like the GEMM): write the normalised 32 x 64 bf16 tile
-  // into this wave's own (already consumed) Q rows of the LDS image, then store whole 128-byte rows.
+  // into the K rows of its own query range (every wave is past its scores), then store whole 128-byte rows.
   {
     const float inv = 1.0f / rsum;
-    char* orow_lds = Qs + (q0 + lrow) * 128;
+    char* orow_lds = Ks + (q0 + lrow) * 128;
     typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(64 * KT) void attention_mfma_kernel(const bf16_t* _
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int r = q0 + it * 8 + (lane >> 3);
-      const u32x4 v = *reinterpret_cast<const u32x4*>(Qs + r * 128 + ((c ^ ((r >> 1) & 7)) << 4));
+      const u32x4 v = *reinterpret_cast<const u32x4*>(Ks + r * 128 + ((c ^ ((r >> 1) & 7)) << 4));
       if (r < S) *reinterpret_cast<u32x4*>(out + ((size_t)b * S + r) * D + h * 64 + c * 8) = v;
     }
   }
