@@ -32,7 +32,15 @@ CASES = {
     "vitb32_b4": ("ViT-B/32", 4, 0, 1, 2, "eos", None),
     "vitb32_b3_zero_pad_ln100": ("ViT-B/32", 3, 7, 8, 9, "zero", LN100),
     "tinyp4_b3": ("tiny-p4", 3, 11, 12, 13, "eos", None),          # 257 vision tokens: chunked online-softmax attention
+    # BASELINE.json configs[2] at its real size: the very batch bench.py times on rank 0 (weights seed 0, pixels seed
+    # 1000, ids seed 2000), all 256 x 256 logits from HF itself.  Embeds + logits only (1.3 MB).
+    "vitb32_b256": ("ViT-B/32", 256, 0, 1000, 2000, "eos", None),
+    # trained-checkpoint-like statistics (weights.heavy_tailed_state_dict): outlier residual channels x30-100,
+    # LayerNorm gains over two decades, logit_scale = ln 100
+    "vitb32_b8_heavy": ("ViT-B/32", 8, 5, 31, 32, "eos", LN100),
 }
+# cases whose fixtures hold embeddings and logits only (no features of every row / hidden states)
+SLIM = {"vitb32_b256"}
 
 
 def fingerprint(sd) -> np.ndarray:
@@ -47,7 +55,10 @@ def case_inputs(name):
     cfg = get_config(arch)
     if not arch.startswith("tiny") and pad == "zero":
         cfg = cfg.replace(eos_token_id=2)       # OpenAI-clip / legacy-HF argmax pooling rule
-    sd = W.synthetic_state_dict(cfg, ws, logit_scale=ls)
+    if name.endswith("_heavy"):
+        sd = W.heavy_tailed_state_dict(cfg, ws, logit_scale=ls)
+    else:
+        sd = W.synthetic_state_dict(cfg, ws, logit_scale=ls)
     px = W.synthetic_pixels(cfg, B, ps)
     ids, mask = W.synthetic_ids(cfg.replace(eos_token_id=get_config(arch).eos_token_id), B, is_, pad=pad)
     return cfg, sd, px, ids, mask
@@ -60,12 +71,16 @@ def main(only=None):
         model = H.build_model(cfg, sd, "sdpa")
         # the OpenAI tokenizer gives no attention_mask: zero-pad cases run without one
         use_mask = None if "zero_pad" in name else mask
-        out = H.run(model, px, ids, use_mask, output_hidden_states=True)
-        save = {k: out[k] for k in ("image_features", "text_features", "image_embeds", "text_embeds",
-                                    "logits_per_image", "logits_per_text")}
+        slim = name in SLIM
+        out = H.run(model, px, ids, use_mask, output_hidden_states=not slim)
+        save = {k: out[k] for k in (("image_embeds", "text_embeds", "logits_per_image") if slim else
+                                    ("image_features", "text_features", "image_embeds", "text_embeds",
+                                     "logits_per_image", "logits_per_text"))}
         # hidden states: all of them for tiny; CLS / first-EOS rows for the full model (small files)
-        vh, th = out["vision_hidden"], out["text_hidden"]
-        if cfg.v_width <= 128 and cfg.v_tokens <= 64:
+        vh, th = (None, None) if slim else (out["vision_hidden"], out["text_hidden"])
+        if slim:
+            pass
+        elif cfg.v_width <= 128 and cfg.v_tokens <= 64:
             save["vision_hidden"] = np.stack(vh)
             save["text_hidden"] = np.stack(th)
         else:

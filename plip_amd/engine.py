@@ -218,25 +218,26 @@ class Engine:
                                             self._stream()), "plipmi_topk")
         return idx
 
-    def resize_crop_u8(self, images_u8: torch.Tensor) -> torch.Tensor:
+    def resize_crop_u8(self, images_u8: torch.Tensor, crop: str = "torchvision") -> torch.Tensor:
         """uint8 [B,H,W,3] images of one size -> uint8 [B,n,n,3] tiles at the model resolution: Pillow-exact bicubic
-        resize (shortest edge -> n) + centre crop on the GPU; feed the result to :meth:`encode_image_u8`."""
+        resize (shortest edge -> n) + centre crop on the GPU; feed the result to :meth:`encode_image_u8`.
+        ``crop`` = "torchvision" (OpenAI ``_transform``) or "hf" (``CLIPImageProcessor``), preprocess.crop_offset."""
         from .preprocess import resize_crop_plan
         n = self.cfg.image_size
         if images_u8.dim() != 4 or images_u8.shape[-1] != 3 or images_u8.dtype != torch.uint8:
             raise ValueError("expected uint8 [B,H,W,3]")
         B, H, Wd = int(images_u8.shape[0]), int(images_u8.shape[1]), int(images_u8.shape[2])
         cache = self.__dict__.setdefault("_resize_plans", {})
-        if (Wd, H) not in cache:
-            plan = resize_crop_plan(Wd, H, n)
+        if (Wd, H, crop) not in cache:
+            plan = resize_crop_plan(Wd, H, n, crop)
             dev = {k: (None if plan[k] is None else torch.from_numpy(plan[k]).to(self.device)) for k in ("xb", "xk", "yb", "yk")}
             if plan["yb"] is not None:
                 r0 = int(plan["yb"][:, 0].min())
                 r1 = int((plan["yb"][:, 0] + plan["yb"][:, 1]).max())
             else:
                 r0, r1 = plan["top"], plan["top"] + n
-            cache[(Wd, H)] = (plan, dev, r0, r1 - r0)
-        plan, dev, r0, R = cache[(Wd, H)]
+            cache[(Wd, H, crop)] = (plan, dev, r0, r1 - r0)
+        plan, dev, r0, R = cache[(Wd, H, crop)]
         with torch.cuda.device(self.device):
             src = images_u8.to(self.device).contiguous()
             tmp = torch.empty((B, R, n, 3), dtype=torch.uint8, device=self.device)

@@ -21,6 +21,10 @@ import torch
 from .model import PlipModel
 from .preprocess import load_tokenizer, preprocess_images
 
+# The top-level reference class preprocesses with HF ``CLIPProcessor`` (plip.py:27,35), whose centre crop starts at
+# ``(extent - n) // 2``; the reproducibility/ embedders use torchvision's rounding instead (preprocess.crop_offset).
+_CROP = "hf"
+
 
 def _native_u8_tiles(chunk, n_px):
     """uint8 HWC tiles that are already at the model resolution -> one [B,n,n,3] array, else None."""
@@ -62,18 +66,27 @@ def _uniform_u8_images(chunk, n_px):
 
 class PLIP:
     def __init__(self, model_name: str = None, auth_token=None, *, model: Optional[PlipModel] = None,
-                 tokenizer: Optional[Callable] = None, dtype: str = "bf16", max_batch: int = 256,
-                 device: str = "cuda:0"):
+                 tokenizer: Optional[Callable] = None, tokenizer_dir: Optional[str] = None, dtype: str = "bf16",
+                 max_batch: int = 256, device: str = "cuda:0"):
+        """``model_name``: local HF directory (what ``CLIPModel/CLIPProcessor.from_pretrained`` take, plip.py:26-27)
+        or an OpenAI-clip ``.pt`` state dict.  The tokenizer comes from ``tokenizer`` (a callable), else from
+        ``tokenizer_dir`` / the model directory when it holds ``vocab.json`` + ``merges.txt``; with neither,
+        ``encode_text`` still takes token ids."""
         if not torch.cuda.is_available():
             raise RuntimeError("plip_amd.PLIP needs an MI355X (ROCm) GPU; there is no CPU path")
         self.device = device
         self.model_name = model_name
+        if model is None and model_name is None:
+            raise ValueError("give a local checkpoint path (HF dir or OpenAI .pt) or a PlipModel")
+        if tokenizer is None:       # resolved BEFORE the engine is built: a bad tokenizer dir must not leak a handle
+            import os
+            cand = tokenizer_dir or (model_name if model_name and os.path.isdir(model_name) else None)
+            if tokenizer_dir is not None and not os.path.exists(os.path.join(tokenizer_dir, "vocab.json")):
+                raise FileNotFoundError(f"tokenizer_dir {tokenizer_dir!r} has no vocab.json / merges.txt")
+            if cand and os.path.exists(os.path.join(cand, "vocab.json")) and os.path.exists(os.path.join(cand, "merges.txt")):
+                tokenizer = load_tokenizer(cand)
         if model is None:
-            if model_name is None:
-                raise ValueError("give a local checkpoint path (HF dir or OpenAI .pt) or a PlipModel")
             model = PlipModel.from_pretrained(model_name, device=device, dtype=dtype, max_batch=max_batch)
-            if tokenizer is None:
-                tokenizer = load_tokenizer(model_name)
         self.model = model.to(self.device)
         self.tokenizer = tokenizer
         self.model_hash = hash            # the reference returns the builtin too (plip.py:29)
@@ -101,14 +114,14 @@ class PLIP:
                 same = _uniform_u8_images(chunk, n_px)
                 if same is not None:       # one size, not the model's: Pillow-exact resize + crop on the GPU as well
                     eng = self.model.engine
-                    outs.append(eng.encode_image_u8(eng.resize_crop_u8(torch.from_numpy(same))))
+                    outs.append(eng.encode_image_u8(eng.resize_crop_u8(torch.from_numpy(same), crop=_CROP)))
                     continue
                 if torch.is_tensor(chunk):
                     px = chunk
                 elif isinstance(chunk, np.ndarray) and chunk.dtype != np.uint8:
                     px = torch.from_numpy(chunk)
                 else:
-                    px = torch.from_numpy(preprocess_images(list(chunk), n_px))
+                    px = torch.from_numpy(preprocess_images(list(chunk), n_px, crop=_CROP))
                 outs.append(self.model.get_image_features(pixel_values=px))
         if not outs:
             return np.zeros((0, self.model.config.projection_dim), np.float32)
@@ -136,7 +149,7 @@ class PLIP:
             same = _uniform_u8_images(chunk, n_px)
             if same is not None:
                 return "resize", same
-            one = lambda im: preprocess_image(im, n_px)
+            one = lambda im: preprocess_image(im, n_px, _CROP)
             arrs = list(pool.map(one, chunk)) if pool is not None else [one(c) for c in chunk]
             return "pixels", np.stack(arrs)
 
@@ -144,7 +157,7 @@ class PLIP:
             if tag == "tiles":
                 return eng.encode_image_u8(t)
             if tag == "resize":
-                return eng.encode_image_u8(eng.resize_crop_u8(t))
+                return eng.encode_image_u8(eng.resize_crop_u8(t, crop=_CROP))
             return self.model.get_image_features(pixel_values=t)
 
         bs = min(int(batch_size), eng.max_batch)
@@ -185,6 +198,11 @@ class PLIP:
     # -- plip.py:78-87 -----------------------------------------------------------
     def _nearest_neighbours(self, k, key_vectors, space_vectors, normalize=True, debug=False):
         eng = self.model.engine
+        key_vectors, space_vectors = np.asarray(key_vectors), np.asarray(space_vectors)
+        # argsort()[:, -k:] hands back every column when k exceeds the corpus (plip.py:84): clamp instead of failing
+        k = max(0, min(int(k), space_vectors.shape[0]))
+        if k == 0 or key_vectors.shape[0] == 0:
+            return np.zeros((key_vectors.shape[0], k), np.int64)
         kv = torch.as_tensor(np.ascontiguousarray(key_vectors, dtype=np.float32)).to(eng.device)
         sv = torch.as_tensor(np.ascontiguousarray(space_vectors, dtype=np.float32)).to(eng.device)
         if normalize:

@@ -16,8 +16,21 @@ CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)   # transform.py:50
 CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
 
 
-def preprocess_image(img, n_px: int = 224) -> np.ndarray:
-    """PIL image / path / HWC uint8 array -> float32 [3, n_px, n_px]."""
+def crop_offset(extent: int, n_px: int, rule: str = "torchvision") -> int:
+    """First row/column of the centre crop.  The two preprocessing front ends of the reference disagree by one
+    pixel when the excess is odd: torchvision ``CenterCrop`` (OpenAI ``_transform``,
+    reproducibility/embedders/transform.py:47) uses ``int(round((extent - n) / 2.0))`` (round-half-to-even), HF
+    ``CLIPImageProcessor.center_crop`` behind ``self.preprocess`` (plip.py:27,35) uses ``(extent - n) // 2``."""
+    if rule == "hf":
+        return (extent - n_px) // 2
+    if rule == "torchvision":
+        return int(round((extent - n_px) / 2.0))
+    raise ValueError(f"unknown crop rule {rule!r} (expected 'hf' or 'torchvision')")
+
+
+def preprocess_image(img, n_px: int = 224, crop: str = "torchvision") -> np.ndarray:
+    """PIL image / path / HWC uint8 array -> float32 [3, n_px, n_px].  ``crop``: see :func:`crop_offset`
+    ("torchvision" = ``_transform`` of reproducibility/, "hf" = the ``CLIPProcessor`` of the top-level PLIP)."""
     from PIL import Image
     if isinstance(img, str):
         img = Image.open(img)
@@ -30,7 +43,7 @@ def preprocess_image(img, n_px: int = 224) -> np.ndarray:
         # torchvision Resize(int): shortest edge -> n_px, long edge int(n_px * long / short)
         nw, nh = (n_px, int(n_px * h / w)) if w == short else (int(n_px * w / h), n_px)
         img = img.resize((nw, nh), resample=Image.BICUBIC)
-        left, top = int(round((nw - n_px) / 2.0)), int(round((nh - n_px) / 2.0))
+        left, top = crop_offset(nw, n_px, crop), crop_offset(nh, n_px, crop)
         img = img.crop((left, top, left + n_px, top + n_px))
     x = np.asarray(img, dtype=np.float32) / np.float32(255.0)
     x = (x - np.asarray(CLIP_MEAN, dtype=np.float32)) / np.asarray(CLIP_STD, dtype=np.float32)
@@ -81,15 +94,16 @@ def resample_coeffs(in_size: int, out_size: int):
     return bounds, kk
 
 
-def resize_crop_plan(w: int, h: int, n_px: int = 224):
+def resize_crop_plan(w: int, h: int, n_px: int = 224, crop: str = "torchvision"):
     """Everything ``plipmi_resize_crop_u8`` needs for [h, w, 3] uint8 images: torchvision ``Resize(n_px)`` geometry
-    (shortest edge -> n_px, long edge ``int(n_px * long / short)``), centre-crop offsets, and the two coefficient
-    tables restricted to the crop window.  ``None`` entries mean that pass is an identity (Pillow skips it too)."""
+    (shortest edge -> n_px, long edge ``int(n_px * long / short)``; HF's ``get_resize_output_image_size`` gives the
+    same numbers), centre-crop offsets by ``crop`` rule (:func:`crop_offset`), and the two coefficient tables
+    restricted to the crop window.  ``None`` entries mean that pass is an identity (Pillow skips it too)."""
     short = min(w, h)
     nw, nh = (n_px, int(n_px * h / w)) if w == short else (int(n_px * w / h), n_px)
     if nw < n_px or nh < n_px:
         raise ValueError(f"image {w}x{h} is too small to crop {n_px}x{n_px} after the resize")
-    left, top = int(round((nw - n_px) / 2.0)), int(round((nh - n_px) / 2.0))
+    left, top = crop_offset(nw, n_px, crop), crop_offset(nh, n_px, crop)
     plan = dict(w=w, h=h, n_px=n_px, nw=nw, nh=nh, left=left, top=top, xb=None, xk=None, yb=None, yk=None)
     if nw != w:
         b, k = resample_coeffs(w, nw)
@@ -124,8 +138,8 @@ def resize_crop_reference(img_u8: np.ndarray, plan) -> np.ndarray:
     return out.astype(np.uint8)
 
 
-def preprocess_images(images: Sequence, n_px: int = 224) -> np.ndarray:
-    return np.stack([preprocess_image(i, n_px) for i in images]) if len(images) else \
+def preprocess_images(images: Sequence, n_px: int = 224, crop: str = "torchvision") -> np.ndarray:
+    return np.stack([preprocess_image(i, n_px, crop) for i in images]) if len(images) else \
         np.zeros((0, 3, n_px, n_px), np.float32)
 
 

@@ -122,6 +122,47 @@ def synthetic_state_dict(cfg: PlipConfig, seed: int = 0, logit_scale: float | No
     return out
 
 
+def heavy_tailed_state_dict(cfg: PlipConfig, seed: int = 0, logit_scale: float | None = None,
+                            n_outliers: int = 4) -> StateDict:
+    """``synthetic_state_dict`` reshaped to look like a TRAINED CLIP/PLIP checkpoint where it hurts low precision:
+
+    * ``n_outliers`` residual channels per tower carry values 30-100x the typical channel ("massive activations"):
+      constant offsets injected by the embeddings / ``pre_layrnorm.bias`` plus token-dependent ones from up-scaled
+      ``out_proj`` / ``fc2`` rows of those channels in the middle layers;
+    * LayerNorm gains of the blocks are log-uniform over two decades (0.1 .. 10) instead of 1 +- 0.1, and the gains
+      of the outlier channels are small (as trained models learn them), LayerNorm biases are 10x larger;
+    * ``logit_scale`` defaults to ln 100 (the trained value CLIP clamps to).
+
+    Deterministic (numpy ``RandomState``), generated THROUGH the same key order as ``synthetic_state_dict`` so the
+    two share everything else.  Used by the outlier-robustness parity case (tests/golden/vitb32_b8_heavy.npz)."""
+    sd = synthetic_state_dict(cfg, seed, math.log(100.0) if logit_scale is None else logit_scale)
+    rs = np.random.RandomState(seed + 7919)
+    for tower, D, L in (("vision_model", cfg.v_width, cfg.v_layers), ("text_model", cfg.t_width, cfg.t_layers)):
+        ch = rs.choice(D, size=n_outliers, replace=False)
+        amp = rs.uniform(30.0, 100.0, size=n_outliers).astype(np.float32) * rs.choice([-1.0, 1.0], size=n_outliers).astype(np.float32)
+        if tower == "vision_model":     # the stream enters the blocks right after pre_layrnorm: unit-scale channels
+            sd["vision_model.pre_layrnorm.bias"][ch] += amp
+            unit = 1.0
+        else:                            # token + position embeddings have std 0.02 each
+            unit = 0.03
+            sd["text_model.embeddings.position_embedding.weight"][:, ch] += amp * np.float32(unit)
+        for i in range(L):
+            p = f"{tower}.encoder.layers.{i}"
+            for ln in ("layer_norm1", "layer_norm2"):
+                g = np.exp(rs.uniform(np.log(0.1), np.log(10.0), size=D)).astype(np.float32)
+                g[ch] = rs.uniform(0.02, 0.1, size=n_outliers).astype(np.float32)
+                sd[f"{p}.{ln}.weight"] = g
+                sd[f"{p}.{ln}.bias"] = sd[f"{p}.{ln}.bias"] * np.float32(10.0)
+            if L // 3 <= i < 2 * L // 3 + 1:          # token-dependent outliers written by the middle blocks
+                sd[f"{p}.self_attn.out_proj.weight"][ch, :] *= np.float32(30.0)
+                sd[f"{p}.mlp.fc2.weight"][ch, :] *= np.float32(30.0)
+            # keep the pre-softmax scores O(1) under the wide gains (a trained model's q/k weights are matched to them)
+            for proj in ("q_proj", "k_proj", "v_proj"):
+                sd[f"{p}.self_attn.{proj}.weight"] *= np.float32(0.3)
+            sd[f"{p}.mlp.fc1.weight"] *= np.float32(0.3)
+    return sd
+
+
 def synthetic_pixels(cfg: PlipConfig, batch: int, seed: int = 1) -> np.ndarray:
     """fp32 [B,3,H,W] ~ N(0,1): the range of CLIP-normalised pixels."""
     rs = np.random.RandomState(seed)
@@ -297,10 +338,14 @@ def check_state_dict(sd: Mapping[str, np.ndarray], cfg: PlipConfig) -> None:
             raise ValueError(f"{k}: shape {tuple(np.shape(sd[k]))}, expected {tuple(shp)}")
 
 
-def load_checkpoint(path: str, arch: str | None = None):
+def load_checkpoint(path: str, arch: str | None = None, trust_pickle: bool = False):
     """Load real PLIP weights from disk: an HF directory (``config.json`` +
     ``model.safetensors`` / ``pytorch_model.bin``, what plip.py:26 pulls from the
-    hub) or an OpenAI-clip ``.pt`` state dict (factory.py:23-25)."""
+    hub) or an OpenAI-clip ``.pt`` state dict (factory.py:23-25).
+
+    ``.pt`` / ``.bin`` files are read with ``weights_only=True`` (tensors only: a plain state dict needs nothing
+    more).  Whole-model or TorchScript pickles execute code while loading; they are refused unless
+    ``trust_pickle=True`` (or ``PLIPMI_TRUST_PICKLE=1``) says the file comes from a trusted source."""
     import json
 
     import torch
@@ -322,7 +367,15 @@ def load_checkpoint(path: str, arch: str | None = None):
         from safetensors.numpy import load_file
         sd = load_file(path)
     else:
-        sd = torch.load(path, map_location="cpu", weights_only=False)
+        try:
+            sd = torch.load(path, map_location="cpu", weights_only=True)
+        except Exception as e:
+            if not (trust_pickle or os.environ.get("PLIPMI_TRUST_PICKLE") == "1"):
+                raise RuntimeError(
+                    f"{path} is not a plain tensor state dict ({type(e).__name__}: {str(e)[:200]}). Loading it needs full "
+                    "unpickling, which can run arbitrary code: pass trust_pickle=True / PLIPMI_TRUST_PICKLE=1 only for a "
+                    "file you trust, or re-save it as model.state_dict().") from e
+            sd = torch.load(path, map_location="cpu", weights_only=False)
         if hasattr(sd, "state_dict"):  # a whole pickled / jit OpenAI model
             sd = sd.state_dict()
         if isinstance(sd, dict) and "state_dict" in sd and "logit_scale" not in sd:

@@ -5,7 +5,9 @@ import pytest
 import torch
 
 from oracle import clip_oracle as O
-from oracle.make_golden import CASES, case_inputs
+from oracle.make_golden import CASES, SLIM, case_inputs
+
+FULL_CASES = [c for c in CASES if c not in SLIM]
 
 pytestmark = pytest.mark.gpu
 
@@ -29,7 +31,51 @@ def _cos_logits(d, sd):
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
-@pytest.mark.parametrize("name", list(CASES))
+def test_full_matrix_parity_bs256_vs_hf_golden(dtype, engines, golden):
+    """BASELINE.json configs[2] as stated: bs=256, ALL 256 x 256 logits_per_image against HF CLIPModel itself
+    (tests/golden/vitb32_b256.npz = oracle/make_golden.py on the batch bench.py times on rank 0)."""
+    g = golden("vitb32_b256")
+    model, cfg, sd, *_ = engines("vitb32_b4", dtype, 256)          # same weights (seed 0), workspace for 256
+    _, sd2, px, ids, mask = case_inputs("vitb32_b256")
+    np.testing.assert_array_equal(sd2["visual_projection.weight"], sd["visual_projection.weight"])
+    out = model(input_ids=torch.from_numpy(ids), pixel_values=torch.from_numpy(px), attention_mask=torch.from_numpy(mask))
+    t = TOL[dtype]
+    scale = np.exp(np.float64(sd["logit_scale"]))
+    got, want = out.logits_per_image.cpu().numpy() / scale, g["logits_per_image"] / scale
+    assert got.shape == (256, 256)
+    err = np.abs(got - want).max()
+    assert err < t["cos"], (dtype, err)
+    assert np.abs(out.image_embeds.cpu().numpy() - g["image_embeds"]).max() < t["emb"]
+    assert np.abs(out.text_embeds.cpu().numpy() - g["text_embeds"]).max() < t["emb"]
+    # arg-max per image over the 256 captions: identical wherever HF's winner leads by more than twice the tolerance
+    top2 = np.sort(want, axis=1)[:, -2:]
+    clear = (top2[:, 1] - top2[:, 0]) > 2 * t["cos"]
+    assert clear.sum() > 128
+    np.testing.assert_array_equal(got.argmax(1)[clear], want.argmax(1)[clear])
+    if dtype == "f32":
+        assert (got.argmax(1) == want.argmax(1)).mean() > 0.99
+
+
+def test_heavy_tailed_checkpoint_fp8_error_is_stated(engines, golden):
+    """The experimental fp8-weights mode on the heavy-tailed checkpoint (outlier channels x30-100, LayerNorm gains over
+    two decades): one fp8 scale per LayerNorm row is exactly what outliers break.  No parity credit is claimed for
+    it; the bound asserted here is the stated error (cosine logits), an order of magnitude above the bf16 bar."""
+    from plip_amd.model import PlipModel
+    g = golden("vitb32_b8_heavy")
+    cfg, sd, px, ids, mask = case_inputs("vitb32_b8_heavy")
+    model = PlipModel(cfg, sd, dtype="fp8", max_batch=8)
+    try:
+        out = model(input_ids=torch.from_numpy(ids), pixel_values=torch.from_numpy(px), attention_mask=torch.from_numpy(mask))
+        scale = np.exp(np.float64(sd["logit_scale"]))
+        err = np.abs(out.logits_per_image.cpu().numpy() - g["logits_per_image"]).max() / scale
+        print(f"fp8-weights engine, heavy-tailed checkpoint: cosine-logit max-abs-err {err:.2e}")
+        assert err < 3e-2, err
+    finally:
+        model.engine.close()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("name", FULL_CASES)
 def test_golden_features_and_logits(name, dtype, engines, golden):
     g = golden(name)
     model, cfg, sd, px, ids, mask = engines(name, dtype)
@@ -64,18 +110,31 @@ def test_hidden_states_layer_by_layer_tiny(dtype, engines, golden):
         assert np.abs((h - g["text_hidden"][layer]) * m).max() < t["hidden"], f"text layer {layer}"
 
 
+@pytest.mark.parametrize("name", ["vitb32_b4", "vitb32_b8_heavy"])
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
-def test_hidden_states_vitb32(dtype, engines, golden):
-    g = golden("vitb32_b4")
-    model, cfg, sd, px, ids, mask = engines("vitb32_b4", dtype)
+def test_hidden_states_vitb32(dtype, name, engines, golden):
+    """HF hidden_states of ViT-B/32 at layers 0, 1, 6, 12 (stored rows: CLS / last token, BOS / token 1).  Besides the
+    max-abs bound, the RELATIVE rms error per layer is bounded -- a systematic per-layer drift (a wrong residual
+    order, a dropped bias) grows that far beyond the bf16 rounding noise (4e-3 at depth 12 in the CPU emulation of the
+    precision plan, oracle/precision_model.py), while the max-abs bound alone would let it through."""
+    g = golden(name)
+    model, cfg, sd, px, ids, mask = engines(name, dtype)
     t = TOL[dtype]
+    rel_tol = 1.5e-2 if dtype == "bf16" else 2e-5
+
+    def check(got, want, what):
+        scale = max(1.0, float(np.abs(want).max()) / 4.0)            # heavy-tailed streams carry |x| ~ 100
+        assert np.abs(got - want).max() < t["hidden"] * 4 * scale, what
+        rel = np.sqrt(((got - want).astype(np.float64) ** 2).mean() / (want.astype(np.float64) ** 2).mean())
+        assert rel < rel_tol, (what, rel)
+
     for layer in (0, 1, 6, 12):
         h = model.engine.hidden("vision", layer, torch.from_numpy(px)).cpu().numpy()
-        assert np.abs(h[:, 0] - g["vision_hidden_cls"][layer]).max() < t["hidden"] * 4, f"vision layer {layer}"
-        assert np.abs(h[:, -1] - g["vision_hidden_last_token"][layer]).max() < t["hidden"] * 4
+        check(h[:, 0], g["vision_hidden_cls"][layer], f"vision layer {layer} cls")
+        check(h[:, -1], g["vision_hidden_last_token"][layer], f"vision layer {layer} last")
         h = model.engine.hidden("text", layer, torch.from_numpy(ids)).cpu().numpy()
-        assert np.abs(h[:, 0] - g["text_hidden_bos"][layer]).max() < t["hidden"] * 4, f"text layer {layer}"
-        assert np.abs(h[:, 1] - g["text_hidden_tok1"][layer]).max() < t["hidden"] * 4
+        check(h[:, 0], g["text_hidden_bos"][layer], f"text layer {layer} bos")
+        check(h[:, 1], g["text_hidden_tok1"][layer], f"text layer {layer} tok1")
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])

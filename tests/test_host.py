@@ -207,3 +207,82 @@ def test_resize_plan_rejects_images_that_cannot_be_cropped():
     plan = resize_crop_plan(640, 480, 224)
     assert (plan["nw"], plan["nh"], plan["left"], plan["top"]) == (298, 224, 37, 0) and plan["yb"].shape == (224, 2)
     assert resize_crop_plan(224, 224, 224)["xb"] is None and resize_crop_plan(224, 224, 224)["yb"] is None
+
+
+def test_crop_rules_match_their_front_ends():
+    """The two preprocessing front ends of the reference disagree by one pixel on odd excesses:
+    HF CLIPImageProcessor (top-level PLIP, plip.py:27,35) crops at (extent - n) // 2, torchvision CenterCrop (OpenAI
+    _transform, reproducibility/embedders/transform.py:47) at int(round((extent - n) / 2.0))."""
+    from PIL import Image
+    from plip_amd.preprocess import crop_offset, preprocess_image, resize_crop_plan, resize_crop_reference
+    assert [crop_offset(e, 224, "hf") for e in (224, 225, 227, 231, 298)] == [0, 0, 1, 3, 37]
+    assert [crop_offset(e, 224, "torchvision") for e in (224, 225, 227, 231, 298)] == [0, 0, 2, 4, 37]
+    with pytest.raises(ValueError):
+        crop_offset(230, 224, "middle")
+    transformers = pytest.importorskip("transformers")
+    proc = transformers.CLIPImageProcessor()
+    rs = np.random.RandomState(3)
+    for (w, h) in [(224, 224), (227, 224), (231, 224), (224, 231), (454, 448), (300, 225), (500, 375)]:
+        im = Image.fromarray(rs.randint(0, 256, (h, w, 3), dtype=np.uint8))
+        want = proc(images=im, return_tensors="np")["pixel_values"][0]
+        np.testing.assert_allclose(preprocess_image(im, 224, crop="hf"), want, rtol=0, atol=1e-6, err_msg=str((w, h)))
+        # the GPU resize path's integer plan, emulated: same pixels as Pillow under the same rule
+        plan = resize_crop_plan(w, h, 224, crop="hf")
+        u8 = resize_crop_reference(np.asarray(im), plan)
+        x = (u8.astype(np.float32) / np.float32(255.0) - np.asarray([0.48145466, 0.4578275, 0.40821073], np.float32)) / \
+            np.asarray([0.26862954, 0.26130258, 0.27577711], np.float32)
+        np.testing.assert_allclose(x.transpose(2, 0, 1), want, rtol=0, atol=1e-6)
+    odd = Image.fromarray(rs.randint(0, 256, (224, 227, 3), dtype=np.uint8))
+    assert np.abs(preprocess_image(odd, 224, crop="hf") - preprocess_image(odd, 224, crop="torchvision")).max() > 0.1
+
+
+def test_tokenizer_contract_on_synthetic_vocab(tmp_path):
+    """plip.py:56-60: ``self.preprocess(text=..., max_length=77, padding="max_length", truncation=True)``.  No CLIP
+    vocabulary is on disk, so a ~100-entry vocab.json / merges.txt in CLIP's format stands in (tests/helpers.py);
+    ``load_tokenizer`` must give BOS first, EOS right after the last token, EOS-padding to the context length,
+    truncation that keeps the EOS, and the matching attention mask -- what ``plipmi_encode_text`` pools on."""
+    pytest.importorskip("transformers")
+    from plip_amd.preprocess import load_tokenizer
+    from tests.helpers import write_tokenizer_fixture
+    write_tokenizer_fixture(str(tmp_path), 510, 511)
+    tok = load_tokenizer(str(tmp_path))
+    ids, mask = tok(["An image of the TUMOR cell", "a", "the " * 40], 16)
+    assert ids.shape == (3, 16) and ids.dtype == np.int64 and mask.dtype == np.int64
+    assert (ids[:, 0] == 510).all()
+    first_eos = (ids == 511).argmax(1)
+    np.testing.assert_array_equal(first_eos, [7, 2, 15])           # 6 word tokens, 1 token, truncated to 14 + BOS + EOS
+    np.testing.assert_array_equal(mask.sum(1), first_eos + 1)
+    for r in range(3):
+        assert (ids[r, first_eos[r]:] == 511).all()                # pad token == EOS
+    a, _ = tok(["an image of the tumor cell"], 16)
+    np.testing.assert_array_equal(a[0], ids[0])                    # lower-cased
+    ids77, _ = tok(["tumor"], 77)
+    assert ids77.shape == (1, 77)
+
+
+def test_load_checkpoint_refuses_code_carrying_pickles(tmp_path, monkeypatch):
+    """``.pt`` files load with weights_only=True; a pickle that needs code execution is refused unless trusted."""
+    import torch
+    cfg = get_config("tiny")
+    sd = W.synthetic_state_dict(cfg, 1)
+    plain = tmp_path / "plain.pt"
+    torch.save({k: torch.from_numpy(np.asarray(v)) for k, v in W.to_openai_state_dict(sd, cfg).items()}, plain)
+    got, gcfg = W.load_checkpoint(str(plain))
+    np.testing.assert_array_equal(got["visual_projection.weight"], sd["visual_projection.weight"])
+
+    class Holder:                       # a whole pickled object, as `torch.save(model)` produces
+        def __init__(self, d):
+            self.d = d
+
+        def state_dict(self):
+            return self.d
+    import tests.test_host as me        # picklable by reference
+    me.Holder = Holder
+    Holder.__module__, Holder.__qualname__ = "tests.test_host", "Holder"
+    whole = tmp_path / "whole.pt"
+    torch.save(Holder({k: torch.from_numpy(np.asarray(v)) for k, v in W.to_openai_state_dict(sd, cfg).items()}), whole)
+    monkeypatch.delenv("PLIPMI_TRUST_PICKLE", raising=False)
+    with pytest.raises(RuntimeError, match="trust_pickle"):
+        W.load_checkpoint(str(whole))
+    got2, _ = W.load_checkpoint(str(whole), trust_pickle=True)
+    np.testing.assert_array_equal(got2["visual_projection.weight"], sd["visual_projection.weight"])

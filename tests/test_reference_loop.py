@@ -1,0 +1,128 @@
+"""The reference's OWN host loops driven against the drop-in (SURVEY.md section 4 item 4, section 8b surface B1).
+
+/root/reference/plip.py:31-71 (``encode_images`` / ``encode_text``: ``datasets.Dataset`` -> ``DataLoader`` ->
+``self.preprocess(...)`` -> ``self.model.get_*_features(**batch).detach().cpu().numpy()``) is imported by path and run
+unmodified via ``object.__new__(PLIP)`` with ``self.model`` := ``plip_amd.model.PlipModel`` and ``self.preprocess`` :=
+``CLIPProcessor(CLIPImageProcessor(), CLIPTokenizer(<synthetic vocab>))`` (both construct offline).
+``PLIP.__init__`` itself cannot run under transformers 5.x (``use_auth_token`` kwarg, plip.py:26).
+
+* CPU variant (runs in the build container): the model is a real ``PlipModel`` whose engine is the oracle-backed
+  stand-in of tests/helpers.py, so what is under test is the HOST surface -- kwargs by name, ``.to(device)``, tensor
+  results, batch loop -- and ``plip_amd.PLIP``'s own loops against the reference's on identical inputs, including the
+  centre-crop rule on a 227 x 224 image.
+* GPU variant: the same loop against the MI355X engine.  It needs BOTH a GPU and /root/reference, which the GPU box
+  does not mount, so there it reports "skipped"; it runs wherever both exist.
+The reference's ``reproducibility`` ``CLIPEmbedder`` cannot be driven this way at all: it imports the OpenAI ``clip``
+package, which is not installed.
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests import helpers as Hh
+
+pytest.importorskip("datasets")
+pytestmark = pytest.mark.skipif(not Hh.reference_available(), reason="/root/reference is not mounted on this box")
+
+
+def _cfg():
+    from plip_amd.config import get_config
+    # what the reference hard-codes: 224-pixel processor output, max_length=77 (plip.py:58)
+    return get_config("tiny").replace(image_size=224, patch_size=32, context_length=77)
+
+
+def _images():
+    from PIL import Image
+    rs = np.random.RandomState(7)
+    sizes = [(224, 224), (227, 224), (224, 231), (300, 225), (224, 224)]      # (w, h); 227 / 231 hit the crop-rule seam
+    return [Image.fromarray(rs.randint(0, 256, (h, w, 3), dtype=np.uint8)) for (w, h) in sizes]
+
+
+def _processor(tmp_path):
+    from transformers import CLIPImageProcessor, CLIPProcessor, CLIPTokenizer
+    Hh.write_tokenizer_fixture(str(tmp_path), 510, 511)
+    tok = CLIPTokenizer.from_pretrained(str(tmp_path))
+    return CLIPProcessor(image_processor=CLIPImageProcessor(), tokenizer=tok), tok
+
+
+CAPTIONS = ["an image of the tumor cell", "the cell", "tumor", "an image of an image of the tumor"]
+
+
+def _reference_instance(model, processor, device):
+    ref_mod = Hh.load_reference_plip_module()
+    ref = object.__new__(ref_mod.PLIP)           # plip.py:14-18 without the hub download
+    ref.device = device
+    ref.model_name = "local"
+    ref.model, ref.preprocess, ref.model_hash = model, processor, hash
+    ref.model = ref.model.to(ref.device)         # plip.py:18
+    return ref
+
+
+def test_reference_host_loops_on_the_drop_in_model_cpu(tmp_path):
+    from oracle import clip_oracle as O
+    from plip_amd import weights as W
+    from plip_amd.plip import PLIP
+    from plip_amd.preprocess import load_tokenizer
+    cfg = _cfg()
+    sd = W.synthetic_state_dict(cfg, 2)
+    model = Hh.oracle_model(cfg, sd)
+    processor, tok = _processor(tmp_path)
+    ref = _reference_instance(model, processor, "cpu")
+    images = _images()
+
+    # --- the reference's loops, unmodified, on the drop-in model --------------------------------------------------
+    got_img = ref.encode_images(images, batch_size=2)                       # plip.py:31-53
+    got_txt = ref.encode_text(CAPTIONS, batch_size=3)                       # plip.py:55-71
+    assert got_img.shape == (5, cfg.projection_dim) and got_img.dtype == np.float32
+    assert got_txt.shape == (4, cfg.projection_dim) and got_txt.dtype == np.float32
+    # what those loops must have computed: HF preprocessing -> the towers, un-normalised
+    px = processor(images=images, return_tensors="np")["pixel_values"]
+    enc = tok(CAPTIONS, return_tensors="np", max_length=77, padding="max_length", truncation=True)
+    np.testing.assert_allclose(got_img, O.vision_tower(px, sd, cfg), rtol=0, atol=1e-6)
+    np.testing.assert_allclose(got_txt, O.text_tower(enc["input_ids"], sd, cfg, enc["attention_mask"]), rtol=0, atol=1e-6)
+    labels = CAPTIONS[:3]
+    ref_pred = ref.zero_shot_classification(images, labels)                 # plip.py:89-103
+    assert len(ref_pred) == 5 and set(ref_pred) <= set(labels)
+
+    # --- plip_amd.PLIP's loops on the same model + inputs: identical arrays, identical predictions -------------------
+    ours = object.__new__(PLIP)                  # the constructor insists on a GPU; the host loops do not need one
+    ours.device, ours.model_name, ours.model = "cpu", "local", model
+    ours.tokenizer = load_tokenizer(str(tmp_path))
+    ours.model_hash, ours.image_vectors = hash, None
+    model.engine.calls.clear()
+    mine_img = ours.encode_images(images, batch_size=2)
+    mine_txt = ours.encode_text(CAPTIONS, batch_size=3)
+    np.testing.assert_allclose(mine_img, got_img, rtol=0, atol=2e-6)        # incl. the 227 x 224 / 224 x 231 crops
+    np.testing.assert_allclose(mine_txt, got_txt, rtol=0, atol=1e-6)
+    assert ours.zero_shot_classification(images, labels) == ref_pred
+    kinds = {c[0] for c in model.engine.calls}
+    assert "encode_image_u8" in kinds            # native 224 x 224 tiles took the fused-normalisation route
+    np.testing.assert_allclose(ours._cosine_similarity(mine_img, mine_txt), ref._cosine_similarity(got_img, got_txt),
+                                rtol=0, atol=1e-5)
+    ours.image_vectors, ref.image_vectors = mine_img, got_img               # (the reference never assigns it: plip.py:114)
+    np.testing.assert_array_equal(ours.retrieval(CAPTIONS, top_k=3), ref.retrieval(CAPTIONS, top_k=3))
+    # k beyond the corpus: the reference's argsort()[:, -k:] hands back every column
+    assert ours.retrieval(CAPTIONS, top_k=10).shape == ref.retrieval(CAPTIONS, top_k=10).shape == (4, 5)
+
+
+@pytest.mark.gpu
+def test_reference_host_loops_on_the_mi355x_engine(tmp_path):
+    from oracle import clip_oracle as O
+    from plip_amd import weights as W
+    from plip_amd.model import PlipModel
+    cfg = _cfg()
+    sd = W.synthetic_state_dict(cfg, 2)
+    model = PlipModel(cfg, sd, dtype="f32", max_batch=8)
+    try:
+        processor, tok = _processor(tmp_path)
+        ref = _reference_instance(model, processor, "cuda")
+        images = _images()
+        got_img = ref.encode_images(images, batch_size=2)
+        got_txt = ref.encode_text(CAPTIONS, batch_size=3)
+        px = processor(images=images, return_tensors="np")["pixel_values"]
+        enc = tok(CAPTIONS, return_tensors="np", max_length=77, padding="max_length", truncation=True)
+        assert np.abs(got_img - O.vision_tower(px, sd, cfg)).max() < 2e-4
+        assert np.abs(got_txt - O.text_tower(enc["input_ids"], sd, cfg, enc["attention_mask"])).max() < 2e-4
+        assert len(ref.zero_shot_classification(images, CAPTIONS[:3])) == 5
+    finally:
+        model.engine.close()
