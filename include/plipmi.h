@@ -200,12 +200,17 @@ int plipmi_debug_hidden(plipmi_handle h, int tower, int layer, const void* input
 int plipmi_gemm_nt(int dtype, int epilogue, int variant, int M, int N, int K, const void* A, const void* W,
                    const float* bias, float alpha, void* C, void* stream);
 const char* plipmi_gemm_variant_name(int variant);
-/* force every GEMM of the process onto one tile variant (>= 0), or back to the engine's own choice (-1):
- * for in-process A/B runs (the environment variable PLIPMI_GEMM_VARIANT sets the same thing at start-up) */
+/* 1 if this build of the library carries `variant` for `dtype` (the default build holds the product tiles only;
+ * -DPLIPMI_ALL_VARIANTS adds the schedule experiments of round 1), else 0 */
+int plipmi_gemm_variant_built(int dtype, int variant);
+/* TEST / A-B HOOK, process-wide, not used by the product path: force every GEMM onto one tile variant (>= 0), or back
+ * to the engine's own choice (-1); the environment variable PLIPMI_GEMM_VARIANT sets the same thing at start-up */
 void plipmi_set_gemm_variant(int variant);
-/* tile policy of the engine's own choice: 0 = wave-quantisation cost model (kernels run one at a time),
- * 1 = the caller runs the two towers on two streams (idle CUs are filled by the other tower: largest tile wins) */
-void plipmi_set_gemm_policy(int policy);
+/* Tile policy of ONE handle's own choice (per-handle state, like everything else behind a handle):
+ * 0 = wave-quantisation cost model (its kernels own the GPU one at a time; the default),
+ * 1..3 = the caller runs the handle's two towers on two streams (idle CUs are filled by the other tower, so the tile
+ *        is fixed per epilogue instead: 3 = 256x256 for q/k/v, 320x256 for fc1, 192x256 for the residual epilogues) */
+int plipmi_set_gemm_policy(plipmi_handle h, int policy);
 /* same call with explicit leading dimensions (in elements) for A [M,K] and W [N,K]: rows may be padded */
 int plipmi_gemm_nt_ld(int dtype, int epilogue, int variant, int M, int N, int K, const void* A, int lda, const void* W,
                       int ldw, const float* bias, float alpha, void* C, void* stream);
@@ -213,6 +218,16 @@ int plipmi_gemm_nt_ld(int dtype, int epilogue, int variant, int M, int N, int K,
  * {start, prologue done, main loop done, epilogue done (s_memtime ticks), tile id, HW_ID|XCC_ID<<32, k tiles, 0} */
 int plipmi_gemm_nt_traced(int dtype, int epilogue, int variant, int M, int N, int K, const void* A, const void* W,
                           const float* bias, float alpha, void* C, uint64_t* trace, void* stream);
+
+/* Kernel-level entry for the LayerNorm-folded epilogues of the bf16 engine (gemm.h EPI_BIAS_LN / EPI_QGELU_LN /
+ * EPI_RESID_EMIT; A, W bf16 as raw uint16):
+ *   mode 0: C(bf16) = rstd[m] * (A.W^T - mean[m] * c1[n]) + bias[n]     mean / rstd from `stats` [M, ns, 2] fp32 =
+ *   mode 1: C(bf16) = quickgelu(that)                                   per-64-column partials {sum, centred M2} of the
+ *                                                                       LayerNorm input rows (D = 64 * ns), eps as given
+ *   mode 2: C(f32) += A.W^T + bias;  xb_out(bf16)[M,N] = C;  st_out [M, N/64, 2] = partials of the updated rows */
+int plipmi_gemm_nt_ln(int mode, int variant, int M, int N, int K, const void* A, const void* W, const float* bias,
+                      const float* c1, const float* stats, int ns, float eps, void* C, void* xb_out, float* st_out,
+                      void* stream);
 
 /* Kernel-level entry for the attention kernels: out[B*S, H*64] = softmax(q k^T + masks) v over the fused
  * activation qkv [B*S, 3*H*64] (q | k | v, 1/sqrt(64) already folded into q).

@@ -40,6 +40,20 @@ def _digest(paths) -> str:
     return h.hexdigest()
 
 
+def source_digest() -> str:
+    """sha256 (first 16 hex digits) over every kernel source and header of libplipmi.so: the identity of the code a
+    measurement was taken on.  bench.py stamps its line with it and refuses profiles/pmc_traffic.json when that file
+    was collected on different sources."""
+    paths = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hip"))]
+    paths.append(os.path.join(os.path.dirname(os.path.dirname(CSRC)), "include", "plipmi.h"))
+    h = hashlib.sha256()
+    for p in sorted(paths):
+        with open(p, "rb") as f:
+            h.update(os.path.basename(p).encode())
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def _compile(hipcc: str, src: str, obj: str) -> str:
     cmd = [hipcc, *FLAGS, "-I", CSRC, "-c", os.path.join(CSRC, src), "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)

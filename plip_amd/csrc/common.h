@@ -51,6 +51,57 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// Sum over the 16 lanes of a DPP row (lanes 16r .. 16r+15), result in every lane of the row: two quad
+// permutes, then row_half_mirror and row_mirror (after the quad steps every quad is uniform, so the mirrors act
+// as the 4- and 8-lane butterfly steps).  Pure VALU (no LDS crossbar, unlike __shfl_xor / ds_bpermute).
+// Call with all 64 lanes active.
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141>(v);  // row_half_mirror
+  v += dpp_mov<0x140>(v);  // row_mirror
+  return v;
+}
+
+// LayerNorm statistics travel as per-row PARTIALS over 64-column slices: {sum, M2 = sum (x - sum/64)^2}.  Folding
+// NS slices with Chan's update gives the row mean and the (biased) variance without ever forming E[x^2] - mean^2.
+constexpr int kLnSlice = 64;
+__device__ __forceinline__ void ln_combine(const float* __restrict__ st, int ns, float inv_d, float eps, float& mean,
+                                           float& rstd) {
+  // ns is even (widths are multiples of 128): two slices per 16-byte load, and all loads of a 16-slice batch are
+  // issued before the first is consumed (the folding itself is a short serial chain)
+  float n = 0.f, mu = 0.f, m2 = 0.f;
+  for (int j0 = 0; j0 < ns; j0 += 16) {
+    float4 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int j = j0 + 2 * k;
+      v[k] = j < ns ? *reinterpret_cast<const float4*>(st + 2 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (j0 + 2 * k < ns) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const float sj = h ? v[k].z : v[k].x, qj = h ? v[k].w : v[k].y;
+          const float mj = sj * (1.0f / kLnSlice);
+          const float nn = n + (float)kLnSlice;
+          const float d = mj - mu;
+          const float w = (float)kLnSlice / nn;
+          mu += d * w;
+          m2 += qj + d * d * n * w;
+          n = nn;
+        }
+      }
+    }
+  }
+  mean = mu;
+  rstd = 1.0f / sqrtf(m2 * inv_d + eps);
+}
+
 // QuickGELU: x * sigmoid(1.702 x)  (transformers/activations.py:117-123)
 // fp32 engine: libm exp + IEEE divide; bf16 engine: v_exp_f32 + v_rcp_f32 (1 ulp), far below bf16 rounding
 template <bool kAccurate> __device__ __forceinline__ float quick_gelu(float x) {

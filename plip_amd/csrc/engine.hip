@@ -50,6 +50,9 @@ struct LayerW {
   void *wqkv8 = nullptr, *w18 = nullptr;  // fp8-weights mode: e4m3fn copies of the QKV / fc1 weights ...
   float *sqkv = nullptr, *s1 = nullptr;   // ... and their per-output-channel scales
   float *bqkv, *bo, *b1, *b2, *ln1w, *ln1b, *ln2w, *ln2b;
+  // LayerNorm-folded engine: wqkv / w1 hold W * g (LayerNorm gain folded in), bqkv / b1 hold c2 = W b_ln + bias,
+  // and these are c1[n] = sum_k W'[n,k] (the coefficient of the row mean in the GEMM epilogue)
+  float *c1qkv = nullptr, *c1fc1 = nullptr;
 };
 struct Tower {
   int D = 0, F = 0, L = 0, H = 0, S = 0;
@@ -59,6 +62,11 @@ struct Tower {
   void *h = nullptr, *qkv = nullptr, *att = nullptr, *mlp = nullptr;
   void* h8 = nullptr;   // fp8-weights mode: LayerNorm output as fp8 rows ...
   float* hs = nullptr;  // ... with one dynamic scale per row
+  float* st = nullptr;  // LayerNorm-folded engine: statistics partials of the residual rows [M, D/64, 2]; h = bf16(x)
+};
+struct LnArgs {         // the LayerNorm side of a folded GEMM (gemm.h EPI_*_LN / EPI_RESID_EMIT)
+  const float* stats = nullptr; const float* c1 = nullptr; int ns = 0; float inv_d = 0.f, eps = 0.f;   // consumer
+  void* xb_out = nullptr; float* st_out = nullptr;                                                        // producer
 };
 struct ProfRec {
   const char* name;
@@ -73,6 +81,10 @@ struct plipmi_engine {
   int dtype = 0;
   size_t esz = 4;
   bool fp8w = false;  // compute_dtype PLIPMI_FP8W: the bf16 engine with fp8 QKV / fc1 projections
+  // bf16 engine: the 2 x L LayerNorms of the blocks are folded into the GEMMs around them (no LayerNorm pass, no
+  // normalised activations in memory); PLIPMI_LN_FOLD=0 restores the separate LayerNorm kernels for A/B runs
+  bool ln_fold = false;
+  int gemm_policy = 0;  // tile policy of this handle's GEMMs (plipmi_set_gemm_policy)
   int np = 0, kpad = 0;
   Tower vis, txt;
   void* patch_w = nullptr;  // [Dv, kpad]
@@ -164,12 +176,14 @@ void carve(plipmi_engine* e, Carver& c) {
         w.wqkv = c.take<void>(3 * D * D, es); w.w1 = c.take<void>(F * D, es);
       }
       w.bqkv = c.take<float>(3 * D, 4); w.bo = c.take<float>(D, 4); w.b1 = c.take<float>(F, 4); w.b2 = c.take<float>(D, 4);
+      if (e->ln_fold) { w.c1qkv = c.take<float>(3 * D, 4); w.c1fc1 = c.take<float>(F, 4); }
       w.ln1w = c.take<float>(D, 4); w.ln1b = c.take<float>(D, 4); w.ln2w = c.take<float>(D, 4); w.ln2b = c.take<float>(D, 4);
     }
     const size_t M = B * t->S;
     t->x = c.take<float>(M * D, 4);
     t->h = c.take<void>(M * D, es);
     if (e->fp8w) { t->h8 = c.take<void>(M * D, 1); t->hs = c.take<float>(M, 4); }
+    if (e->ln_fold) t->st = c.take<float>(M * (D / kLnSlice) * 2, 4);
     t->qkv = c.take<void>(M * 3 * D, es);
     t->att = c.take<void>(M * D, es);
     t->mlp = c.take<void>(M * F, es);
@@ -189,6 +203,13 @@ int pack_tower(plipmi_engine* e, Tower& t, const plipmi_layer_weights* src, hipS
       HIP_TRY(launch_quantize_rows_fp8(w.k_w, wq8 + (size_t)D * D, d.sqkv + D, D, D, 1.f, s));
       HIP_TRY(launch_quantize_rows_fp8(w.v_w, wq8 + (size_t)2 * D * D, d.sqkv + 2 * D, D, D, 1.f, s));
       HIP_TRY(launch_quantize_rows_fp8(w.fc1_w, d.w18, d.s1, F, D, 1.f, s));
+    } else if (e->ln_fold) {
+      // W' = bf16(W * g) (q rows also x 1/8), c1 = row sums of W', c2 = W b_ln + bias -> the bias slot
+      char* wq = reinterpret_cast<char*>(d.wqkv);
+      HIP_TRY(launch_fold_ln(w.q_w, w.q_b, w.ln1_w, w.ln1_b, wq, d.c1qkv, d.bqkv, D, D, qscale, s));
+      HIP_TRY(launch_fold_ln(w.k_w, w.k_b, w.ln1_w, w.ln1_b, wq + (size_t)D * D * e->esz, d.c1qkv + D, d.bqkv + D, D, D, 1.f, s));
+      HIP_TRY(launch_fold_ln(w.v_w, w.v_b, w.ln1_w, w.ln1_b, wq + (size_t)2 * D * D * e->esz, d.c1qkv + 2 * D, d.bqkv + 2 * D, D, D, 1.f, s));
+      HIP_TRY(launch_fold_ln(w.fc1_w, w.fc1_b, w.ln2_w, w.ln2_b, d.w1, d.c1fc1, d.b1, F, D, 1.f, s));
     } else {
       char* wq = reinterpret_cast<char*>(d.wqkv);
       HIP_TRY(launch_convert(w.q_w, wq, dt, D, D, D, qscale, s));
@@ -196,13 +217,15 @@ int pack_tower(plipmi_engine* e, Tower& t, const plipmi_layer_weights* src, hipS
       HIP_TRY(launch_convert(w.v_w, wq + (size_t)2 * D * D * e->esz, dt, D, D, D, 1.f, s));
       HIP_TRY(launch_convert(w.fc1_w, d.w1, dt, F, D, D, 1.f, s));
     }
-    HIP_TRY(launch_scale_copy(w.q_b, d.bqkv, D, qscale, s));
-    HIP_TRY(launch_scale_copy(w.k_b, d.bqkv + D, D, 1.f, s));
-    HIP_TRY(launch_scale_copy(w.v_b, d.bqkv + 2 * D, D, 1.f, s));
+    if (!e->ln_fold) {
+      HIP_TRY(launch_scale_copy(w.q_b, d.bqkv, D, qscale, s));
+      HIP_TRY(launch_scale_copy(w.k_b, d.bqkv + D, D, 1.f, s));
+      HIP_TRY(launch_scale_copy(w.v_b, d.bqkv + 2 * D, D, 1.f, s));
+      HIP_TRY(launch_scale_copy(w.fc1_b, d.b1, F, 1.f, s));
+    }
     HIP_TRY(launch_convert(w.o_w, d.wo, dt, D, D, D, 1.f, s));
     HIP_TRY(launch_convert(w.fc2_w, d.w2, dt, D, F, F, 1.f, s));
     HIP_TRY(launch_scale_copy(w.o_b, d.bo, D, 1.f, s));
-    HIP_TRY(launch_scale_copy(w.fc1_b, d.b1, F, 1.f, s));
     HIP_TRY(launch_scale_copy(w.fc2_b, d.b2, D, 1.f, s));
     HIP_TRY(launch_scale_copy(w.ln1_w, d.ln1w, D, 1.f, s));
     HIP_TRY(launch_scale_copy(w.ln1_b, d.ln1b, D, 1.f, s));
@@ -213,13 +236,20 @@ int pack_tower(plipmi_engine* e, Tower& t, const plipmi_layer_weights* src, hipS
 }
 
 int run_gemm(plipmi_engine* e, int epi, const void* A, const void* W, void* C, const float* bias, int M, int N, int K,
-             int ldc, int np, hipStream_t s) {
+             int ldc, int np, hipStream_t s, const LnArgs* ln = nullptr) {
   GemmParams p;
   p.A = A; p.W = W; p.C = C; p.bias = bias;
   p.M = M; p.N = N; p.K = K; p.lda = K; p.ldw = K; p.ldc = ldc; p.alpha = 1.f; p.np = np;
+  if (ln) {
+    p.ln_stats = ln->stats; p.ln_c1 = ln->c1; p.ln_ns = ln->ns; p.ln_inv_d = ln->inv_d; p.ln_eps = ln->eps;
+    p.xb_out = ln->xb_out; p.st_out = ln->st_out;
+  }
   const char* name = "gemm_nt";
-  Scope sc(e, s, name, 2.0 * M * N * (double)K, ((double)M * K + (double)N * K) * e->esz + (double)M * N * 4);
-  const int rc = gemm_launch(e->dtype, epi, -1, p, s, &name);
+  // algorithmic bytes: operands once, output once (bf16 outputs 2 B, fp32 residual read + written, + bf16 copy when emitted)
+  const double out_bytes = epi_is_colwise(epi) ? (double)M * N * e->esz
+                           : (double)M * N * (epi_is_resid(epi) ? 8.0 : 4.0) + (epi == EPI_RESID_EMIT ? (double)M * N * 2.0 : 0.0);
+  Scope sc(e, s, name, 2.0 * M * N * (double)K, ((double)M * K + (double)N * K) * e->esz + out_bytes);
+  const int rc = gemm_launch(e->dtype, epi, -1, p, s, &name, e->gemm_policy);
   sc.rename(name);
   if (rc != 0) return fail(PLIPMI_ERR_HIP, "gemm launch (%s, M=%d N=%d K=%d) failed: %s", name, M, N, K,
                            hipGetErrorString((hipError_t)rc));
@@ -245,6 +275,32 @@ int run_gemm_fp8(plipmi_engine* e, int epi, const void* A8, const float* row_sca
 int run_layers(plipmi_engine* e, Tower& t, int B, int n_layers, int causal, const int64_t* key_mask, hipStream_t s) {
   const int M = B * t.S, D = t.D, F = t.F;
   const float eps = e->cfg.layer_norm_eps;
+  const int impl = (&t == &e->vis) ? e->attn_impl_vis : e->attn_impl_txt;
+  auto attention = [&]() -> int {
+    Scope sc(e, s, impl ? "attention_mfma" : "attention_valu", 4.0 * B * t.H * (double)t.S * t.S * 64, (double)M * 4 * D * e->esz);
+    HIP_TRY(launch_attention(t.qkv, t.att, e->dtype, B, t.S, t.H, causal, key_mask, impl, s));
+    return PLIPMI_OK;
+  };
+  if (e->ln_fold) {
+    // LayerNorm never runs as a pass: t.h = bf16(x) and t.st = the rows' statistics partials arrive with x from its
+    // producer (embedding kernel, or the residual GEMM's epilogue); the consuming GEMMs carry LayerNorm's gain / bias in
+    // their weights and apply mean / rstd in their epilogues.  HF order (modeling_clip.py:370-381) is unchanged:
+    // x += out_proj(attn(LN1(x))); x += fc2(quick_gelu(fc1(LN2(x)))).
+    LnArgs use;  use.stats = t.st; use.ns = D / kLnSlice; use.inv_d = 1.0f / (float)D; use.eps = eps;
+    LnArgs emit; emit.xb_out = t.h; emit.st_out = t.st;
+    for (int l = 0; l < n_layers; ++l) {
+      const LayerW& w = t.layers[l];
+      use.c1 = w.c1qkv;
+      RUN(run_gemm(e, EPI_BIAS_LN, t.h, w.wqkv, t.qkv, w.bqkv, M, 3 * D, D, 3 * D, 0, s, &use));
+      RUN(attention());
+      RUN(run_gemm(e, EPI_RESID_EMIT, t.att, w.wo, t.x, w.bo, M, D, D, D, 0, s, &emit));
+      use.c1 = w.c1fc1;
+      RUN(run_gemm(e, EPI_QGELU_LN, t.h, w.w1, t.mlp, w.b1, M, F, D, F, 0, s, &use));
+      if (l + 1 < n_layers) RUN(run_gemm(e, EPI_RESID_EMIT, t.mlp, w.w2, t.x, w.b2, M, D, F, D, 0, s, &emit));
+      else RUN(run_gemm(e, EPI_BIAS_RESID, t.mlp, w.w2, t.x, w.b2, M, D, F, D, 0, s));   // nothing reads LN partials after the last block
+    }
+    return PLIPMI_OK;
+  }
   for (int l = 0; l < n_layers; ++l) {
     const LayerW& w = t.layers[l];
     if (e->fp8w) {
@@ -256,10 +312,7 @@ int run_layers(plipmi_engine* e, Tower& t, int B, int n_layers, int causal, cons
         HIP_TRY(launch_layernorm(t.x, D, w.ln1w, w.ln1b, t.h, e->dtype, M, D, eps, s)); }
       RUN(run_gemm(e, EPI_BIAS, t.h, w.wqkv, t.qkv, w.bqkv, M, 3 * D, D, 3 * D, 0, s));
     }
-    { const int impl = (&t == &e->vis) ? e->attn_impl_vis : e->attn_impl_txt;
-      Scope sc(e, s, impl ? "attention_mfma" : "attention_valu", 4.0 * B * t.H * (double)t.S * t.S * 64,
-               (double)M * 4 * D * e->esz);
-      HIP_TRY(launch_attention(t.qkv, t.att, e->dtype, B, t.S, t.H, causal, key_mask, impl, s)); }
+    RUN(attention());
     RUN(run_gemm(e, EPI_BIAS_RESID, t.att, w.wo, t.x, w.bo, M, D, D, D, 0, s));
     if (e->fp8w) {
       { Scope sc(e, s, "layernorm_fp8", 0, (double)M * D * 5);
@@ -288,6 +341,11 @@ int vision_embed(plipmi_engine* e, const float* pixels, const uint8_t* tiles_u8,
   { Scope sc(e, s, "cls_rows", 0, (double)B * t.D * 4);
     HIP_TRY(launch_cls_rows(e->cls, e->vpos, t.x, B, t.S, t.D, s)); }
   RUN(run_gemm(e, EPI_PATCH, e->patches, e->patch_w, t.x, e->vpos, B * e->np, t.D, e->kpad, t.D, e->np, s));
+  if (e->ln_fold) {   // the tower's one LayerNorm pass; it also hands the first block bf16(x) and the row statistics
+    Scope sc(e, s, "layernorm", 0, (double)B * t.S * t.D * 10.2);
+    HIP_TRY(launch_layernorm_emit(t.x, e->pre_w, e->pre_b, t.h, t.st, B * t.S, t.D, g.layer_norm_eps, s));
+    return PLIPMI_OK;
+  }
   { Scope sc(e, s, "layernorm", 0, (double)B * t.S * t.D * 8);
     HIP_TRY(launch_layernorm(t.x, t.D, e->pre_w, e->pre_b, t.x, 0, B * t.S, t.D, g.layer_norm_eps, s)); }
   return PLIPMI_OK;
@@ -295,13 +353,15 @@ int vision_embed(plipmi_engine* e, const float* pixels, const uint8_t* tiles_u8,
 
 int text_embed(plipmi_engine* e, const int64_t* ids, int B, hipStream_t s) {
   Tower& t = e->txt;
-  Scope sc(e, s, "text_embed", 0, (double)B * t.S * t.D * 8);
-  HIP_TRY(launch_text_embed(ids, e->tok, e->tpos, t.x, B, t.S, t.D, e->cfg.vocab_size, s));
+  Scope sc(e, s, "text_embed", 0, (double)B * t.S * t.D * (e->ln_fold ? 10.2 : 8.0));
+  if (e->ln_fold) HIP_TRY(launch_text_embed_emit(ids, e->tok, e->tpos, t.x, t.h, t.st, B, t.S, t.D, e->cfg.vocab_size, s));
+  else HIP_TRY(launch_text_embed(ids, e->tok, e->tpos, t.x, B, t.S, t.D, e->cfg.vocab_size, s));
   return PLIPMI_OK;
 }
 
-// pooled row -> LayerNorm -> bias-free projection (-> L2 normalise).  Real heads (P % 128 == 0) run the
-// projection on the exact-fp32 MFMA GEMM; other widths use the fused one-block-per-sample kernel.
+// pooled row -> LayerNorm -> bias-free projection (-> L2 normalise).  Widths that are multiples of 32 (every
+// config plipmi_create accepts today) run the projection on the split-K exact-fp32 MFMA head kernel; the fused
+// one-block-per-sample kernel covers anything else.
 int run_head(plipmi_engine* e, Tower& t, const int64_t* ids, int eos_id, const float* ln_w, const float* ln_b,
              const float* W, const float* Wt, float* pooled, float* out, int B, int normalize, hipStream_t s) {
   const int P = e->cfg.projection_dim, D = t.D;
@@ -310,20 +370,6 @@ int run_head(plipmi_engine* e, Tower& t, const int64_t* ids, int eos_id, const f
       HIP_TRY(launch_pool_layernorm(t.x, t.S, D, ids, eos_id, ln_w, ln_b, e->cfg.layer_norm_eps, pooled, B, s)); }
     { Scope sc(e, s, "head_gemm", 2.0 * B * P * (double)D, ((double)B * D + (double)P * D + (double)B * P) * 4);
       HIP_TRY(launch_head_gemm(pooled, W, out, B, P, D, s)); }
-    if (normalize) { Scope sc(e, s, "l2_normalize", 0, (double)B * P * 8); HIP_TRY(launch_l2_normalize(out, B, P, s)); }
-    return PLIPMI_OK;
-  }
-  if (P % 128 == 0) {
-    { Scope sc(e, s, "pool_layernorm", 0, (double)B * D * 8);
-      HIP_TRY(launch_pool_layernorm(t.x, t.S, D, ids, eos_id, ln_w, ln_b, e->cfg.layer_norm_eps, pooled, B, s)); }
-    GemmParams p;
-    p.A = pooled; p.W = W; p.C = out; p.bias = nullptr; p.M = B; p.N = P; p.K = D; p.lda = D; p.ldw = D; p.ldc = P;
-    p.alpha = 1.f; p.np = 1;
-    const char* name = "gemm_nt";
-    { Scope sc(e, s, name, 2.0 * B * P * (double)D, ((double)B * D + (double)P * D + (double)B * P) * 4);
-      const int rc = gemm_launch(PLIPMI_F32, EPI_SCALE, 1, p, s, &name);
-      sc.rename(name);
-      if (rc != 0) return fail(PLIPMI_ERR_HIP, "projection gemm failed: %s", hipGetErrorString((hipError_t)rc)); }
     if (normalize) { Scope sc(e, s, "l2_normalize", 0, (double)B * P * 8); HIP_TRY(launch_l2_normalize(out, B, P, s)); }
     return PLIPMI_OK;
   }
@@ -383,6 +429,8 @@ int plipmi_create(const plipmi_config* cfg, const plipmi_weights* w, void* strea
   e->fp8w = g.compute_dtype == PLIPMI_FP8W;
   e->dtype = e->fp8w ? PLIPMI_BF16 : g.compute_dtype;
   e->esz = e->dtype == PLIPMI_BF16 ? 2 : 4;
+  { const char* lf = getenv("PLIPMI_LN_FOLD");
+    e->ln_fold = e->dtype == PLIPMI_BF16 && !e->fp8w && !(lf && atoi(lf) == 0); }
   e->np = tokens - 1;
   e->kpad = (int)align_up((size_t)3 * g.patch_size * g.patch_size, 64);
   snprintf(e->devname, sizeof(e->devname), "%s:%s", prop.gcnArchName, prop.name);
@@ -509,6 +557,20 @@ int plipmi_logits(plipmi_handle h, const float* img, int Ni, const float* txt, i
                   float* logits_per_image, float* logits_per_text, int32_t* argmax_per_image, void* stream) {
   if (!h || !img || !txt || !logits_per_image || Ni < 0 || Nt < 0 || D <= 0) return fail(PLIPMI_ERR_INVALID, "bad argument");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (Ni == 0 || Nt == 0) return PLIPMI_OK;
+  // Exact-fp32 MFMA whenever the shape tiles (the bs=256 logits of CLIPModel.forward do): one 32x32 tile per workgroup,
+  // K split over its four waves.  logits_per_text is the same kernel with the operands exchanged -- products commute
+  // and the k order is identical, so it is bit-for-bit the transpose.  Other shapes (e.g. 10 class prompts) take the
+  // scalar-FMA kernel.
+  if (D % 32 == 0 && Nt % 32 == 0 && (!logits_per_text || Ni % 32 == 0) && (size_t)Ni * Nt <= (1u << 22)) {
+    { Scope sc(h, s, "logits_mfma", 2.0 * Ni * (double)Nt * D, ((double)Ni + Nt) * D * 4 + (double)Ni * Nt * 4);
+      HIP_TRY(launch_head_gemm(img, txt, logits_per_image, Ni, Nt, D, s, scale)); }
+    if (logits_per_text) {
+      Scope sc(h, s, "logits_mfma", 2.0 * Ni * (double)Nt * D, ((double)Ni + Nt) * D * 4 + (double)Ni * Nt * 4);
+      HIP_TRY(launch_head_gemm(txt, img, logits_per_text, Nt, Ni, D, s, scale)); }
+    if (argmax_per_image) { Scope sc(h, s, "row_argmax", 0, (double)Ni * Nt * 4); HIP_TRY(launch_row_argmax(logits_per_image, Ni, Nt, argmax_per_image, s)); }
+    return PLIPMI_OK;
+  }
   Scope sc(h, s, "logits", 2.0 * Ni * (double)Nt * D, ((double)Ni + Nt) * D * 4 + (double)Ni * Nt * 4);
   HIP_TRY(launch_logits(img, Ni, txt, Nt, D, scale, logits_per_image, logits_per_text, argmax_per_image, s));
   return PLIPMI_OK;
@@ -628,6 +690,23 @@ int plipmi_gemm_nt_traced(int dtype, int epilogue, int variant, int M, int N, in
   return PLIPMI_OK;
 }
 
+int plipmi_gemm_nt_ln(int mode, int variant, int M, int N, int K, const void* A, const void* W, const float* bias,
+                      const float* c1, const float* stats, int ns, float eps, void* C, void* xb_out, float* st_out,
+                      void* stream) {
+  if (mode < 0 || mode > 2 || M < 0 || N <= 0 || K <= 0 || !A || !W || !C || !bias) return fail(PLIPMI_ERR_INVALID, "bad argument");
+  if (mode < 2 && (!c1 || !stats || ns <= 0)) return fail(PLIPMI_ERR_INVALID, "mode 0/1 need c1 and stats");
+  if (mode == 2 && (!xb_out || !st_out || N % kLnSlice)) return fail(PLIPMI_ERR_INVALID, "mode 2 needs xb_out, st_out and N % 64 == 0");
+  GemmParams p;
+  p.A = A; p.W = W; p.C = C; p.bias = bias; p.M = M; p.N = N; p.K = K; p.lda = K; p.ldw = K; p.ldc = N; p.alpha = 1.f; p.np = 1;
+  p.ln_stats = stats; p.ln_c1 = c1; p.ln_ns = ns; p.ln_inv_d = ns > 0 ? 1.0f / (float)(ns * kLnSlice) : 0.f; p.ln_eps = eps;
+  p.xb_out = xb_out; p.st_out = st_out;
+  const int epi = mode == 0 ? EPI_BIAS_LN : mode == 1 ? EPI_QGELU_LN : EPI_RESID_EMIT;
+  const int rc = gemm_launch(PLIPMI_BF16, epi, variant, p, reinterpret_cast<hipStream_t>(stream), nullptr);
+  if (rc != 0) return fail(PLIPMI_ERR_HIP, "gemm launch failed (LN mode %d, variant %d, M=%d N=%d K=%d): %s", mode, variant, M, N, K,
+                           hipGetErrorString((hipError_t)rc));
+  return PLIPMI_OK;
+}
+
 int plipmi_attention(int dtype, int impl, const void* qkv, void* out, int B, int S, int H, int causal,
                      const int64_t* key_mask, void* stream) {
   if ((dtype != PLIPMI_F32 && dtype != PLIPMI_BF16) || !qkv || !out || B < 0 || S <= 0 || H <= 0)
@@ -655,7 +734,16 @@ int plipmi_gemm_nt_ld(int dtype, int epilogue, int variant, int M, int N, int K,
 }
 
 void plipmi_set_gemm_variant(int variant) { gemm_set_default_override(variant); }
-void plipmi_set_gemm_policy(int policy) { gemm_set_policy(policy); }
+int plipmi_set_gemm_policy(plipmi_handle h, int policy) {
+  if (!h) return fail(PLIPMI_ERR_INVALID, "null handle");
+  if (policy < 0 || policy > 3) return fail(PLIPMI_ERR_INVALID, "policy must be 0..3");
+  h->gemm_policy = policy;
+  return PLIPMI_OK;
+}
+int plipmi_gemm_variant_built(int dtype, int variant) {
+  if (dtype != PLIPMI_F32 && dtype != PLIPMI_BF16) return 0;
+  return gemm_variant_is_built(dtype, variant) ? 1 : 0;
+}
 
 const char* plipmi_gemm_variant_name(int variant) {
   if (variant < 0 || variant >= gemm_num_variants()) return nullptr;

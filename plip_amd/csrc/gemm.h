@@ -40,8 +40,20 @@ enum Epilogue : int {
   EPI_BIAS_RESID = 2,  // C(f32) += acc + bias[n]            (in-place residual stream)
   EPI_SCALE = 3,       // C(f32) = alpha * acc
   EPI_PATCH = 4,       // C(f32)[img*(np+1)+1+p, n] = acc + pos[(1+p), n]   (m = img*np + p)
-  EPI_COUNT = 5
+  // LayerNorm folded into the GEMMs on either side of it (bf16 engine; modeling_clip.py:370-381: LN -> Linear):
+  //   the Linear's weights carry LayerNorm's gain (W' = W * g), its bias carries LayerNorm's bias (c2 = W b + bias),
+  //   the A operand is the bf16 residual stream itself, and the row statistics enter in the epilogue:
+  //   y = rstd[m] * (acc - mean[m] * c1[n]) + c2[n],  c1[n] = sum_k W'[n,k]
+  EPI_BIAS_LN = 5,     // C(bf16) = that                                   (LN1 -> q/k/v)
+  EPI_QGELU_LN = 6,    // C(bf16) = quickgelu(that)                        (LN2 -> fc1)
+  // ... and the producer of the NEXT LayerNorm's input: the in-place residual update also emits the bf16 copy of the
+  // new rows (the next GEMM's A operand) and their statistics as per-64-column partials {sum, centred M2}
+  EPI_RESID_EMIT = 7,  // C(f32) += acc + bias[n];  xb(bf16) = C;  st[m, n/64] = {sum, M2}
+  EPI_COUNT = 8
 };
+constexpr bool epi_is_ln(int e) { return e == EPI_BIAS_LN || e == EPI_QGELU_LN; }
+constexpr bool epi_is_colwise(int e) { return e == EPI_BIAS || e == EPI_BIAS_QGELU || epi_is_ln(e); }
+constexpr bool epi_is_resid(int e) { return e == EPI_BIAS_RESID || e == EPI_RESID_EMIT; }
 
 struct GemmParams {
   const void* A;
@@ -55,6 +67,15 @@ struct GemmParams {
   // fp8 operands only: C = acc * row_scale[m] * col_scale[n] (+ bias ...); nullptr = 1
   const float* row_scale = nullptr;
   const float* col_scale = nullptr;
+  // EPI_*_LN consumers: per-row statistics partials [M, ln_ns, 2] fp32 over 64-column slices of the LayerNorm input
+  // (ln_combine), c1 [N] fp32 (bias carries c2), 1/D and eps of that LayerNorm
+  const float* ln_stats = nullptr;
+  const float* ln_c1 = nullptr;
+  int ln_ns = 0;
+  float ln_inv_d = 0.f, ln_eps = 0.f;
+  // EPI_RESID_EMIT producer: bf16 copy of the updated rows [M, ldc] and their partial statistics [M, N/64, 2]
+  void* xb_out = nullptr;
+  float* st_out = nullptr;
   // Tile raster: the N tiles are cut in column groups `gw` tiles wide; logical tile ids run group by group,
   // M-major inside a group.  An XCD's contiguous id range is then a compact (rows x gw) patch whose W panels
   // (gw*BN rows of W) stay resident in its 4 MiB L2 while the A row panels stream through once.
@@ -172,9 +193,9 @@ template <typename T, int EPI>
 struct EpilogueOp {
   static constexpr bool kAccurate = sizeof(T) == 4;
   __device__ __forceinline__ static float4 load(const GemmParams& p, int m, int n0) {
-    if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_QGELU) {
+    if constexpr (epi_is_colwise(EPI)) {
       return *reinterpret_cast<const float4*>(p.bias + n0);
-    } else if constexpr (EPI == EPI_BIAS_RESID) {
+    } else if constexpr (epi_is_resid(EPI)) {
       const float4 b = *reinterpret_cast<const float4*>(p.bias + n0);
       const float4 r = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.C) + (size_t)m * p.ldc + n0);
       return make_float4(r.x + b.x, r.y + b.y, r.z + b.z, r.w + b.w);
@@ -188,7 +209,7 @@ struct EpilogueOp {
   // 4 consecutive columns n0..n0+3 of output row m
   __device__ __forceinline__ static void store(const GemmParams& p, int m, int n0, float v0, float v1, float v2,
                                                float v3, const float4 add) {
-    if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_QGELU) {
+    if constexpr (epi_is_colwise(EPI)) {
       v0 += add.x; v1 += add.y; v2 += add.z; v3 += add.w;
       if constexpr (EPI == EPI_BIAS_QGELU) {
         v0 = quick_gelu<kAccurate>(v0); v1 = quick_gelu<kAccurate>(v1);
@@ -196,7 +217,7 @@ struct EpilogueOp {
       }
       using OutT = std::conditional_t<sizeof(T) == 4, float, bf16_t>;
       store4(reinterpret_cast<OutT*>(p.C) + (size_t)m * p.ldc + n0, v0, v1, v2, v3);
-    } else if constexpr (EPI == EPI_BIAS_RESID) {
+    } else if constexpr (epi_is_resid(EPI)) {
       store4(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n0, add.x + v0, add.y + v1, add.z + v2, add.w + v3);
     } else if constexpr (EPI == EPI_SCALE) {
       store4(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n0, p.alpha * v0, p.alpha * v1, p.alpha * v2,
@@ -238,6 +259,8 @@ void gemm_nt_kernel(const GemmParams p) {
   using OutT = std::conditional_t<sizeof(T) == 4, float, bf16_t>;
   static_assert(sizeof(T) != 1 || ((EPI == EPI_BIAS || EPI == EPI_BIAS_QGELU) && GLDS && NSTAGE == 2 && L2PF == 0),
                 "the fp8 form exists for the bf16-output column-wise epilogues of the LDS-DMA kernels");
+  static_assert(!(epi_is_ln(EPI) || EPI == EPI_RESID_EMIT) || sizeof(T) == 2, "LayerNorm folding is a bf16-engine form");
+  static_assert(!epi_is_ln(EPI) || NSTAGE == 2, "the row statistics are staged by the two-stage kernels' prologue");
   constexpr int BK = 8 * ELEMS16;          // 128-byte rows
   constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, STAGE = A_BYTES + W_BYTES;
   constexpr int PA = BM * 8 / NT, PW = BN * 8 / NT;  // 16-byte chunks per thread per tile
@@ -416,7 +439,7 @@ void gemm_nt_kernel(const GemmParams p) {
   // fit for the early request, accumulators + two operand blocks + the transposed values for the double buffer;
   // the 192x256 tile affords both, 320x256 and the 4x2-wave 256x256 tile neither (they would spill).
   constexpr int kAccRegs = MI * NI * 16, kBlkRegs = (NI / 2) * 32;
-  constexpr bool kRowOperand = (EPI == EPI_BIAS_RESID || EPI == EPI_PATCH) && NSTAGE == 2 && sizeof(T) == 2 &&
+  constexpr bool kRowOperand = (epi_is_resid(EPI) || EPI == EPI_PATCH) && NSTAGE == 2 && sizeof(T) == 2 &&
                                kAccRegs + 2 * (MI + NI) * 4 + kBlkRegs + 24 <= 256;
   constexpr int kAddBufs = (kAccRegs + 2 * kBlkRegs + 32 + 24 <= 256) ? 2 : 1;
   const int rd_row = lane >> 4, rd_col = (lane & 15) * 4;
@@ -588,6 +611,20 @@ void gemm_nt_kernel(const GemmParams p) {
     }
   } else {
   stage_issue(0);
+  if constexpr (epi_is_ln(EPI)) {
+    // LayerNorm statistics of this tile's BM rows and the c1 coefficients of its BN columns go to LDS once, while the
+    // first K tile is in flight: the epilogue then reads {mean, rstd} per row and c1 per column group from LDS instead of
+    // walking the partials (a dependent chain of L2 round trips per row) in front of the stores.
+    float* ln_rows = reinterpret_cast<float*>(smem + NSTAGE * STAGE);
+    float* c1s = ln_rows + 2 * BM;
+    for (int r = tid; r < BM; r += NT) {
+      const int mr = m0 + r < p.M ? m0 + r : p.M - 1;
+      float mu, rs;
+      ln_combine(p.ln_stats + (size_t)mr * p.ln_ns * 2, p.ln_ns, p.ln_inv_d, p.ln_eps, mu, rs);
+      *reinterpret_cast<float2*>(ln_rows + 2 * r) = make_float2(mu, rs);
+    }
+    for (int c = tid; c < BN; c += NT) c1s[c] = p.ln_c1[n0 + c];
+  }
   if constexpr (L2PF > 0) {
 #pragma unroll
     for (int d = 1; d <= L2PF; ++d)
@@ -642,7 +679,7 @@ void gemm_nt_kernel(const GemmParams p) {
   __syncthreads();  // every wave is done reading the last K tile: the staging LDS can be reused
   if (p.ablate & 4) return;
   char* slab = smem + wave * SLAB_BYTES;
-  if constexpr (sizeof(T) <= 2 && (EPI == EPI_BIAS || EPI == EPI_BIAS_QGELU)) {
+  if constexpr (sizeof(T) <= 2 && epi_is_colwise(EPI)) {
     // bf16 outputs whose epilogue is column-wise (bias, QuickGELU): finish the arithmetic in the ACCUMULATOR layout
     // -- the bias of a lane's 4 x 4 columns per MFMA tile is loaded once per tile column, not once per output row --
     // round to bf16 there, and transpose HALF the bytes: 8 ds_write_b64 + 4 ds_read_b128 + 4 16-byte global stores
@@ -677,6 +714,11 @@ void gemm_nt_kernel(const GemmParams p) {
             }
         }
       }
+      float ln_mu = 0.f, ln_rs = 1.f;
+      if constexpr (epi_is_ln(EPI)) {  // this lane's row of the block: mean / rstd of the LayerNorm input row (staged at kernel start)
+        const float2 mr = *reinterpret_cast<const float2*>(smem + NSTAGE * STAGE + (wm * TM + i * 32 + lrow) * 8);
+        ln_mu = mr.x; ln_rs = mr.y;
+      }
 #pragma unroll
       for (int jp = 0; jp < NI / 2; ++jp) {
 #pragma unroll
@@ -684,9 +726,18 @@ void gemm_nt_kernel(const GemmParams p) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const int j = 2 * jp + jj;
-            float v0 = acc[i][j][4 * q + 0] + bq[j][q].x, v1 = acc[i][j][4 * q + 1] + bq[j][q].y;
-            float v2 = acc[i][j][4 * q + 2] + bq[j][q].z, v3 = acc[i][j][4 * q + 3] + bq[j][q].w;
-            if constexpr (EPI == EPI_BIAS_QGELU) {
+            float v0, v1, v2, v3;
+            if constexpr (epi_is_ln(EPI)) {
+              const float4 c1 = *reinterpret_cast<const float4*>(smem + NSTAGE * STAGE + BM * 8 + (wn * TN + j * 32 + 8 * q + 4 * lgrp) * 4);
+              v0 = fmaf(ln_rs, fmaf(-ln_mu, c1.x, acc[i][j][4 * q + 0]), bq[j][q].x);
+              v1 = fmaf(ln_rs, fmaf(-ln_mu, c1.y, acc[i][j][4 * q + 1]), bq[j][q].y);
+              v2 = fmaf(ln_rs, fmaf(-ln_mu, c1.z, acc[i][j][4 * q + 2]), bq[j][q].z);
+              v3 = fmaf(ln_rs, fmaf(-ln_mu, c1.w, acc[i][j][4 * q + 3]), bq[j][q].w);
+            } else {
+              v0 = acc[i][j][4 * q + 0] + bq[j][q].x; v1 = acc[i][j][4 * q + 1] + bq[j][q].y;
+              v2 = acc[i][j][4 * q + 2] + bq[j][q].z; v3 = acc[i][j][4 * q + 3] + bq[j][q].w;
+            }
+            if constexpr (EPI == EPI_BIAS_QGELU || EPI == EPI_QGELU_LN) {
               v0 = quick_gelu<false>(v0); v1 = quick_gelu<false>(v1);
               v2 = quick_gelu<false>(v2); v3 = quick_gelu<false>(v3);
             }
@@ -749,7 +800,25 @@ void gemm_nt_kernel(const GemmParams p) {
         int m = m0 + wm * TM + i * 32 + it * 4 + rd_row;
         const bool in_range = m < p.M;
         if (p.ablate & 32) m &= 255;  // timeline experiment: every tile stores to the same 256 rows (L2-resident)
-        if (in_range) EpilogueOp<T, EPI>::store(p, m, n, v[it][0], v[it][1], v[it][2], v[it][3], add[kAddBufs == 2 ? (i & 1) : 0][jp][it]);
+        if constexpr (EPI == EPI_RESID_EMIT) {
+          // the updated residual row piece (4 columns per lane, 16 lanes = one 64-column slice of one row): fp32 in
+          // place, its bf16 copy for the next GEMM's A operand, and the slice's LayerNorm partials {sum, centred M2}
+          const float4 a4 = add[kAddBufs == 2 ? (i & 1) : 0][jp][it];
+          const float o0 = a4.x + v[it][0], o1 = a4.y + v[it][1], o2 = a4.z + v[it][2], o3 = a4.w + v[it][3];
+          const float ssum = row16_sum((o0 + o1) + (o2 + o3));
+          const float mj = ssum * (1.0f / kLnSlice);
+          const float d0 = o0 - mj, d1 = o1 - mj, d2 = o2 - mj, d3 = o3 - mj;
+          const float m2 = row16_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
+          if (in_range) {
+            store4(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n, o0, o1, o2, o3);
+            store4(reinterpret_cast<bf16_t*>(p.xb_out) + (size_t)m * p.ldc + n, o0, o1, o2, o3);
+            if ((lane & 15) == 0)
+              *reinterpret_cast<float2*>(p.st_out + ((size_t)m * (p.N / kLnSlice) + (n0 + wn * TN + jp * 64) / kLnSlice) * 2) =
+                  make_float2(ssum, m2);
+          }
+        } else {
+          if (in_range) EpilogueOp<T, EPI>::store(p, m, n, v[it][0], v[it][1], v[it][2], v[it][3], add[kAddBufs == 2 ? (i & 1) : 0][jp][it]);
+        }
       }
       __builtin_amdgcn_wave_barrier();
     }
@@ -788,10 +857,13 @@ int gemm_num_variants();
 const GemmVariant& gemm_variant(int v);
 // dtype: 0 fp32, 1 bf16.  variant -1 = auto, -2 = naive.  Returns hipError_t as int; *kernel_name (optional)
 // receives a static string naming the kernel that ran.
-int gemm_launch(int dtype, int epi, int variant, const GemmParams& p, hipStream_t stream, const char** kernel_name);
-int gemm_default_variant(int dtype, int M, int N, int K, int epi = -1);
+// policy (tile choice of variant -1): 0 = wave-quantisation cost model (kernels own the GPU one at a time),
+// 1..3 = the caller co-schedules the two towers on two streams (fixed tile per epilogue, see gemm.hip)
+int gemm_launch(int dtype, int epi, int variant, const GemmParams& p, hipStream_t stream, const char** kernel_name,
+                int policy = 0);
+int gemm_default_variant(int dtype, int M, int N, int K, int epi = -1, int policy = 0);
+bool gemm_variant_is_built(int dtype, int variant);
 int gemm_launch_fp8(int epi, int variant, const GemmParams& p, hipStream_t stream);  // experimental test hook
-void gemm_set_default_override(int variant);  // PLIPMI_GEMM_VARIANT / tests
-void gemm_set_policy(int policy);             // 0: wave-quantisation cost model (one stream), 1: co-scheduled streams
+void gemm_set_default_override(int variant);  // PLIPMI_GEMM_VARIANT / tests (process-wide A/B hook, not a product knob)
 
 }  // namespace plipmi

@@ -51,18 +51,21 @@ int gemm_num_cus() {
 int gemm_num_variants() { return kNumVariants; }
 const GemmVariant& gemm_variant(int v) { return kVariants[v]; }
 
+// Process-wide override of the tile choice: a TEST / A-B hook only (PLIPMI_GEMM_VARIANT, plipmi_set_gemm_variant).
+// The product path never writes it; the tile POLICY is a per-call argument owned by the handle.
 static int g_override = -100;  // -100 = not yet read
 void gemm_set_default_override(int variant) { g_override = variant; }
-static int g_policy = 0;
-void gemm_set_policy(int policy) { g_policy = policy; }
+bool gemm_variant_is_built(int dtype, int variant) {
+  return dtype == 1 ? gemm_built_bf16(variant) : gemm_built_f32(variant);
+}
 
-int gemm_default_variant(int dtype, int M, int N, int K, int epi) {
+int gemm_default_variant(int dtype, int M, int N, int K, int epi, int policy) {
   if (g_override == -100) {
     const char* e = getenv("PLIPMI_GEMM_VARIANT");
     g_override = e ? atoi(e) : -1;
   }
   if (g_override >= 0 || g_override == -2) {
-    if (g_override >= 0 && N % kVariants[g_override].bn != 0) return 1;
+    if (g_override >= 0 && (N % kVariants[g_override].bn != 0 || !gemm_variant_is_built(dtype, g_override))) return 1;
     return g_override;
   }
   // Tile choice = wave quantisation.  One 256-wide tile family runs one workgroup per CU (LDS-bound), so a GEMM
@@ -76,13 +79,13 @@ int gemm_default_variant(int dtype, int M, int N, int K, int epi) {
   // Policy 1 = the two towers are co-scheduled on two streams: CUs a partial round would leave idle are taken by
   // the other tower's kernels, so quantisation stops mattering and the tile with the fewest L2->LDS bytes per FLOP
   // wins (in-process A/B, profiles/r01_gemm_policy_ab.txt: 5.69 ms/step vs 6.04 ms with the cost model).
-  if (g_policy == 1 && dtype == 1 && N % 256 == 0) return 36;
+  if (policy == 1 && dtype == 1 && N % 256 == 0) return 36;
   // Policy 2: as 1, but the fp32 residual epilogues take the 192x256 tile, whose register budget lets it request the
   // residual rows one block ahead (gemm.h kRowOperand).
-  if (g_policy == 2 && dtype == 1 && N % 256 == 0) return (epi == EPI_BIAS_RESID || epi == EPI_PATCH) ? 37 : 36;
+  if (policy == 2 && dtype == 1 && N % 256 == 0) return (epi_is_resid(epi) || epi == EPI_PATCH) ? 37 : 36;
   // Policy 3: as 2, with the 256x256 fill2 tile for the bias-only (QKV) epilogue
-  if (g_policy == 3 && dtype == 1 && N % 256 == 0)
-    return (epi == EPI_BIAS_RESID || epi == EPI_PATCH) ? 37 : (epi == EPI_BIAS ? 42 : 36);
+  if (policy == 3 && dtype == 1 && N % 256 == 0)
+    return (epi_is_resid(epi) || epi == EPI_PATCH) ? 37 : ((epi == EPI_BIAS || epi == EPI_BIAS_LN) ? 42 : 36);
   const int cus = gemm_num_cus();
   struct Cand { int variant, bm, bn, per_cu; double rel; };
   const Cand cands_bf16[] = {{42, 256, 256, 1, 1.00}, {36, 320, 256, 1, 1.00}, {37, 192, 256, 1, 1.05}, {41, 128, 128, 2, 1.21}};
@@ -126,20 +129,19 @@ int gemm_launch_fp8(int epi, int variant, const GemmParams& p, hipStream_t strea
   return fn(pr, stream);
 }
 
-static const char* kEpiNames[EPI_COUNT] = {"bias", "bias_qgelu", "bias_resid", "scale", "patch"};
+static const char* kEpiNames[EPI_COUNT] = {"bias", "bias_qgelu", "bias_resid", "scale", "patch", "ln_bias", "ln_qgelu",
+                                           "resid_emit"};
 
-int gemm_launch(int dtype, int epi, int variant, const GemmParams& p, hipStream_t stream, const char** kernel_name) {
-  if (variant == -1) variant = gemm_default_variant(dtype, p.M, p.N, p.K, epi);
-  // the buffer-addressed kernels (35..41) carry 32-bit byte offsets: operands or outputs of 4 GiB and more take the
-  // 64-bit-address twins
-  if ((variant >= 35 && variant <= 41) || variant == 42) {
+int gemm_launch(int dtype, int epi, int variant, const GemmParams& p, hipStream_t stream, const char** kernel_name,
+                int policy) {
+  if (variant == -1) variant = gemm_default_variant(dtype, p.M, p.N, p.K, epi, policy);
+  // the buffer-addressed kernels (35..42) carry 32-bit byte offsets: operands or outputs of 4 GiB and more take the
+  // 64-bit-address tile (variant 1, global_load_lds with per-lane 64-bit addresses)
+  if (variant >= 35 && variant <= 42) {
     const size_t es = dtype == 1 ? 2 : 4;
     const size_t out_rows = epi == EPI_PATCH ? (size_t)p.M + p.M / (p.np > 0 ? p.np : 1) + 1 : (size_t)p.M;
     const size_t span = std::max(std::max((size_t)p.M * p.lda * es, (size_t)p.N * p.ldw * es), out_rows * p.ldc * 4);
-    if (span >= (1ull << 32)) {
-      static const int twin[8] = {32, 33, 34, 6, 26, 24, 8, 29};
-      variant = twin[variant - 35];
-    }
+    if (span >= (1ull << 32)) variant = 1;
   }
   if (p.M <= 0) return 0;
   const int bk = dtype == 1 ? 64 : 32;

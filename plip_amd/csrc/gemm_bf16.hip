@@ -2,4 +2,5 @@
 #include "gemm_inst.h"
 namespace plipmi {
 GemmLaunchFn gemm_get_bf16(int variant, int epi) { return GemmTable<bf16_t>::get(variant, epi); }
+bool gemm_built_bf16(int variant) { return gemm_variant_built<bf16_t>(variant); }
 }  // namespace plipmi

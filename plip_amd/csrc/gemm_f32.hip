@@ -2,4 +2,5 @@
 #include "gemm_inst.h"
 namespace plipmi {
 GemmLaunchFn gemm_get_f32(int variant, int epi) { return GemmTable<float>::get(variant, epi); }
+bool gemm_built_f32(int variant) { return gemm_variant_built<float>(variant); }
 }  // namespace plipmi

@@ -11,6 +11,17 @@ namespace plipmi {
 hipError_t launch_layernorm(const float* x, size_t x_row_stride, const float* g, const float* b, void* y, int y_dtype,
                             int rows, int D, float eps, hipStream_t s);
 
+// LayerNorm folded into the GEMMs (bf16 engine, gemm.h EPI_*_LN): the one LayerNorm pass a tower keeps -- fp32 in place
+// plus the bf16 copy xb [rows, D] and the statistics partials st [rows, D/64, 2] of its OUTPUT rows (D % 64 == 0)
+hipError_t launch_layernorm_emit(float* x, const float* g, const float* b, void* xb, float* st, int rows, int D, float eps,
+                                 hipStream_t s);
+// weight folding at plipmi_create: Wf[n,:] = bf16(pre * W[n,:] * g), c1[n] = sum_k Wf[n,k], c2[n] = pre * (W[n,:].b + bias[n])
+hipError_t launch_fold_ln(const float* W, const float* bias, const float* g, const float* b, void* Wf, float* c1, float* c2,
+                          int rows, int K, float pre, hipStream_t s);
+// token + position embedding with the same by-products (text tower's first block)
+hipError_t launch_text_embed_emit(const int64_t* ids, const float* tok, const float* pos, float* x, void* xb, float* st, int B,
+                                  int S, int D, int vocab, hipStream_t s);
+
 // pixels fp32 [B,3,H,W] -> patch rows [B*np, Kpad] (dtype), column (c,u,v), zero padded to Kpad.
 // fp8-weights engine: LayerNorm output as fp8 rows + one dynamic scale per row; weight rows -> fp8 + scale per row
 hipError_t launch_layernorm_fp8(const float* x, size_t x_row_stride, const float* g, const float* b, void* y_fp8,
@@ -46,7 +57,10 @@ hipError_t launch_pool_layernorm(const float* x, int S, int D, const int64_t* id
 
 hipError_t launch_l2_normalize(float* x, int N, int D, hipStream_t s);
 // C[M,N] = A[M,K] . W[N,K]^T, exact fp32 MFMA, split-K over the four waves of a 32x32-tile workgroup (N, K % 32 == 0)
-hipError_t launch_head_gemm(const float* A, const float* W, float* C, int M, int N, int K, hipStream_t s);
+// (also the MFMA form of the logits: C = scale * A . W^T; exchanging A and W gives the bit-exact transpose)
+hipError_t launch_head_gemm(const float* A, const float* W, float* C, int M, int N, int K, hipStream_t s, float scale = 1.0f);
+// out[i] = first arg-max of row i of x [N, M]
+hipError_t launch_row_argmax(const float* x, int N, int M, int32_t* out, hipStream_t s);
 
 // logits_per_image[i,j] = scale*<img_i,txt_j>; optional transpose output and per-row first arg-max.
 hipError_t launch_logits(const float* img, int Ni, const float* txt, int Nt, int D, float scale, float* lpi,

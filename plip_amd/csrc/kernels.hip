@@ -205,6 +205,108 @@ hipError_t launch_quantize_rows_fp8(const float* src, void* dst, float* scale, i
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------
+// LayerNorm folded into the neighbouring GEMMs (bf16 engine; gemm.h EPI_*_LN / EPI_RESID_EMIT).
+//   * layernorm_emit_kernel: the ONE LayerNorm pass a tower keeps (vision pre_layrnorm, modeling_clip.py:642): fp32
+//     in place, plus what the first block's folded LayerNorm needs of its output -- the bf16 copy of the rows (A
+//     operand of the q/k/v GEMM) and their statistics as per-64-column partials {sum, centred M2}.
+//   * fold_ln_kernel (plipmi_create): W'[n,:] = bf16(pre * W[n,:] * g), c1[n] = sum_k W'[n,k],
+//     c2[n] = pre * (sum_k W[n,k] b[k] + bias[n]); sums in fp64.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void layernorm_emit_kernel(float* x, const float* __restrict__ g, const float* __restrict__ b,
+                                                             bf16_t* __restrict__ xb, float* __restrict__ st, int rows, int D,
+                                                             float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;                       // wave-uniform
+  float* xr = x + (size_t)row * D;
+  float4 v[kLnMaxVec];
+  float s = 0.f;
+#pragma unroll
+  for (int it = 0; it < kLnMaxVec; ++it) {
+    const int idx = it * 256 + lane * 4;
+    v[it] = idx < D ? *reinterpret_cast<const float4*>(xr + idx) : make_float4(0.f, 0.f, 0.f, 0.f);
+    s += (v[it].x + v[it].y) + (v[it].z + v[it].w);
+  }
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int it = 0; it < kLnMaxVec; ++it) {
+    const int idx = it * 256 + lane * 4;
+    if (idx < D) {
+      const float a = v[it].x - mean, c = v[it].y - mean, d = v[it].z - mean, e = v[it].w - mean;
+      q += (a * a + c * c) + (d * d + e * e);
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+  const int ns = D / kLnSlice;
+#pragma unroll
+  for (int it = 0; it < kLnMaxVec; ++it) {
+    const int idx = it * 256 + lane * 4;       // 16 lanes = one 64-column slice (D % 64 == 0)
+    if (it * 256 >= D) break;                    // wave-uniform: every lane runs the DPP reductions of a live chunk
+    const bool live = idx < D;
+    float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live) {
+      const float4 gg = *reinterpret_cast<const float4*>(g + idx);
+      const float4 bb = *reinterpret_cast<const float4*>(b + idx);
+      y = make_float4((v[it].x - mean) * rstd * gg.x + bb.x, (v[it].y - mean) * rstd * gg.y + bb.y,
+                      (v[it].z - mean) * rstd * gg.z + bb.z, (v[it].w - mean) * rstd * gg.w + bb.w);
+    }
+    const float ssum = row16_sum((y.x + y.y) + (y.z + y.w));
+    const float mj = ssum * (1.0f / kLnSlice);
+    const float d0 = y.x - mj, d1 = y.y - mj, d2 = y.z - mj, d3 = y.w - mj;
+    const float m2 = row16_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
+    if (live) {
+      store4(xr + idx, y.x, y.y, y.z, y.w);
+      store4(xb + (size_t)row * D + idx, y.x, y.y, y.z, y.w);
+      if ((lane & 15) == 0) *reinterpret_cast<float2*>(st + ((size_t)row * ns + idx / kLnSlice) * 2) = make_float2(ssum, m2);
+    }
+  }
+}
+hipError_t launch_layernorm_emit(float* x, const float* g, const float* b, void* xb, float* st, int rows, int D, float eps,
+                                 hipStream_t s) {
+  if (rows <= 0) return hipSuccess;
+  if (D % kLnSlice || D > kLnMaxVec * 256) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(layernorm_emit_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, g, b, (bf16_t*)xb, st, rows, D, eps);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void fold_ln_kernel(const float* __restrict__ W, const float* __restrict__ bias,
+                                                      const float* __restrict__ g, const float* __restrict__ b,
+                                                      bf16_t* __restrict__ Wf, float* __restrict__ c1, float* __restrict__ c2,
+                                                      int rows, int K, float pre) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* wr = W + (size_t)row * K;
+  double s1 = 0.0, s2 = 0.0;
+  for (int k = lane * 4; k < K; k += 256) {
+    const float4 w = *reinterpret_cast<const float4*>(wr + k);
+    const float4 gg = *reinterpret_cast<const float4*>(g + k);
+    const float4 bb = *reinterpret_cast<const float4*>(b + k);
+    const bf16_t f0 = (bf16_t)(pre * w.x * gg.x), f1 = (bf16_t)(pre * w.y * gg.y), f2 = (bf16_t)(pre * w.z * gg.z),
+                 f3 = (bf16_t)(pre * w.w * gg.w);
+    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+    const bf16x4 pk = {f0, f1, f2, f3};
+    *reinterpret_cast<bf16x4*>(Wf + (size_t)row * K + k) = pk;
+    s1 += ((double)(float)f0 + (double)(float)f1) + ((double)(float)f2 + (double)(float)f3);
+    s2 += ((double)w.x * bb.x + (double)w.y * bb.y) + ((double)w.z * bb.z + (double)w.w * bb.w);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+  if (lane == 0) {
+    c1[row] = (float)s1;
+    c2[row] = (float)((double)pre * (s2 + (double)bias[row]));
+  }
+}
+hipError_t launch_fold_ln(const float* W, const float* bias, const float* g, const float* b, void* Wf, float* c1, float* c2,
+                          int rows, int K, float pre, hipStream_t s) {
+  if (rows <= 0) return hipSuccess;
+  if (K % 4) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(fold_ln_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, W, bias, g, b, (bf16_t*)Wf, c1, c2, rows, K, pre);
+  return hipGetLastError();
+}
+
 hipError_t launch_layernorm(const float* x, size_t xs, const float* g, const float* b, void* y, int y_dtype, int rows,
                             int D, float eps, hipStream_t s) {
   if (rows <= 0) return hipSuccess;
@@ -350,6 +452,48 @@ hipError_t launch_text_embed(const int64_t* ids, const float* tok, const float* 
                              int vocab, hipStream_t s) {
   if (B <= 0) return hipSuccess;
   hipLaunchKernelGGL(text_embed_kernel, dim3(B * S), dim3(128), 0, s, ids, tok, pos, x, S, D, vocab);
+  return hipGetLastError();
+}
+
+// the same lookup for the LayerNorm-folded engine: also emits the bf16 copy of the rows and their statistics partials
+// (one wave per row; 16 lanes cover one 64-column slice)
+__global__ __launch_bounds__(256) void text_embed_emit_kernel(const int64_t* __restrict__ ids, const float* __restrict__ tok,
+                                                              const float* __restrict__ pos, float* __restrict__ x,
+                                                              bf16_t* __restrict__ xb, float* __restrict__ st, int rows,
+                                                              int S, int D, int vocab) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  long long id = ids[row];
+  id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+  const float* t = tok + (size_t)id * D;
+  const float* p = pos + (size_t)(row % S) * D;
+  const int ns = D / kLnSlice;
+  for (int c0 = 0; c0 < D; c0 += 256) {          // wave-uniform trip count
+    const int idx = c0 + lane * 4;
+    const bool live = idx < D;
+    float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live) {
+      const float4 a = *reinterpret_cast<const float4*>(t + idx), b = *reinterpret_cast<const float4*>(p + idx);
+      y = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+    }
+    const float ssum = row16_sum((y.x + y.y) + (y.z + y.w));
+    const float mj = ssum * (1.0f / kLnSlice);
+    const float d0 = y.x - mj, d1 = y.y - mj, d2 = y.z - mj, d3 = y.w - mj;
+    const float m2 = row16_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
+    if (live) {
+      store4(x + (size_t)row * D + idx, y.x, y.y, y.z, y.w);
+      store4(xb + (size_t)row * D + idx, y.x, y.y, y.z, y.w);
+      if ((lane & 15) == 0) *reinterpret_cast<float2*>(st + ((size_t)row * ns + idx / kLnSlice) * 2) = make_float2(ssum, m2);
+    }
+  }
+}
+hipError_t launch_text_embed_emit(const int64_t* ids, const float* tok, const float* pos, float* x, void* xb, float* st, int B,
+                                  int S, int D, int vocab, hipStream_t s) {
+  if (B <= 0) return hipSuccess;
+  if (D % kLnSlice) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(text_embed_emit_kernel, dim3((B * S + 3) / 4), dim3(256), 0, s, ids, tok, pos, x, (bf16_t*)xb, st, B * S, S,
+                     D, vocab);
   return hipGetLastError();
 }
 
@@ -675,7 +819,7 @@ hipError_t launch_topk(const float* scores, int N, int M, int k, int64_t* idx, h
 // through LDS in a fixed order (deterministic, independent of the batch size).
 // ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void head_gemm_kernel(const float* __restrict__ A, const float* __restrict__ W,
-                                                        float* __restrict__ C, int M, int N, int K) {
+                                                        float* __restrict__ C, int M, int N, int K, float scale) {
   __shared__ __attribute__((aligned(16))) float part[4][16][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int lrow = lane & 31, lgrp = lane >> 5;
@@ -703,13 +847,18 @@ __global__ __launch_bounds__(256) void head_gemm_kernel(const float* __restrict_
   float* op = &o.x;
 #pragma unroll
   for (int e = 0; e < 4; ++e)
-    op[e] = ((part[0][4 * wave + e][lane] + part[1][4 * wave + e][lane]) + part[2][4 * wave + e][lane]) + part[3][4 * wave + e][lane];
+    op[e] = scale * (((part[0][4 * wave + e][lane] + part[1][4 * wave + e][lane]) + part[2][4 * wave + e][lane]) + part[3][4 * wave + e][lane]);
   if (m0 + lrow < M) *reinterpret_cast<float4*>(C + (size_t)(m0 + lrow) * N + n0 + 8 * wave + 4 * lgrp) = o;
 }
-hipError_t launch_head_gemm(const float* A, const float* W, float* C, int M, int N, int K, hipStream_t s) {
+hipError_t launch_head_gemm(const float* A, const float* W, float* C, int M, int N, int K, hipStream_t s, float scale) {
   if (M <= 0) return hipSuccess;
   if (N % 32 || K % 32) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(head_gemm_kernel, dim3(N / 32, (M + 31) / 32), dim3(256), 0, s, A, W, C, M, N, K);
+  hipLaunchKernelGGL(head_gemm_kernel, dim3(N / 32, (M + 31) / 32), dim3(256), 0, s, A, W, C, M, N, K, scale);
+  return hipGetLastError();
+}
+hipError_t launch_row_argmax(const float* x, int N, int M, int32_t* out, hipStream_t s) {
+  if (N <= 0) return hipSuccess;
+  hipLaunchKernelGGL(row_argmax_kernel, dim3((N + 3) / 4), dim3(256), 0, s, x, N, M, out);
   return hipGetLastError();
 }
 

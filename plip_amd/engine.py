@@ -166,13 +166,17 @@ class Engine:
         the towers are independent (separate workspaces), so the tail of one tower's GEMM grid -- 150..600
         workgroups over 256 CUs -- is filled by the other tower's kernels instead of idling."""
         if not overlap:
-            self.lib.plipmi_set_gemm_policy(0)
             return self.encode_image(pixels, normalize), self.encode_text(input_ids, attention_mask, normalize)
-        self.lib.plipmi_set_gemm_policy(getattr(self, "pair_policy", 3))  # co-scheduled towers: tile choice by bytes/FLOP, not by wave quantisation
+        # co-scheduled towers: tile choice per epilogue instead of by wave quantisation -- a field of THIS handle, set
+        # for the duration of the call (handles are not thread-safe, include/plipmi.h), never process-wide state
+        self._set_policy(getattr(self, "pair_policy", 3))
         try:
             return self._encode_pair_two_streams(pixels, input_ids, attention_mask, normalize)
         finally:
-            self.lib.plipmi_set_gemm_policy(0)
+            self._set_policy(0)
+
+    def _set_policy(self, policy: int):
+        _lib.check(self.lib.plipmi_set_gemm_policy(self._h, int(policy)), "plipmi_set_gemm_policy")
 
     def _encode_pair_two_streams(self, pixels, input_ids, attention_mask, normalize):
         main = torch.cuda.current_stream(self.device)
@@ -347,6 +351,35 @@ def attention(qkv: torch.Tensor, B: int, S: int, H: int, causal: bool = False, k
         _lib.check(lib.plipmi_attention(code, impl, _ptr(qkv), _ptr(out), B, S, H, int(causal), _ptr(key_mask),
                                         C.c_void_p(torch.cuda.current_stream(qkv.device).cuda_stream)), "plipmi_attention")
     return out
+
+
+def gemm_nt_ln(mode: int, a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, c1: Optional[torch.Tensor] = None,
+               stats: Optional[torch.Tensor] = None, eps: float = 1e-5, variant: int = -1,
+               out: Optional[torch.Tensor] = None):
+    """Kernel-level entry (tests) for the LayerNorm-folded epilogues, see include/plipmi.h plipmi_gemm_nt_ln.
+    mode 0/1 -> bf16 [M,N]; mode 2 -> (C fp32 updated in place, xb bf16 [M,N], st fp32 [M,N/64,2])."""
+    lib = _lib.load()
+    assert a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and a.is_contiguous() and w.is_contiguous()
+    M, K = a.shape
+    N = w.shape[0]
+    stream = C.c_void_p(torch.cuda.current_stream(a.device).cuda_stream)
+    with torch.cuda.device(a.device):
+        if mode in (0, 1):
+            if out is None:
+                out = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
+            _lib.check(lib.plipmi_gemm_nt_ln(mode, variant, M, N, K, _ptr(a), _ptr(w), _ptr(bias), _ptr(c1), _ptr(stats),
+                                             stats.shape[1], float(eps), _ptr(out), None, None, stream), "plipmi_gemm_nt_ln")
+            return out
+        xb = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
+        st = torch.empty((M, N // 64, 2), dtype=torch.float32, device=a.device)
+        _lib.check(lib.plipmi_gemm_nt_ln(2, variant, M, N, K, _ptr(a), _ptr(w), _ptr(bias), None, None, 0, float(eps),
+                                         _ptr(out), _ptr(xb), _ptr(st), stream), "plipmi_gemm_nt_ln")
+        return out, xb, st
+
+
+def gemm_variant_built(dtype, variant: int) -> bool:
+    code = _lib.BF16 if dtype in (torch.bfloat16, "bf16") else _lib.F32
+    return bool(_lib.load().plipmi_gemm_variant_built(code, int(variant)))
 
 
 def gemm_variants():

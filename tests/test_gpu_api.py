@@ -63,15 +63,16 @@ def test_gpu_resize_crop_is_pillow_exact(engines, h, w):
     n = cfg.image_size
     rs = np.random.RandomState(h + w)
     imgs = rs.randint(0, 256, (5, h, w, 3), dtype=np.uint8)
-    got = model.engine.resize_crop_u8(torch.from_numpy(imgs)).cpu().numpy()
-    plan = resize_crop_plan(w, h, n)
-    for i in range(5):
-        im = Image.fromarray(imgs[i]).resize((plan["nw"], plan["nh"]), resample=Image.BICUBIC)
-        want = np.asarray(im.crop((plan["left"], plan["top"], plan["left"] + n, plan["top"] + n)))
-        np.testing.assert_array_equal(got[i], want)
+    for rule in ("torchvision", "hf"):          # OpenAI _transform vs HF CLIPImageProcessor centre crop (odd excess)
+        got = model.engine.resize_crop_u8(torch.from_numpy(imgs), crop=rule).cpu().numpy()
+        plan = resize_crop_plan(w, h, n, crop=rule)
+        for i in range(5):
+            im = Image.fromarray(imgs[i]).resize((plan["nw"], plan["nh"]), resample=Image.BICUBIC)
+            want = np.asarray(im.crop((plan["left"], plan["top"], plan["left"] + n, plan["top"] + n)))
+            np.testing.assert_array_equal(got[i], want)
     plip = PLIP(model=model, tokenizer=fake_tokenizer(cfg))
     a = plip.encode_images(list(imgs), batch_size=3)                                   # GPU resize + fused normalise
-    b = model.engine.encode_image(torch.from_numpy(preprocess_images(list(imgs), n))).cpu().numpy()   # host Pillow path
+    b = model.engine.encode_image(torch.from_numpy(preprocess_images(list(imgs), n, crop="hf"))).cpu().numpy()   # host Pillow path, PLIP's (HF) crop rule
     assert np.abs(a - b).max() < 2e-5
     c = plip.encode_images([Image.fromarray(x) for x in imgs], batch_size=5)
     np.testing.assert_array_equal(a, c)

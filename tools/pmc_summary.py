@@ -12,7 +12,8 @@ import json
 import re
 import sys
 
-EPI = {"0": "bias", "1": "bias_qgelu", "2": "bias_resid", "3": "scale", "4": "patch"}
+EPI = {"0": "bias", "1": "bias_qgelu", "2": "bias_resid", "3": "scale", "4": "patch", "5": "ln_bias", "6": "ln_qgelu",
+       "7": "resid_emit"}
 
 
 def pretty(sym, variants):
@@ -57,6 +58,11 @@ def main():
                   "launches": len(c["FETCH_SIZE"]),
                   "note": "rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE, separate passes, "
                           "mean over the launches of `bench.py --steps 3` (both stream modes)"}
+    # stamp: the kernel sources these counters were collected on (bench.py emits `traffic: null` on a mismatch)
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from plip_amd.build import source_digest
+    out["_stamp"] = {"csrc_sha16": source_digest(), "how": "tools/gpu_round.sh pmcbench (rocprofv3 --kernel-trace --pmc, one counter per pass)"}
     json.dump(out, sys.stdout, indent=1, sort_keys=True)
 
 
