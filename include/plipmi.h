@@ -146,6 +146,14 @@ int plipmi_encode_image_u8(plipmi_handle h, const uint8_t* tiles, int B, float* 
 int plipmi_encode_text(plipmi_handle h, const int64_t* ids, const int64_t* attention_mask, int B,
                        int eos_token_id, float* out, int normalize, void* stream);
 
+/* Small-batch launch amortisation.  An encode call of at most `max_batch` samples (default min(32, cfg.max_batch);
+ * environment PLIPMI_GRAPH_BATCH; 0 = never) replays a captured hipGraph of its ~170 kernel launches instead of issuing
+ * them one by one: the first call of a shape (tower, batch, normalise, pooling rule, mask present) runs eagerly, the
+ * second captures on the caller's stream, later ones replay.  Inputs / outputs of a replay travel through handle-owned
+ * staging buffers (two device-to-device copies per call), results are bit-identical to the eager path.  The reference's
+ * zero_shot_classification runs both towers at batch 8 (plip.py:90-91), where the step is launch-bound. */
+int plipmi_set_graph_batch(plipmi_handle h, int max_batch);
+
 /* in-place row-wise x / sqrt(sum x^2), no epsilon (modeling_clip.py:57-65) */
 int plipmi_l2_normalize(plipmi_handle h, float* x, int N, int D, void* stream);
 
@@ -221,13 +229,13 @@ int plipmi_gemm_nt_traced(int dtype, int epilogue, int variant, int M, int N, in
 
 /* Kernel-level entry for the LayerNorm-folded epilogues of the bf16 engine (gemm.h EPI_BIAS_LN / EPI_QGELU_LN /
  * EPI_RESID_EMIT; A, W bf16 as raw uint16):
- *   mode 0: C(bf16) = rstd[m] * (A.W^T - mean[m] * c1[n]) + bias[n]     mean / rstd from `stats` [M, ns, 2] fp32 =
- *   mode 1: C(bf16) = quickgelu(that)                                   per-64-column partials {sum, centred M2} of the
- *                                                                       LayerNorm input rows (D = 64 * ns), eps as given
+ *   mode 0: C(bf16) = rstd[m] * A.W^T + bias[n]       rstd from `stats` [M, ns, 2] fp32 = per-64-column partials
+ *   mode 1: C(bf16) = quickgelu(that)                 {sum, centred M2} of the LayerNorm input rows (D = 64 * ns), eps as
+ *                                                     given; W is expected to carry LayerNorm's gain with CENTRED rows
+ *                                                     (sum_k W[n,k] = 0), which is what subtracts the row mean
  *   mode 2: C(f32) += A.W^T + bias;  xb_out(bf16)[M,N] = C;  st_out [M, N/64, 2] = partials of the updated rows */
 int plipmi_gemm_nt_ln(int mode, int variant, int M, int N, int K, const void* A, const void* W, const float* bias,
-                      const float* c1, const float* stats, int ns, float eps, void* C, void* xb_out, float* st_out,
-                      void* stream);
+                      const float* stats, int ns, float eps, void* C, void* xb_out, float* st_out, void* stream);
 
 /* Kernel-level entry for the attention kernels: out[B*S, H*64] = softmax(q k^T + masks) v over the fused
  * activation qkv [B*S, 3*H*64] (q | k | v, 1/sqrt(64) already folded into q).

@@ -9,10 +9,11 @@ spent on it, and so the tests can tell "the kernel is wrong" from "the plan is t
 Two plans for the LayerNorm -> Linear pairs (modeling_clip.py:370-381: layer_norm1 -> q/k/v, layer_norm2 -> fc1):
 
 * ``"round_ln"``  h = bf16(LN(x) * g + b);  y = h @ bf16(W)^T + bias                      (round 1 engine)
-* ``"folded"``    y = rstd * (bf16(x) @ bf16(W * g)^T - mean * c1) + c2                   (round 2 engine)
-                  c1[n] = sum_k bf16(W * g)[n,k],  c2 = W @ b + bias  (fp32)
-  -- LayerNorm's affine map is folded into the weights and its statistics into the GEMM epilogue, so the
-  normalised activations never exist in memory; algebraically identical to the reference's
+* ``"folded"``    y = rstd * (bf16(x) @ W'^T) + c2,   W' = bf16(W * g - rowmean_k(W * g)),  c2 = W @ b + bias (fp32)
+                                                                                             (round 2 engine)
+  -- LayerNorm's gain AND its mean subtraction are folded into the weights (a row of W' sums to zero, so
+  ``x @ W'^T == (x - mean(x)) @ (W * g)^T``), its bias into the Linear's bias, and only the row's rstd enters in the
+  GEMM epilogue: the normalised activations never exist in memory; algebraically identical to the reference's
   ``linear(layer_norm(x))``.
 
 GEMM accumulation is emulated in float64 (the MFMA accumulates fp32: its error is far below one bf16 ulp of the
@@ -54,11 +55,10 @@ def ln_linear(x, g, b, W, bias, eps, plan, pre=1.0):
         h = bf16((x - mu) * rstd * g + b)
         return _mm(h, bf16(W * np.float32(pre))) + bias * np.float32(pre)
     if plan == "folded":
-        Wg = bf16(W * g[None, :] * np.float32(pre))
-        c1 = Wg.astype(np.float64).sum(axis=1).astype(np.float32)
+        Wg = (W * g[None, :]).astype(np.float32)
+        Wg = bf16(np.float32(pre) * (Wg - Wg.astype(np.float64).mean(axis=1, keepdims=True).astype(np.float32)))
         c2 = ((W.astype(np.float64) @ b.astype(np.float64)) * pre).astype(np.float32) + bias * np.float32(pre)
-        acc = _mm(bf16(x), Wg)
-        return rstd * (acc - mu * c1) + c2
+        return rstd * _mm(bf16(x), Wg) + c2
     raise ValueError(plan)
 
 

@@ -53,6 +53,7 @@ SYMBOLS = {
     "plipmi_encode_image": (_i, [_vp, _vp, _i, _vp, _i, _vp]),
     "plipmi_encode_image_u8": (_i, [_vp, _vp, _i, _vp, _i, _vp]),
     "plipmi_encode_text": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _vp]),
+    "plipmi_set_graph_batch": (_i, [_vp, _i]),
     "plipmi_l2_normalize": (_i, [_vp, _vp, _i, _i, _vp]),
     "plipmi_logits": (_i, [_vp, _vp, _i, _vp, _i, _i, _f, _vp, _vp, _vp, _vp]),
     "plipmi_topk": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
@@ -64,7 +65,7 @@ SYMBOLS = {
     "plipmi_set_gemm_variant": (None, [_i]),
     "plipmi_set_gemm_policy": (_i, [_vp, _i]),
     "plipmi_gemm_variant_built": (_i, [_i, _i]),
-    "plipmi_gemm_nt_ln": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp]),
+    "plipmi_gemm_nt_ln": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp]),
     "plipmi_gemm_nt_ld": (_i, [_i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _f, _vp, _vp]),
     "plipmi_gemm_nt_traced": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
     "plipmi_attention": (_i, [_i, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),

@@ -40,144 +40,180 @@ __device__ __forceinline__ bf16x8 vtr_fragment(const char* vs, int byte_off) {
   return __builtin_bit_cast(bf16x8, v);
 }
 
-template <int KT>  // 32-key tiles: S <= 32*KT
+// PAIRS (sample, head) problems per workgroup, one after the other, the K / V rows of problem p+1 requested (into
+// registers) right after problem p's rows have been handed to LDS.  MEASURED AND NOT SHIPPED (profiles/r02_attention.txt):
+// at bs=256 two problems per workgroup make the grid resident in one round, but the loop form costs registers (132 / 155
+// VGPRs vs 64 / 80: three waves per SIMD instead of six to eight) and the launch got slower, 18.4 -> 19.6 us (S = 50) and
+// 21.0 -> 29.2 us (S = 77): the many small independent workgroups already overlap each other's load -> compute -> store
+// chains better than a prefetching loop does.  The launcher instantiates PAIRS = 1; the template keeps the experiment.
+template <int KT, int PAIRS>  // 32-key tiles: S <= 32*KT
 __global__ __launch_bounds__(64 * KT) void attention_mfma_kernel(const bf16_t* __restrict__ qkv,
                                                                  bf16_t* __restrict__ out, int S, int H, int causal,
-                                                                 const int64_t* __restrict__ key_mask) {
+                                                                 const int64_t* __restrict__ key_mask, int n_problems,
+                                                                 int pairs /* == PAIRS; a run-time value so the loop stays a loop */) {
   constexpr int SP = 32 * KT;   // padded sequence
-  // Q and K rows are staged through LDS in whole 128-byte lines (8 lanes x 16 B per row) instead of being loaded
+  constexpr int NT = 64 * KT;
+  constexpr int NP = SP * 8 / NT;   // 16-byte pieces of K (and of V) per thread: 4
+  // K rows are staged through LDS in whole 128-byte lines (8 lanes x 16 B per row) instead of being loaded
   // fragment-shaped (16 B from each of 32 rows per instruction, which costs the texture-address unit 2x the
   // time for the same bytes); the LDS image uses the GEMM's XOR swizzle so the fragment ds_read_b128 are
   // conflict-free.  V keeps its row-major form (two [SP][32] images) and is transposed by the LDS read itself.
+  // The second V image starts 64 bytes past a 128-byte boundary: the eight 16-byte pieces of one V row (four per image)
+  // then cover all 32 write banks once instead of hitting the same 16 twice (SQ_LDS_BANK_CONFLICT, round 1: half of
+  // the 3.9e5 conflict cycles per launch; the other half was the output staging below).
+  constexpr int VIMG = SP * 64 + 64;
   __shared__ __attribute__((aligned(16))) char Ks[SP * 128];
-  __shared__ __attribute__((aligned(16))) char Vs[2 * SP * 64];
+  __shared__ __attribute__((aligned(16))) char Vs[2 * VIMG];
   __shared__ unsigned long long mk[4];
 
-  const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
   const int D = H * 64, ld = 3 * D;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bf16_t* base = qkv + (size_t)b * S * ld + h * 64;
-
-  // key validity bits (sequence padding and the tokenizer's attention_mask): key = tid
-  {
-    const bool ok = tid < S && (key_mask == nullptr || key_mask[(size_t)b * S + tid] != 0);
-    const unsigned long long bits = __ballot(ok);
-    if (lane == 0) mk[wave] = bits;
-    if (KT < 4 && tid < 4 - KT) mk[KT + tid] = 0ull;
-  }
-  for (int e = tid; e < SP * 8; e += 64 * KT) {
-    const int row = e >> 3, c = e & 7;
-    const int rg = row < S ? row : S - 1;
-    const bf16_t* src = base + (size_t)rg * ld + c * 8;
-    const u32x4 k16 = *reinterpret_cast<const u32x4*>(src + D);
-    const u32x4 v16 = *reinterpret_cast<const u32x4*>(src + 2 * D);
-    const int off = row * 128 + ((c ^ ((row >> 1) & 7)) << 4);
-    *reinterpret_cast<u32x4*>(Ks + off) = k16;
-    *reinterpret_cast<u32x4*>(Vs + (c >> 2) * (SP * 64) + row * 64 + (c & 3) * 16) = v16;
-  }
   const int q0 = wave * 32;
   const bool active = q0 < S;
-  const int lrow = lane & 31, hi = lane >> 5;
-  const int qidx = q0 + lrow;
+  const int lrow = lane & 31, hi_c = lane >> 5;
+  const int qidx_c = q0 + lrow;
   const int lsw = (lrow >> 1) & 7;
 
-  // Q fragments (B operand) straight from global memory: Q[query = lrow][d = 16ks + 8hi .. +7].  Only this wave reads
-  // these rows, so an LDS image of Q would only cost residency (8-16 KB per workgroup = a third of its LDS).
-  u32x4 qf[4];
-  {
-    const bf16_t* qrow = base + (size_t)(qidx < S ? qidx : S - 1) * ld;
+  u32x4 kreg[NP], vreg[NP];
+  auto fetch = [&](int bh) {   // this thread's pieces of problem bh's K and V rows -> registers
+    const int b = bh / H, h = bh - b * H;
+    const bf16_t* base = qkv + (size_t)b * S * ld + h * 64;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const u32x4*>(qrow + (ks * 2 + hi) * 8);
-  }
-  __syncthreads();
+    for (int i = 0; i < NP; ++i) {
+      const int e = tid + i * NT, row = e >> 3, c = e & 7;
+      const bf16_t* src = base + (size_t)(row < S ? row : S - 1) * ld + c * 8;
+      kreg[i] = *reinterpret_cast<const u32x4*>(src + D);
+      vreg[i] = *reinterpret_cast<const u32x4*>(src + 2 * D);
+    }
+  };
+  const int bh0 = blockIdx.x * PAIRS;
+  fetch(bh0);
+#pragma unroll 1
+  for (int pp = 0; pp < pairs; ++pp) {
+    const int bh = bh0 + pp;
+    if (bh >= n_problems) break;                    // uniform
+    // Everything below that depends only on the lane (query index, key slots) is loop-invariant; hoisted out of the loop
+    // the 16 x KT mask predicates alone stay live as SGPR pairs / VGPRs across the whole body (187-241 VGPRs instead of
+    // 64-80: one wave per SIMD).  An empty asm makes the two lane values opaque per iteration, so they are recomputed.
+    int qidx = qidx_c, hi = hi_c;
+    asm volatile("" : "+v"(qidx), "+v"(hi));
+    const int b = bh / H, h = bh - b * H;
+    const bf16_t* base = qkv + (size_t)b * S * ld + h * 64;
+    // key validity bits (sequence padding and the tokenizer's attention_mask): key = tid
+    {
+      const bool ok = tid < S && (key_mask == nullptr || key_mask[(size_t)b * S + tid] != 0);
+      const unsigned long long bits = __ballot(ok);
+      if (lane == 0) mk[wave] = bits;
+      if (KT < 4 && tid < 4 - KT) mk[KT + tid] = 0ull;
+    }
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int e = tid + i * NT, row = e >> 3, c = e & 7;
+      *reinterpret_cast<u32x4*>(Ks + row * 128 + ((c ^ ((row >> 1) & 7)) << 4)) = kreg[i];
+      *reinterpret_cast<u32x4*>(Vs + (c >> 2) * VIMG + row * 64 + (c & 3) * 16) = vreg[i];
+    }
+    // Q fragments (B operand) straight from global memory: Q[query = lrow][d = 16ks + 8hi .. +7].  Only this wave reads
+    // these rows, so an LDS image of Q would only cost residency (8-16 KB per workgroup = a third of its LDS).
+    u32x4 qf[4];
+    {
+      const bf16_t* qrow = base + (size_t)(qidx < S ? qidx : S - 1) * ld;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const u32x4*>(qrow + (ks * 2 + hi) * 8);
+    }
+    __syncthreads();
+    if (pp + 1 < pairs && bh + 1 < n_problems) fetch(bh + 1);   // in flight during this problem's arithmetic
 
-  // scores^T tiles
-  f32x16 sc[KT];
-  const unsigned long long m0 = mk[0], m1 = mk[1];
-  float rmax = -INFINITY;
+    // scores^T tiles
+    f32x16 sc[KT];
+    const unsigned long long m0 = mk[0], m1 = mk[1];
+    float rmax = -INFINITY;
 #pragma unroll
-  for (int t = 0; t < KT; ++t) {
-    const bool live = !(causal && 32 * t > q0 + 31);  // wave-uniform: tile entirely above the diagonal
+    for (int t = 0; t < KT; ++t) {
+      const bool live = active && !(causal && 32 * t > q0 + 31);  // wave-uniform: tile entirely above the diagonal
 #pragma unroll
-    for (int r = 0; r < 16; ++r) sc[t][r] = 0.f;
-    if (live) {
+      for (int r = 0; r < 16; ++r) sc[t][r] = 0.f;
+      if (live) {
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const u32x4 kf = *reinterpret_cast<const u32x4*>(Ks + (32 * t + lrow) * 128 + (((ks * 2 + hi) ^ lsw) << 4));
-        sc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf), __builtin_bit_cast(bf16x8, qf[ks]),
-                                                        sc[t], 0, 0, 0);
+        for (int ks = 0; ks < 4; ++ks) {
+          const u32x4 kf = *reinterpret_cast<const u32x4*>(Ks + (32 * t + lrow) * 128 + (((ks * 2 + hi) ^ lsw) << 4));
+          sc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf), __builtin_bit_cast(bf16x8, qf[ks]),
+                                                          sc[t], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        const unsigned long long word = key < 64 ? m0 : m1;
+        const bool ok = live && ((word >> (key & 63)) & 1ull) && (!causal || key <= qidx);
+        sc[t][r] = ok ? sc[t][r] : -INFINITY;
+        rmax = fmaxf(rmax, sc[t][r]);
       }
     }
+    __syncthreads();  // every wave has its scores: the K rows may now be reused as output staging
+    if (active) {
+      rmax = fmaxf(rmax, __shfl_xor(rmax, 32, 64));
+      const float m_use = (rmax == -INFINITY) ? 0.f : rmax;
+      float rsum = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int key = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * hi;
-      const unsigned long long word = key < 64 ? m0 : m1;
-      const bool ok = live && ((word >> (key & 63)) & 1ull) && (!causal || key <= qidx);
-      sc[t][r] = ok ? sc[t][r] : -INFINITY;
-      rmax = fmaxf(rmax, sc[t][r]);
-    }
-  }
-  __syncthreads();  // every wave has its scores: the K rows may now be reused as output staging
-  if (!active) return;
-  rmax = fmaxf(rmax, __shfl_xor(rmax, 32, 64));
-  const float m_use = (rmax == -INFINITY) ? 0.f : rmax;
-  float rsum = 0.f;
+      for (int t = 0; t < KT; ++t)
 #pragma unroll
-  for (int t = 0; t < KT; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      sc[t][r] = __expf(sc[t][r] - m_use);
-      rsum += sc[t][r];
-    }
-  rsum += __shfl_xor(rsum, 32, 64);
+        for (int r = 0; r < 16; ++r) {
+          sc[t][r] = __expf(sc[t][r] - m_use);
+          rsum += sc[t][r];
+        }
+      rsum += __shfl_xor(rsum, 32, 64);
 
-  // O^T = V^T P^T
-  f32x16 acc[2];
+      // O^T = V^T P^T
+      f32x16 acc[2];
 #pragma unroll
-  for (int dt = 0; dt < 2; ++dt)
+      for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[dt][r] = 0.f;
-  const char* vlane = Vs + vtr_lane_offset(lrow, hi);
+        for (int r = 0; r < 16; ++r) acc[dt][r] = 0.f;
+      const char* vlane = Vs + vtr_lane_offset(lrow, hi);
 #pragma unroll
-  for (int t = 0; t < KT; ++t) {
-    if (causal && 32 * t > q0 + 31) continue;
+      for (int t = 0; t < KT; ++t) {
+        if (causal && 32 * t > q0 + 31) continue;
 #pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-      bf16x8 pf;
+        for (int s2 = 0; s2 < 2; ++s2) {
+          bf16x8 pf;
 #pragma unroll
-      for (int jj = 0; jj < 8; ++jj) pf[jj] = (bf16_t)sc[t][8 * s2 + jj];
+          for (int jj = 0; jj < 8; ++jj) pf[jj] = (bf16_t)sc[t][8 * s2 + jj];
 #pragma unroll
-      for (int dt = 0; dt < 2; ++dt) {
-        const bf16x8 vf = vtr_fragment(vlane, dt * (SP * 64) + (32 * t + 16 * s2) * 64);
-        acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, acc[dt], 0, 0, 0);
+          for (int dt = 0; dt < 2; ++dt) {
+            const bf16x8 vf = vtr_fragment(vlane, dt * VIMG + (32 * t + 16 * s2) * 64);
+            acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, acc[dt], 0, 0, 0);
+          }
+        }
+      }
+      // The accumulator layout gives a lane one query ROW (like the GEMM): write the normalised 32 x 64 bf16 tile
+      // into the K rows of its own query range (every wave is past its scores), then store whole 128-byte rows.
+      // Rows 2k and 2k+1 share a swizzle slot; odd rows keep their two 8-byte halves exchanged, so the 16 lanes of a
+      // ds_write_b64 group (16 consecutive rows, same column chunk) touch 16 distinct 8-byte bank pairs.
+      const float inv = 1.0f / rsum;
+      char* orow_lds = Ks + (q0 + lrow) * 128;
+      typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          const int d = dt * 32 + 8 * q4 + 4 * hi;                 // 4 consecutive head-dim columns
+          const int c = d >> 3;                                    // 16-byte chunk, half (d&4) inside it
+          const bf16x4 v = {(bf16_t)(acc[dt][4 * q4 + 0] * inv), (bf16_t)(acc[dt][4 * q4 + 1] * inv),
+                            (bf16_t)(acc[dt][4 * q4 + 2] * inv), (bf16_t)(acc[dt][4 * q4 + 3] * inv)};
+          *reinterpret_cast<bf16x4*>(orow_lds + ((c ^ lsw) << 4) + ((((d >> 2) ^ lrow) & 1) << 3)) = v;
+        }
+      __builtin_amdgcn_wave_barrier();
+      const int c = lane & 7;
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int r = q0 + it * 8 + (lane >> 3);
+        const u32x4 raw = *reinterpret_cast<const u32x4*>(Ks + r * 128 + ((c ^ ((r >> 1) & 7)) << 4));
+        const u32x4 v = (r & 1) ? u32x4{raw[2], raw[3], raw[0], raw[1]} : raw;
+        if (r < S) *reinterpret_cast<u32x4*>(out + ((size_t)b * S + r) * D + h * 64 + c * 8) = v;
       }
     }
-  }
-  // The accumulator layout gives a lane one query ROW (like the GEMM): write the normalised 32 x 64 bf16 tile
-  // into the K rows of its own query range (every wave is past its scores), then store whole 128-byte rows.
-  {
-    const float inv = 1.0f / rsum;
-    char* orow_lds = Ks + (q0 + lrow) * 128;
-    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int q4 = 0; q4 < 4; ++q4) {
-        const int d = dt * 32 + 8 * q4 + 4 * hi;                 // 4 consecutive head-dim columns
-        const int c = d >> 3;                                    // 16-byte chunk, half (d&4) inside it
-        const bf16x4 v = {(bf16_t)(acc[dt][4 * q4 + 0] * inv), (bf16_t)(acc[dt][4 * q4 + 1] * inv),
-                          (bf16_t)(acc[dt][4 * q4 + 2] * inv), (bf16_t)(acc[dt][4 * q4 + 3] * inv)};
-        *reinterpret_cast<bf16x4*>(orow_lds + ((c ^ lsw) << 4) + (d & 4) * 2) = v;
-      }
-    __builtin_amdgcn_wave_barrier();
-    const int c = lane & 7;
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int r = q0 + it * 8 + (lane >> 3);
-      const u32x4 v = *reinterpret_cast<const u32x4*>(Ks + r * 128 + ((c ^ ((r >> 1) & 7)) << 4));
-      if (r < S) *reinterpret_cast<u32x4*>(out + ((size_t)b * S + r) * D + h * 64 + c * 8) = v;
-    }
+    if (pp + 1 < pairs) __syncthreads();   // the next problem overwrites Ks / Vs / mk
   }
 }
 
@@ -360,9 +396,11 @@ hipError_t launch_attention_mfma(const void* qkv, void* out, int B, int S, int H
     return hipGetLastError();
   }
   const int KT = (S + 31) / 32;
-  const dim3 grid(B * H), block(64 * KT);
+  constexpr int kPairs = 1;                   // (sample, head) problems per workgroup, see the kernel's header
+  const dim3 grid((B * H + kPairs - 1) / kPairs), block(64 * KT);
 #define PLIPMI_ATT(K) \
-  hipLaunchKernelGGL(attention_mfma_kernel<K>, grid, block, 0, s, (const bf16_t*)qkv, (bf16_t*)out, S, H, causal, key_mask)
+  hipLaunchKernelGGL((attention_mfma_kernel<K, kPairs>), grid, block, 0, s, (const bf16_t*)qkv, (bf16_t*)out, S, H, causal, \
+                     key_mask, B * H, kPairs)
   switch (KT) {
     case 1: PLIPMI_ATT(1); break;
     case 2: PLIPMI_ATT(2); break;

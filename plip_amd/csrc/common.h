@@ -71,15 +71,16 @@ __device__ __forceinline__ float row16_sum(float v) {
 constexpr int kLnSlice = 64;
 __device__ __forceinline__ void ln_combine(const float* __restrict__ st, int ns, float inv_d, float eps, float& mean,
                                            float& rstd) {
-  // ns is even (widths are multiples of 128): two slices per 16-byte load, and all loads of a 16-slice batch are
-  // issued before the first is consumed (the folding itself is a short serial chain)
+  // ns is even (widths are multiples of 128): two slices per 16-byte load.  The loads of a 16-slice batch are
+  // UNCONDITIONAL (index clamped) and issued back to back -- a per-load predicate makes hipcc branch around each load
+  // and wait for it separately, i.e. one L2/HBM round trip per load; only the (wave-uniform) folding steps are guarded.
   float n = 0.f, mu = 0.f, m2 = 0.f;
   for (int j0 = 0; j0 < ns; j0 += 16) {
     float4 v[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      const int j = j0 + 2 * k;
-      v[k] = j < ns ? *reinterpret_cast<const float4*>(st + 2 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const int j = j0 + 2 * k < ns ? j0 + 2 * k : ns - 2;
+      v[k] = *reinterpret_cast<const float4*>(st + 2 * j);
     }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -90,7 +91,7 @@ __device__ __forceinline__ void ln_combine(const float* __restrict__ st, int ns,
           const float mj = sj * (1.0f / kLnSlice);
           const float nn = n + (float)kLnSlice;
           const float d = mj - mu;
-          const float w = (float)kLnSlice / nn;
+          const float w = (float)kLnSlice * __builtin_amdgcn_rcpf(nn);   // nn = 64 (j + 1): 1-ulp reciprocal of a small integer
           mu += d * w;
           m2 += qj + d * d * n * w;
           n = nn;
@@ -99,7 +100,7 @@ __device__ __forceinline__ void ln_combine(const float* __restrict__ st, int ns,
     }
   }
   mean = mu;
-  rstd = 1.0f / sqrtf(m2 * inv_d + eps);
+  rstd = __builtin_amdgcn_rsqf(m2 * inv_d + eps);   // v_rsq_f32, 1 ulp: far below the bf16 rounding of what it scales
 }
 
 // QuickGELU: x * sigmoid(1.702 x)  (transformers/activations.py:117-123)

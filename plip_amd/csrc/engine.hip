@@ -15,7 +15,9 @@
 #include <string.h>
 
 #include <algorithm>
+#include <map>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "../../include/plipmi.h"
@@ -50,9 +52,8 @@ struct LayerW {
   void *wqkv8 = nullptr, *w18 = nullptr;  // fp8-weights mode: e4m3fn copies of the QKV / fc1 weights ...
   float *sqkv = nullptr, *s1 = nullptr;   // ... and their per-output-channel scales
   float *bqkv, *bo, *b1, *b2, *ln1w, *ln1b, *ln2w, *ln2b;
-  // LayerNorm-folded engine: wqkv / w1 hold W * g (LayerNorm gain folded in), bqkv / b1 hold c2 = W b_ln + bias,
-  // and these are c1[n] = sum_k W'[n,k] (the coefficient of the row mean in the GEMM epilogue)
-  float *c1qkv = nullptr, *c1fc1 = nullptr;
+  // LayerNorm-folded engine: wqkv / w1 hold the centred W * g (LayerNorm gain and mean subtraction folded in),
+  // bqkv / b1 hold c2 = W b_ln + bias
 };
 struct Tower {
   int D = 0, F = 0, L = 0, H = 0, S = 0;
@@ -65,8 +66,16 @@ struct Tower {
   float* st = nullptr;  // LayerNorm-folded engine: statistics partials of the residual rows [M, D/64, 2]; h = bf16(x)
 };
 struct LnArgs {         // the LayerNorm side of a folded GEMM (gemm.h EPI_*_LN / EPI_RESID_EMIT)
-  const float* stats = nullptr; const float* c1 = nullptr; int ns = 0; float inv_d = 0.f, eps = 0.f;   // consumer
+  const float* stats = nullptr; int ns = 0; float inv_d = 0.f, eps = 0.f;   // consumer
   void* xb_out = nullptr; float* st_out = nullptr;                                                        // producer
+};
+// One captured tower forward (hipGraph) per (tower, input kind, batch, normalise, pooling rule, mask?): the ~170 launches
+// of a small-batch encode are replayed with ONE host call instead of being issued one by one (launch-bound at the
+// reference's own batch size of 8, plip.py:90-91).  Inputs / outputs of a captured forward live in handle-owned staging
+// buffers, because the caller's pointers change from call to call and graph nodes hold theirs fixed.
+struct GraphEntry {
+  int seen = 0;                 // calls so far: the first runs eagerly (it also sets the kernels' attributes)
+  hipGraphExec_t exec = nullptr;
 };
 struct ProfRec {
   const char* name;
@@ -85,6 +94,16 @@ struct plipmi_engine {
   // normalised activations in memory); PLIPMI_LN_FOLD=0 restores the separate LayerNorm kernels for A/B runs
   bool ln_fold = false;
   int gemm_policy = 0;  // tile policy of this handle's GEMMs (plipmi_set_gemm_policy)
+  // small-batch hipGraph replay (plipmi_set_graph_batch; PLIPMI_GRAPH_BATCH): batches of at most this many samples
+  int graph_batch = 0;
+  std::map<std::tuple<int, int, int, int, int>, GraphEntry> graphs;
+  void* g_vin = nullptr;      // staged image input (fp32 pixels or uint8 tiles) [graph_batch_cap, 3, H, W] x 4 B
+  int64_t* g_tin = nullptr;   // staged ids   [graph_batch_cap, ctx]
+  int64_t* g_tmask = nullptr; // staged attention mask
+  float *g_vout = nullptr, *g_tout = nullptr;   // staged embeddings [graph_batch_cap, P]
+  int graph_batch_cap = 0;
+  hipStream_t cap_stream = nullptr;   // captures run here: the legacy default stream cannot capture, and the caller's
+                                      // stream never enters capture mode (other threads may be enqueueing on it)
   int np = 0, kpad = 0;
   Tower vis, txt;
   void* patch_w = nullptr;  // [Dv, kpad]
@@ -176,7 +195,6 @@ void carve(plipmi_engine* e, Carver& c) {
         w.wqkv = c.take<void>(3 * D * D, es); w.w1 = c.take<void>(F * D, es);
       }
       w.bqkv = c.take<float>(3 * D, 4); w.bo = c.take<float>(D, 4); w.b1 = c.take<float>(F, 4); w.b2 = c.take<float>(D, 4);
-      if (e->ln_fold) { w.c1qkv = c.take<float>(3 * D, 4); w.c1fc1 = c.take<float>(F, 4); }
       w.ln1w = c.take<float>(D, 4); w.ln1b = c.take<float>(D, 4); w.ln2w = c.take<float>(D, 4); w.ln2b = c.take<float>(D, 4);
     }
     const size_t M = B * t->S;
@@ -189,6 +207,14 @@ void carve(plipmi_engine* e, Carver& c) {
     t->mlp = c.take<void>(M * F, es);
   }
   e->patches = c.take<void>(B * e->np * e->kpad, es);
+  const size_t gb = (size_t)e->graph_batch_cap;
+  if (gb) {
+    e->g_vin = c.take<void>(gb * 3 * g.image_size * g.image_size, 4);
+    e->g_tin = c.take<int64_t>(gb * g.context_length, 8);
+    e->g_tmask = c.take<int64_t>(gb * g.context_length, 8);
+    e->g_vout = c.take<float>(gb * g.projection_dim, 4);
+    e->g_tout = c.take<float>(gb * g.projection_dim, 4);
+  }
 }
 
 int pack_tower(plipmi_engine* e, Tower& t, const plipmi_layer_weights* src, hipStream_t s) {
@@ -204,12 +230,12 @@ int pack_tower(plipmi_engine* e, Tower& t, const plipmi_layer_weights* src, hipS
       HIP_TRY(launch_quantize_rows_fp8(w.v_w, wq8 + (size_t)2 * D * D, d.sqkv + 2 * D, D, D, 1.f, s));
       HIP_TRY(launch_quantize_rows_fp8(w.fc1_w, d.w18, d.s1, F, D, 1.f, s));
     } else if (e->ln_fold) {
-      // W' = bf16(W * g) (q rows also x 1/8), c1 = row sums of W', c2 = W b_ln + bias -> the bias slot
+      // W' = bf16(W * g, rows centred) (q rows also x 1/8), c2 = W b_ln + bias -> the bias slot
       char* wq = reinterpret_cast<char*>(d.wqkv);
-      HIP_TRY(launch_fold_ln(w.q_w, w.q_b, w.ln1_w, w.ln1_b, wq, d.c1qkv, d.bqkv, D, D, qscale, s));
-      HIP_TRY(launch_fold_ln(w.k_w, w.k_b, w.ln1_w, w.ln1_b, wq + (size_t)D * D * e->esz, d.c1qkv + D, d.bqkv + D, D, D, 1.f, s));
-      HIP_TRY(launch_fold_ln(w.v_w, w.v_b, w.ln1_w, w.ln1_b, wq + (size_t)2 * D * D * e->esz, d.c1qkv + 2 * D, d.bqkv + 2 * D, D, D, 1.f, s));
-      HIP_TRY(launch_fold_ln(w.fc1_w, w.fc1_b, w.ln2_w, w.ln2_b, d.w1, d.c1fc1, d.b1, F, D, 1.f, s));
+      HIP_TRY(launch_fold_ln(w.q_w, w.q_b, w.ln1_w, w.ln1_b, wq, d.bqkv, D, D, qscale, s));
+      HIP_TRY(launch_fold_ln(w.k_w, w.k_b, w.ln1_w, w.ln1_b, wq + (size_t)D * D * e->esz, d.bqkv + D, D, D, 1.f, s));
+      HIP_TRY(launch_fold_ln(w.v_w, w.v_b, w.ln1_w, w.ln1_b, wq + (size_t)2 * D * D * e->esz, d.bqkv + 2 * D, D, D, 1.f, s));
+      HIP_TRY(launch_fold_ln(w.fc1_w, w.fc1_b, w.ln2_w, w.ln2_b, d.w1, d.b1, F, D, 1.f, s));
     } else {
       char* wq = reinterpret_cast<char*>(d.wqkv);
       HIP_TRY(launch_convert(w.q_w, wq, dt, D, D, D, qscale, s));
@@ -241,7 +267,7 @@ int run_gemm(plipmi_engine* e, int epi, const void* A, const void* W, void* C, c
   p.A = A; p.W = W; p.C = C; p.bias = bias;
   p.M = M; p.N = N; p.K = K; p.lda = K; p.ldw = K; p.ldc = ldc; p.alpha = 1.f; p.np = np;
   if (ln) {
-    p.ln_stats = ln->stats; p.ln_c1 = ln->c1; p.ln_ns = ln->ns; p.ln_inv_d = ln->inv_d; p.ln_eps = ln->eps;
+    p.ln_stats = ln->stats; p.ln_ns = ln->ns; p.ln_inv_d = ln->inv_d; p.ln_eps = ln->eps;
     p.xb_out = ln->xb_out; p.st_out = ln->st_out;
   }
   const char* name = "gemm_nt";
@@ -283,18 +309,16 @@ int run_layers(plipmi_engine* e, Tower& t, int B, int n_layers, int causal, cons
   };
   if (e->ln_fold) {
     // LayerNorm never runs as a pass: t.h = bf16(x) and t.st = the rows' statistics partials arrive with x from its
-    // producer (embedding kernel, or the residual GEMM's epilogue); the consuming GEMMs carry LayerNorm's gain / bias in
-    // their weights and apply mean / rstd in their epilogues.  HF order (modeling_clip.py:370-381) is unchanged:
+    // producer (embedding kernel, or the residual GEMM's epilogue); the consuming GEMMs carry LayerNorm's gain, centring
+    // and bias in their weights and apply rstd in their epilogues.  HF order (modeling_clip.py:370-381) is unchanged:
     // x += out_proj(attn(LN1(x))); x += fc2(quick_gelu(fc1(LN2(x)))).
     LnArgs use;  use.stats = t.st; use.ns = D / kLnSlice; use.inv_d = 1.0f / (float)D; use.eps = eps;
     LnArgs emit; emit.xb_out = t.h; emit.st_out = t.st;
     for (int l = 0; l < n_layers; ++l) {
       const LayerW& w = t.layers[l];
-      use.c1 = w.c1qkv;
       RUN(run_gemm(e, EPI_BIAS_LN, t.h, w.wqkv, t.qkv, w.bqkv, M, 3 * D, D, 3 * D, 0, s, &use));
       RUN(attention());
       RUN(run_gemm(e, EPI_RESID_EMIT, t.att, w.wo, t.x, w.bo, M, D, D, D, 0, s, &emit));
-      use.c1 = w.c1fc1;
       RUN(run_gemm(e, EPI_QGELU_LN, t.h, w.w1, t.mlp, w.b1, M, F, D, F, 0, s, &use));
       if (l + 1 < n_layers) RUN(run_gemm(e, EPI_RESID_EMIT, t.mlp, w.w2, t.x, w.b2, M, D, F, D, 0, s, &emit));
       else RUN(run_gemm(e, EPI_BIAS_RESID, t.mlp, w.w2, t.x, w.b2, M, D, F, D, 0, s));   // nothing reads LN partials after the last block
@@ -385,6 +409,49 @@ int check_batch(plipmi_engine* e, int B) {
   return PLIPMI_OK;
 }
 
+// the three tower forwards, on whatever pointers they are given (caller's, or the staging buffers under capture)
+int image_forward(plipmi_handle h, const float* pixels, const uint8_t* tiles, int B, float* out, int normalize,
+                         hipStream_t s) {
+  RUN(vision_embed(h, pixels, tiles, B, s));
+  RUN(run_layers(h, h->vis, B, h->vis.L, 0, nullptr, s));
+  return run_head(h, h->vis, nullptr, -1, h->post_w, h->post_b, h->vproj, h->vproj_t, h->vpooled, out, B, normalize, s);
+}
+int text_forward(plipmi_handle h, const int64_t* ids, const int64_t* mask, int B, int eos_token_id, float* out,
+                        int normalize, hipStream_t s) {
+  RUN(text_embed(h, ids, B, s));
+  RUN(run_layers(h, h->txt, B, h->txt.L, 1, mask, s));
+  return run_head(h, h->txt, ids, eos_token_id, h->fin_w, h->fin_b, h->tproj, h->tproj_t, h->tpooled, out, B, normalize, s);
+}
+
+// Small batches: replay a captured graph of the same launches.  kind 0 = fp32 pixels, 1 = uint8 tiles, 2 = text.
+// Call 1 of a shape runs eagerly (and leaves every kernel's attributes set), call 2 captures, later calls replay.
+template <typename Fwd>
+int graph_or_eager(plipmi_handle h, int kind, int B, int normalize, int eos, int has_mask, hipStream_t s,
+                          const void* in, size_t in_bytes, void* in_stage, const int64_t* mask, size_t mask_bytes,
+                          float* out, float* out_stage, Fwd&& forward /* (in, mask, out, stream) -> rc */) {
+  const bool eligible = h->graph_batch > 0 && B <= h->graph_batch && !h->prof;
+  if (!eligible) return forward(in, mask, out, s);
+  GraphEntry& ge = h->graphs[std::make_tuple(kind, B, normalize, eos, has_mask)];
+  if (ge.seen++ == 0) return forward(in, mask, out, s);
+  HIP_TRY(hipMemcpyAsync(in_stage, in, in_bytes, hipMemcpyDeviceToDevice, s));
+  if (has_mask) HIP_TRY(hipMemcpyAsync(h->g_tmask, mask, mask_bytes, hipMemcpyDeviceToDevice, s));
+  if (!ge.exec) {
+    hipGraph_t graph = nullptr;
+    if (!h->cap_stream) HIP_TRY(hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
+    const int rc = forward(in_stage, has_mask ? h->g_tmask : nullptr, out_stage, h->cap_stream);
+    const hipError_t ee = hipStreamEndCapture(h->cap_stream, &graph);   // always end the capture: the stream must leave capture mode
+    if (rc != PLIPMI_OK) { if (graph) hipGraphDestroy(graph); return rc; }
+    if (ee != hipSuccess) return fail(PLIPMI_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(ee));
+    const hipError_t ie = hipGraphInstantiate(&ge.exec, graph, nullptr, nullptr, 0);
+    hipGraphDestroy(graph);
+    if (ie != hipSuccess) { ge.exec = nullptr; return fail(PLIPMI_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(ie)); }
+  }
+  HIP_TRY(hipGraphLaunch(ge.exec, s));
+  HIP_TRY(hipMemcpyAsync(out, out_stage, (size_t)B * h->cfg.projection_dim * 4, hipMemcpyDeviceToDevice, s));
+  return PLIPMI_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -431,6 +498,9 @@ int plipmi_create(const plipmi_config* cfg, const plipmi_weights* w, void* strea
   e->esz = e->dtype == PLIPMI_BF16 ? 2 : 4;
   { const char* lf = getenv("PLIPMI_LN_FOLD");
     e->ln_fold = e->dtype == PLIPMI_BF16 && !e->fp8w && !(lf && atoi(lf) == 0); }
+  { const char* gb = getenv("PLIPMI_GRAPH_BATCH");
+    e->graph_batch_cap = std::min(g.max_batch, 32);
+    e->graph_batch = gb ? std::max(0, std::min(atoi(gb), e->graph_batch_cap)) : e->graph_batch_cap; }
   e->np = tokens - 1;
   e->kpad = (int)align_up((size_t)3 * g.patch_size * g.patch_size, 64);
   snprintf(e->devname, sizeof(e->devname), "%s:%s", prop.gcnArchName, prop.name);
@@ -494,6 +564,8 @@ void plipmi_destroy(plipmi_handle h) {
   if (!h) return;
   for (ProfRec& r : h->recs) { hipEventDestroy(r.t0); hipEventDestroy(r.t1); }
   for (hipEvent_t ev : h->pool) hipEventDestroy(ev);
+  for (auto& kv : h->graphs) if (kv.second.exec) hipGraphExecDestroy(kv.second.exec);
+  if (h->cap_stream) hipStreamDestroy(h->cap_stream);
   if (h->slab) hipFree(h->slab);
   if (h->sim_ws) hipFree(h->sim_ws);
   delete h;
@@ -504,9 +576,10 @@ int plipmi_encode_image(plipmi_handle h, const float* pixels, int B, float* out,
   if (B == 0) return PLIPMI_OK;
   if (!pixels || !out) return fail(PLIPMI_ERR_INVALID, "null pixels/out");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  RUN(vision_embed(h, pixels, nullptr, B, s));
-  RUN(run_layers(h, h->vis, B, h->vis.L, 0, nullptr, s));
-  return run_head(h, h->vis, nullptr, -1, h->post_w, h->post_b, h->vproj, h->vproj_t, h->vpooled, out, B, normalize, s);
+  const size_t n = (size_t)B * 3 * h->cfg.image_size * h->cfg.image_size;
+  return graph_or_eager(h, 0, B, normalize != 0, 0, 0, s, pixels, n * 4, h->g_vin, nullptr, 0, out, h->g_vout,
+                        [&](const void* in, const int64_t*, float* o, hipStream_t st) {
+                          return image_forward(h, reinterpret_cast<const float*>(in), nullptr, B, o, normalize, st); });
 }
 
 int plipmi_encode_image_u8(plipmi_handle h, const uint8_t* tiles, int B, float* out, int normalize, void* stream) {
@@ -514,9 +587,10 @@ int plipmi_encode_image_u8(plipmi_handle h, const uint8_t* tiles, int B, float* 
   if (B == 0) return PLIPMI_OK;
   if (!tiles || !out) return fail(PLIPMI_ERR_INVALID, "null tiles/out");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  RUN(vision_embed(h, nullptr, tiles, B, s));
-  RUN(run_layers(h, h->vis, B, h->vis.L, 0, nullptr, s));
-  return run_head(h, h->vis, nullptr, -1, h->post_w, h->post_b, h->vproj, h->vproj_t, h->vpooled, out, B, normalize, s);
+  const size_t n = (size_t)B * 3 * h->cfg.image_size * h->cfg.image_size;
+  return graph_or_eager(h, 1, B, normalize != 0, 0, 0, s, tiles, n, h->g_vin, nullptr, 0, out, h->g_vout,
+                        [&](const void* in, const int64_t*, float* o, hipStream_t st) {
+                          return image_forward(h, nullptr, reinterpret_cast<const uint8_t*>(in), B, o, normalize, st); });
 }
 
 int plipmi_encode_text(plipmi_handle h, const int64_t* ids, const int64_t* attention_mask, int B, int eos_token_id,
@@ -525,9 +599,17 @@ int plipmi_encode_text(plipmi_handle h, const int64_t* ids, const int64_t* atten
   if (B == 0) return PLIPMI_OK;
   if (!ids || !out) return fail(PLIPMI_ERR_INVALID, "null ids/out");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  RUN(text_embed(h, ids, B, s));
-  RUN(run_layers(h, h->txt, B, h->txt.L, 1, attention_mask, s));
-  return run_head(h, h->txt, ids, eos_token_id, h->fin_w, h->fin_b, h->tproj, h->tproj_t, h->tpooled, out, B, normalize, s);
+  const size_t n = (size_t)B * h->cfg.context_length * 8;
+  return graph_or_eager(h, 2, B, normalize != 0, eos_token_id, attention_mask != nullptr, s, ids, n, h->g_tin,
+                        attention_mask, n, out, h->g_tout,
+                        [&](const void* in, const int64_t* m, float* o, hipStream_t st) {
+                          return text_forward(h, reinterpret_cast<const int64_t*>(in), m, B, eos_token_id, o, normalize, st); });
+}
+
+int plipmi_set_graph_batch(plipmi_handle h, int max_batch) {
+  if (!h) return fail(PLIPMI_ERR_INVALID, "null handle");
+  h->graph_batch = std::max(0, std::min(max_batch, h->graph_batch_cap));
+  return PLIPMI_OK;
 }
 
 int plipmi_debug_hidden(plipmi_handle h, int tower, int layer, const void* input, int B, float* out, void* stream) {
@@ -691,14 +773,13 @@ int plipmi_gemm_nt_traced(int dtype, int epilogue, int variant, int M, int N, in
 }
 
 int plipmi_gemm_nt_ln(int mode, int variant, int M, int N, int K, const void* A, const void* W, const float* bias,
-                      const float* c1, const float* stats, int ns, float eps, void* C, void* xb_out, float* st_out,
-                      void* stream) {
+                      const float* stats, int ns, float eps, void* C, void* xb_out, float* st_out, void* stream) {
   if (mode < 0 || mode > 2 || M < 0 || N <= 0 || K <= 0 || !A || !W || !C || !bias) return fail(PLIPMI_ERR_INVALID, "bad argument");
-  if (mode < 2 && (!c1 || !stats || ns <= 0)) return fail(PLIPMI_ERR_INVALID, "mode 0/1 need c1 and stats");
+  if (mode < 2 && (!stats || ns <= 0)) return fail(PLIPMI_ERR_INVALID, "mode 0/1 need the row statistics");
   if (mode == 2 && (!xb_out || !st_out || N % kLnSlice)) return fail(PLIPMI_ERR_INVALID, "mode 2 needs xb_out, st_out and N % 64 == 0");
   GemmParams p;
   p.A = A; p.W = W; p.C = C; p.bias = bias; p.M = M; p.N = N; p.K = K; p.lda = K; p.ldw = K; p.ldc = N; p.alpha = 1.f; p.np = 1;
-  p.ln_stats = stats; p.ln_c1 = c1; p.ln_ns = ns; p.ln_inv_d = ns > 0 ? 1.0f / (float)(ns * kLnSlice) : 0.f; p.ln_eps = eps;
+  p.ln_stats = stats; p.ln_ns = ns; p.ln_inv_d = ns > 0 ? 1.0f / (float)(ns * kLnSlice) : 0.f; p.ln_eps = eps;
   p.xb_out = xb_out; p.st_out = st_out;
   const int epi = mode == 0 ? EPI_BIAS_LN : mode == 1 ? EPI_QGELU_LN : EPI_RESID_EMIT;
   const int rc = gemm_launch(PLIPMI_BF16, epi, variant, p, reinterpret_cast<hipStream_t>(stream), nullptr);

@@ -41,9 +41,10 @@ enum Epilogue : int {
   EPI_SCALE = 3,       // C(f32) = alpha * acc
   EPI_PATCH = 4,       // C(f32)[img*(np+1)+1+p, n] = acc + pos[(1+p), n]   (m = img*np + p)
   // LayerNorm folded into the GEMMs on either side of it (bf16 engine; modeling_clip.py:370-381: LN -> Linear):
-  //   the Linear's weights carry LayerNorm's gain (W' = W * g), its bias carries LayerNorm's bias (c2 = W b + bias),
-  //   the A operand is the bf16 residual stream itself, and the row statistics enter in the epilogue:
-  //   y = rstd[m] * (acc - mean[m] * c1[n]) + c2[n],  c1[n] = sum_k W'[n,k]
+  //   the Linear's weights carry LayerNorm's gain AND its centring (W' = W * g with each row's mean over k removed, so
+  //   x . W'^T == (x - mean(x)) . (W * g)^T: the mean subtraction happens inside the contraction), its bias carries
+  //   LayerNorm's bias (c2 = W b + bias), the A operand is the bf16 residual stream itself, and only the row's rstd
+  //   enters in the epilogue:   y = rstd[m] * acc + c2[n]
   EPI_BIAS_LN = 5,     // C(bf16) = that                                   (LN1 -> q/k/v)
   EPI_QGELU_LN = 6,    // C(bf16) = quickgelu(that)                        (LN2 -> fc1)
   // ... and the producer of the NEXT LayerNorm's input: the in-place residual update also emits the bf16 copy of the
@@ -68,9 +69,8 @@ struct GemmParams {
   const float* row_scale = nullptr;
   const float* col_scale = nullptr;
   // EPI_*_LN consumers: per-row statistics partials [M, ln_ns, 2] fp32 over 64-column slices of the LayerNorm input
-  // (ln_combine), c1 [N] fp32 (bias carries c2), 1/D and eps of that LayerNorm
+  // (ln_combine; bias carries c2), 1/D and eps of that LayerNorm
   const float* ln_stats = nullptr;
-  const float* ln_c1 = nullptr;
   int ln_ns = 0;
   float ln_inv_d = 0.f, ln_eps = 0.f;
   // EPI_RESID_EMIT producer: bf16 copy of the updated rows [M, ldc] and their partial statistics [M, N/64, 2]
@@ -612,18 +612,15 @@ void gemm_nt_kernel(const GemmParams p) {
   } else {
   stage_issue(0);
   if constexpr (epi_is_ln(EPI)) {
-    // LayerNorm statistics of this tile's BM rows and the c1 coefficients of its BN columns go to LDS once, while the
-    // first K tile is in flight: the epilogue then reads {mean, rstd} per row and c1 per column group from LDS instead of
-    // walking the partials (a dependent chain of L2 round trips per row) in front of the stores.
+    // rstd of this tile's BM LayerNorm-input rows goes to LDS once, while the first K tile is in flight: the epilogue
+    // then reads one float per row instead of walking the partials (a chain of L2 round trips per row) before the stores.
     float* ln_rows = reinterpret_cast<float*>(smem + NSTAGE * STAGE);
-    float* c1s = ln_rows + 2 * BM;
     for (int r = tid; r < BM; r += NT) {
       const int mr = m0 + r < p.M ? m0 + r : p.M - 1;
       float mu, rs;
       ln_combine(p.ln_stats + (size_t)mr * p.ln_ns * 2, p.ln_ns, p.ln_inv_d, p.ln_eps, mu, rs);
-      *reinterpret_cast<float2*>(ln_rows + 2 * r) = make_float2(mu, rs);
+      ln_rows[r] = rs;
     }
-    for (int c = tid; c < BN; c += NT) c1s[c] = p.ln_c1[n0 + c];
   }
   if constexpr (L2PF > 0) {
 #pragma unroll
@@ -714,11 +711,9 @@ void gemm_nt_kernel(const GemmParams p) {
             }
         }
       }
-      float ln_mu = 0.f, ln_rs = 1.f;
-      if constexpr (epi_is_ln(EPI)) {  // this lane's row of the block: mean / rstd of the LayerNorm input row (staged at kernel start)
-        const float2 mr = *reinterpret_cast<const float2*>(smem + NSTAGE * STAGE + (wm * TM + i * 32 + lrow) * 8);
-        ln_mu = mr.x; ln_rs = mr.y;
-      }
+      float ln_rs = 1.f;
+      if constexpr (epi_is_ln(EPI))  // this lane's row of the block: rstd of the LayerNorm input row (staged at kernel start)
+        ln_rs = *reinterpret_cast<const float*>(smem + NSTAGE * STAGE + (wm * TM + i * 32 + lrow) * 4);
 #pragma unroll
       for (int jp = 0; jp < NI / 2; ++jp) {
 #pragma unroll
@@ -728,11 +723,8 @@ void gemm_nt_kernel(const GemmParams p) {
             const int j = 2 * jp + jj;
             float v0, v1, v2, v3;
             if constexpr (epi_is_ln(EPI)) {
-              const float4 c1 = *reinterpret_cast<const float4*>(smem + NSTAGE * STAGE + BM * 8 + (wn * TN + j * 32 + 8 * q + 4 * lgrp) * 4);
-              v0 = fmaf(ln_rs, fmaf(-ln_mu, c1.x, acc[i][j][4 * q + 0]), bq[j][q].x);
-              v1 = fmaf(ln_rs, fmaf(-ln_mu, c1.y, acc[i][j][4 * q + 1]), bq[j][q].y);
-              v2 = fmaf(ln_rs, fmaf(-ln_mu, c1.z, acc[i][j][4 * q + 2]), bq[j][q].z);
-              v3 = fmaf(ln_rs, fmaf(-ln_mu, c1.w, acc[i][j][4 * q + 3]), bq[j][q].w);
+              v0 = fmaf(ln_rs, acc[i][j][4 * q + 0], bq[j][q].x); v1 = fmaf(ln_rs, acc[i][j][4 * q + 1], bq[j][q].y);
+              v2 = fmaf(ln_rs, acc[i][j][4 * q + 2], bq[j][q].z); v3 = fmaf(ln_rs, acc[i][j][4 * q + 3], bq[j][q].w);
             } else {
               v0 = acc[i][j][4 * q + 0] + bq[j][q].x; v1 = acc[i][j][4 * q + 1] + bq[j][q].y;
               v2 = acc[i][j][4 * q + 2] + bq[j][q].z; v3 = acc[i][j][4 * q + 3] + bq[j][q].w;

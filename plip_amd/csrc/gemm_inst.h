@@ -14,8 +14,8 @@ typedef int (*GemmLaunchFn)(const GemmParams&, hipStream_t);
 template <typename T, int BM, int BN, int WM, int WN, int EPI, bool GLDS, int SCHED = 0, int L2PF = 0, int NSTAGE = 2, int ADDR = 0>
 int launch_tiled(const GemmParams& p, hipStream_t stream) {
   constexpr int NT = WM * WN * 64;
-  // + {mean, rstd} per tile row and c1 per tile column for the LayerNorm-folded epilogues
-  constexpr int LDS = NSTAGE * (BM + BN) * 128 + (epi_is_ln(EPI) ? BM * 8 + BN * 4 : 0);
+  // + rstd per tile row for the LayerNorm-folded epilogues
+  constexpr int LDS = NSTAGE * (BM + BN) * 128 + (epi_is_ln(EPI) ? BM * 4 : 0);
   auto kern = gemm_nt_kernel<T, BM, BN, WM, WN, EPI, GLDS, SCHED, L2PF, NSTAGE, ADDR>;
   static bool attr_set = false;  // one handle per process; set once per instantiation
   if (!attr_set) {

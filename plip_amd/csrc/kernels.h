@@ -15,9 +15,9 @@ hipError_t launch_layernorm(const float* x, size_t x_row_stride, const float* g,
 // plus the bf16 copy xb [rows, D] and the statistics partials st [rows, D/64, 2] of its OUTPUT rows (D % 64 == 0)
 hipError_t launch_layernorm_emit(float* x, const float* g, const float* b, void* xb, float* st, int rows, int D, float eps,
                                  hipStream_t s);
-// weight folding at plipmi_create: Wf[n,:] = bf16(pre * W[n,:] * g), c1[n] = sum_k Wf[n,k], c2[n] = pre * (W[n,:].b + bias[n])
-hipError_t launch_fold_ln(const float* W, const float* bias, const float* g, const float* b, void* Wf, float* c1, float* c2,
-                          int rows, int K, float pre, hipStream_t s);
+// weight folding at plipmi_create: Wf[n,:] = bf16(pre * (W[n,:] * g - mean_k(W[n,:] * g))), c2[n] = pre * (W[n,:].b + bias[n])
+hipError_t launch_fold_ln(const float* W, const float* bias, const float* g, const float* b, void* Wf, float* c2, int rows,
+                          int K, float pre, hipStream_t s);
 // token + position embedding with the same by-products (text tower's first block)
 hipError_t launch_text_embed_emit(const int64_t* ids, const float* tok, const float* pos, float* x, void* xb, float* st, int B,
                                   int S, int D, int vocab, hipStream_t s);

@@ -210,7 +210,8 @@ hipError_t launch_quantize_rows_fp8(const float* src, void* dst, float* scale, i
 //   * layernorm_emit_kernel: the ONE LayerNorm pass a tower keeps (vision pre_layrnorm, modeling_clip.py:642): fp32
 //     in place, plus what the first block's folded LayerNorm needs of its output -- the bf16 copy of the rows (A
 //     operand of the q/k/v GEMM) and their statistics as per-64-column partials {sum, centred M2}.
-//   * fold_ln_kernel (plipmi_create): W'[n,:] = bf16(pre * W[n,:] * g), c1[n] = sum_k W'[n,k],
+//   * fold_ln_kernel (plipmi_create): W'[n,:] = bf16(pre * (W[n,:] * g - mean_k(W[n,:] * g))) -- gain folded in and the
+//     row centred, so that x . W'^T == (x - mean(x)) . (W * g)^T and LayerNorm's mean subtraction needs no epilogue term;
 //     c2[n] = pre * (sum_k W[n,k] b[k] + bias[n]); sums in fp64.
 // ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void layernorm_emit_kernel(float* x, const float* __restrict__ g, const float* __restrict__ b,
@@ -273,37 +274,40 @@ hipError_t launch_layernorm_emit(float* x, const float* g, const float* b, void*
 
 __global__ __launch_bounds__(256) void fold_ln_kernel(const float* __restrict__ W, const float* __restrict__ bias,
                                                       const float* __restrict__ g, const float* __restrict__ b,
-                                                      bf16_t* __restrict__ Wf, float* __restrict__ c1, float* __restrict__ c2,
-                                                      int rows, int K, float pre) {
+                                                      bf16_t* __restrict__ Wf, float* __restrict__ c2, int rows, int K,
+                                                      float pre) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const float* wr = W + (size_t)row * K;
+  // pass 1: mean over k of W[n,k] * g[k] (what centring the row removes), and W[n,:] . b
   double s1 = 0.0, s2 = 0.0;
   for (int k = lane * 4; k < K; k += 256) {
     const float4 w = *reinterpret_cast<const float4*>(wr + k);
     const float4 gg = *reinterpret_cast<const float4*>(g + k);
     const float4 bb = *reinterpret_cast<const float4*>(b + k);
-    const bf16_t f0 = (bf16_t)(pre * w.x * gg.x), f1 = (bf16_t)(pre * w.y * gg.y), f2 = (bf16_t)(pre * w.z * gg.z),
-                 f3 = (bf16_t)(pre * w.w * gg.w);
-    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-    const bf16x4 pk = {f0, f1, f2, f3};
-    *reinterpret_cast<bf16x4*>(Wf + (size_t)row * K + k) = pk;
-    s1 += ((double)(float)f0 + (double)(float)f1) + ((double)(float)f2 + (double)(float)f3);
+    s1 += ((double)w.x * gg.x + (double)w.y * gg.y) + ((double)w.z * gg.z + (double)w.w * gg.w);
     s2 += ((double)w.x * bb.x + (double)w.y * bb.y) + ((double)w.z * bb.z + (double)w.w * bb.w);
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
-  if (lane == 0) {
-    c1[row] = (float)s1;
-    c2[row] = (float)((double)pre * (s2 + (double)bias[row]));
+  const float wmean = (float)(s1 / (double)K);
+  // pass 2: the folded, centred, scaled row in bf16
+  for (int k = lane * 4; k < K; k += 256) {
+    const float4 w = *reinterpret_cast<const float4*>(wr + k);
+    const float4 gg = *reinterpret_cast<const float4*>(g + k);
+    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+    const bf16x4 pk = {(bf16_t)(pre * (w.x * gg.x - wmean)), (bf16_t)(pre * (w.y * gg.y - wmean)),
+                       (bf16_t)(pre * (w.z * gg.z - wmean)), (bf16_t)(pre * (w.w * gg.w - wmean))};
+    *reinterpret_cast<bf16x4*>(Wf + (size_t)row * K + k) = pk;
   }
+  if (lane == 0) c2[row] = (float)((double)pre * (s2 + (double)bias[row]));
 }
-hipError_t launch_fold_ln(const float* W, const float* bias, const float* g, const float* b, void* Wf, float* c1, float* c2,
-                          int rows, int K, float pre, hipStream_t s) {
+hipError_t launch_fold_ln(const float* W, const float* bias, const float* g, const float* b, void* Wf, float* c2, int rows,
+                          int K, float pre, hipStream_t s) {
   if (rows <= 0) return hipSuccess;
   if (K % 4) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(fold_ln_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, W, bias, g, b, (bf16_t*)Wf, c1, c2, rows, K, pre);
+  hipLaunchKernelGGL(fold_ln_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, W, bias, g, b, (bf16_t*)Wf, c2, rows, K, pre);
   return hipGetLastError();
 }
 

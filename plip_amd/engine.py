@@ -175,6 +175,10 @@ class Engine:
         finally:
             self._set_policy(0)
 
+    def set_graph_batch(self, max_batch: int):
+        """Batches of at most ``max_batch`` samples replay a captured hipGraph (0 = always launch eagerly)."""
+        _lib.check(self.lib.plipmi_set_graph_batch(self._h, int(max_batch)), "plipmi_set_graph_batch")
+
     def _set_policy(self, policy: int):
         _lib.check(self.lib.plipmi_set_gemm_policy(self._h, int(policy)), "plipmi_set_gemm_policy")
 
@@ -353,9 +357,8 @@ def attention(qkv: torch.Tensor, B: int, S: int, H: int, causal: bool = False, k
     return out
 
 
-def gemm_nt_ln(mode: int, a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, c1: Optional[torch.Tensor] = None,
-               stats: Optional[torch.Tensor] = None, eps: float = 1e-5, variant: int = -1,
-               out: Optional[torch.Tensor] = None):
+def gemm_nt_ln(mode: int, a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, stats: Optional[torch.Tensor] = None,
+               eps: float = 1e-5, variant: int = -1, out: Optional[torch.Tensor] = None):
     """Kernel-level entry (tests) for the LayerNorm-folded epilogues, see include/plipmi.h plipmi_gemm_nt_ln.
     mode 0/1 -> bf16 [M,N]; mode 2 -> (C fp32 updated in place, xb bf16 [M,N], st fp32 [M,N/64,2])."""
     lib = _lib.load()
@@ -367,12 +370,12 @@ def gemm_nt_ln(mode: int, a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, 
         if mode in (0, 1):
             if out is None:
                 out = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
-            _lib.check(lib.plipmi_gemm_nt_ln(mode, variant, M, N, K, _ptr(a), _ptr(w), _ptr(bias), _ptr(c1), _ptr(stats),
+            _lib.check(lib.plipmi_gemm_nt_ln(mode, variant, M, N, K, _ptr(a), _ptr(w), _ptr(bias), _ptr(stats),
                                              stats.shape[1], float(eps), _ptr(out), None, None, stream), "plipmi_gemm_nt_ln")
             return out
         xb = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
         st = torch.empty((M, N // 64, 2), dtype=torch.float32, device=a.device)
-        _lib.check(lib.plipmi_gemm_nt_ln(2, variant, M, N, K, _ptr(a), _ptr(w), _ptr(bias), None, None, 0, float(eps),
+        _lib.check(lib.plipmi_gemm_nt_ln(2, variant, M, N, K, _ptr(a), _ptr(w), _ptr(bias), None, 0, float(eps),
                                          _ptr(out), _ptr(xb), _ptr(st), stream), "plipmi_gemm_nt_ln")
         return out, xb, st
 

@@ -65,17 +65,22 @@ def run_batches(items: Sequence, batch_size: int, prepare_item: Optional[Callabl
                 nlo, nhi = bounds[k + 1]
                 fut = ahead.submit(prep, items[nlo:nhi])
             if not use_gpu:
-                outs.append(eat(prepared, torch.from_numpy(host)))
+                outs.append(eat(prepared, host if torch.is_tensor(host) else torch.from_numpy(host)))
                 continue
             slot = k & 1
             if consumed[slot] is not None:
                 consumed[slot].synchronize()            # the tower that read this slot's device copy has finished
-            if staging[slot] is None or staging[slot].shape != host.shape or staging[slot].dtype != torch.from_numpy(host).dtype:
-                staging[slot] = torch.empty(host.shape, dtype=torch.from_numpy(host).dtype).pin_memory()
-            staging[slot].copy_(torch.from_numpy(host))
+            if torch.is_tensor(host) and host.is_pinned():
+                src = host                              # the producer already wrote into page-locked memory: no staging copy
+            else:
+                ht = host if torch.is_tensor(host) else torch.from_numpy(host)
+                if staging[slot] is None or staging[slot].shape != ht.shape or staging[slot].dtype != ht.dtype:
+                    staging[slot] = torch.empty(ht.shape, dtype=ht.dtype).pin_memory()
+                staging[slot].copy_(ht)
+                src = staging[slot]
             main = torch.cuda.current_stream(device)
             with torch.cuda.stream(copy_stream):
-                dev = staging[slot].to(device, non_blocking=True)
+                dev = src.to(device, non_blocking=True)
                 copied[slot].record(copy_stream)
             main.wait_event(copied[slot])
             dev.record_stream(main)

@@ -196,10 +196,11 @@ def sec_lnbench():
             try:
                 if epi in (0, 1):
                     out = torch.zeros(M, N, device=dev, dtype=torch.bfloat16)
-                    st = torch.randn(M, K // 64, 2, generator=g).abs().to(dev)
-                    c1 = torch.randn(N, generator=g).to(dev)
+                    x = torch.randn(M, K, generator=g).to(dev)              # plausible rows: partials {sum, centred M2} per 64 columns
+                    xs = x.reshape(M, K // 64, 64)
+                    st = torch.stack((xs.sum(-1), ((xs - xs.mean(-1, keepdim=True)) ** 2).sum(-1)), dim=-1).contiguous()
                     t0 = _time(lambda: gemm_nt(a, w, bias, epilogue=epi, variant=v, out=out), iters=20)
-                    t1 = _time(lambda: gemm_nt_ln(epi, a, w, bias, c1, st, variant=v, out=out), iters=20)
+                    t1 = _time(lambda: gemm_nt_ln(epi, a, w, bias, st, variant=v, out=out), iters=20)
                 else:
                     out = torch.zeros(M, N, device=dev, dtype=torch.float32)
                     t0 = _time(lambda: gemm_nt(a, w, bias, epilogue=2, variant=v, out=out), iters=20)
@@ -208,6 +209,44 @@ def sec_lnbench():
             except Exception as e:
                 row.append(f"v{v}: n/a")
         print(f"{name:6s} {M}x{N}x{K} epi{epi} plain -> folded: " + "   ".join(row))
+
+
+def sec_latency():
+    """Small-batch latency of one zero_shot_classification-sized step (the reference runs both towers at batch 8,
+    plip.py:90-91): eager launches vs hipGraph replay, wall time per call with a host sync (what a caller sees)."""
+    import time
+    cfg = get_config("ViT-B/32")
+    sd = W.synthetic_state_dict(cfg, 0)
+    model = PlipModel(cfg, sd, dtype="bf16", max_batch=32)
+    eng = model.engine
+    for B in (1, 8, 32):
+        px = torch.from_numpy(W.synthetic_pixels(cfg, B, 1)).to(dev)
+        ids = torch.from_numpy(W.synthetic_ids(cfg, B, 2)[0]).to(dev)
+        for mode, gb in (("eager", 0), ("graph", 32)):
+            eng.set_graph_batch(gb)
+            for _ in range(4):
+                eng.encode_image(px, True); eng.encode_text(ids, None, True)
+            torch.cuda.synchronize()
+            res = {}
+            for what, fn in (("image", lambda: eng.encode_image(px, True)), ("text", lambda: eng.encode_text(ids, None, True)),
+                             ("pair_2streams", lambda: eng.encode_pair(px, ids, None, True, True))):
+                for _ in range(3):
+                    fn()
+                torch.cuda.synchronize()
+                n = 30
+                t0 = time.perf_counter()
+                for _ in range(n):
+                    fn()
+                    torch.cuda.synchronize()
+                res[what] = (time.perf_counter() - t0) / n * 1e3
+                t0 = time.perf_counter()
+                for _ in range(n):
+                    fn()
+                host = (time.perf_counter() - t0) / n * 1e3        # enqueue cost only (no sync inside)
+                torch.cuda.synchronize()
+                res[what + "_enqueue"] = host
+            print(f"B={B:3d} {mode:5s}: " + "  ".join(f"{k} {v:.3f} ms" for k, v in res.items()))
+    model.engine.close()
 
 
 def sec_libgemm():
@@ -542,6 +581,6 @@ def sec_e2e():
 
 if __name__ == "__main__":
     t0 = time.time()
-    {"gemm": sec_gemm, "attn": sec_attn, "tiny": sec_tiny, "vitb32": sec_vitb32, "gemmbench": sec_gemmbench, "lnbench": sec_lnbench, "libgemm": sec_libgemm, "fp8": sec_fp8, "fp8w": sec_fp8w, "towerswap": sec_towerswap, "e2e": sec_e2e, "gemmone": sec_gemmone, "policy": sec_policy, "ldpad": sec_ldpad, "gemmtrace": sec_gemmtrace,
+    {"gemm": sec_gemm, "attn": sec_attn, "tiny": sec_tiny, "vitb32": sec_vitb32, "gemmbench": sec_gemmbench, "lnbench": sec_lnbench, "latency": sec_latency, "libgemm": sec_libgemm, "fp8": sec_fp8, "fp8w": sec_fp8w, "towerswap": sec_towerswap, "e2e": sec_e2e, "gemmone": sec_gemmone, "policy": sec_policy, "ldpad": sec_ldpad, "gemmtrace": sec_gemmtrace,
      "overlap": sec_overlap}[sys.argv[1]]()
     print(f"[{sys.argv[1]} done in {time.time() - t0:.1f} s]")

@@ -36,6 +36,20 @@ for s in $SECTIONS; do
              done; done
              python tools/pmc_summary.py gpurun_out/pmc_bench_FETCH_SIZE_ov0 gpurun_out/pmc_bench_WRITE_SIZE_ov0 gpurun_out/pmc_bench_FETCH_SIZE_ov1 gpurun_out/pmc_bench_WRITE_SIZE_ov1 > gpurun_out/pmc_traffic.json 2>> gpurun_out/pmcbench.log ;;
     torchrun1) timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline --no-fp32-tower > gpurun_out/bench_torchrun1.json 2> gpurun_out/bench_torchrun1.err ;;
+    pmcstep) # hardware counters of EVERY kernel of the step (one stream), separate passes; then HBM traffic in both stream modes
+             rm -rf gpurun_out/pmcstep_* gpurun_out/pmc_bench_*
+             i=0
+             for pass in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAVES" \
+                         "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_LDS SQ_INSTS_VALU SQ_LDS_IDX_ACTIVE"; do
+               i=$((i+1))
+               (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d "$OLDPWD/gpurun_out/pmcstep_$i" -o pmc -- python "$OLDPWD/bench.py" --steps 3 --warmup 1 --overlap 0 --no-cpu-baseline --no-profile --no-fp32-tower >> "$OLDPWD/gpurun_out/pmcstep.log" 2>&1)
+             done
+             for ov in 0 1; do for pass in "FETCH_SIZE" "WRITE_SIZE"; do
+               (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d "$OLDPWD/gpurun_out/pmc_bench_${pass}_ov$ov" -o pmc -- python "$OLDPWD/bench.py" --steps 3 --warmup 1 --overlap $ov --no-cpu-baseline --no-profile --no-fp32-tower >> "$OLDPWD/gpurun_out/pmcstep.log" 2>&1)
+             done; done
+             python tools/pmc_table.py gpurun_out/pmcstep_1 gpurun_out/pmcstep_2 gpurun_out/pmc_bench_FETCH_SIZE_ov0 gpurun_out/pmc_bench_WRITE_SIZE_ov0 > gpurun_out/pmc_step_counters.txt 2>> gpurun_out/pmcstep.log
+             python tools/pmc_summary.py gpurun_out/pmc_bench_FETCH_SIZE_ov0 gpurun_out/pmc_bench_WRITE_SIZE_ov0 gpurun_out/pmc_bench_FETCH_SIZE_ov1 gpurun_out/pmc_bench_WRITE_SIZE_ov1 > gpurun_out/pmc_traffic.json 2>> gpurun_out/pmcstep.log ;;
+    config3) timeout 900 python tools/config3_shard.py > gpurun_out/config3_shard.json 2> gpurun_out/config3_shard.err ;;
     smoke)   timeout 600 python __graft_entry__.py --smoke > gpurun_out/smoke.log 2>&1 ;;
     *)       timeout 600 python tools/gpu_diag.py $s > gpurun_out/diag_$s.log 2>&1 ;;
   esac
