@@ -241,15 +241,24 @@ def main():
     # ---- roofline of the dominant kernel: HIP events on the launch stream(s), same K steps, same stream
     # setup as the timed region; then once more single-stream, where no other kernel shares the CUs ----------
     def profile_pass(overlap):
-        rows = []
-        with model.engine.profile(rows):
+        """-> (rows merged per kernel symbol, rows per (kernel, role)); the engine tags GEMM launches 'name|role'."""
+        raw = []
+        with model.engine.profile(raw):
             for _ in range(args.steps):
                 sharded_pair_logits(model, px, ids, mask, overlap=overlap, equal_shards=True)
-        rows.sort(key=lambda r: -r["total_ms"])
-        return rows
+        merged = {}
+        for r in raw:
+            name = r["name"].split("|")[0]
+            m = merged.setdefault(name, {"name": name, "calls": 0, "total_ms": 0.0, "flops": 0.0, "bytes": 0.0})
+            for k in ("calls", "total_ms", "flops", "bytes"):
+                m[k] += r[k]
+        rows = sorted(merged.values(), key=lambda r: -r["total_ms"])
+        return rows, raw
+
+    HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
     def roofline_of(rows, name=None):
-        dom = next((r for r in rows if r["flops"] > 0 and (name is None or r["name"] == name)), None)
+        dom = next((r for r in rows if r["flops"] > 0 and r["name"].startswith("gemm") and (name is None or r["name"] == name)), None)
         if not dom:
             return None
         ach = dom["flops"] / (dom["total_ms"] * 1e-3) / 1e12
@@ -260,11 +269,33 @@ def main():
                 "flops_per_launch": round(dom["flops"] / dom["calls"]),
                 "all_gemm_tflops": round(sum(r["flops"] for r in gem) / (sum(r["total_ms"] for r in gem) * 1e9), 1)}
 
+    def by_role(raw, kernel):
+        """The dominant kernel symbol serves launches with different ceilings (out-proj: 10 B of residual traffic per
+        output element for 2*D FLOP -> HBM-bound; fc2: MFMA-bound).  Split its launches by role and price each against
+        the bound that applies (ridge = peak FLOP/s / peak B/s)."""
+        peak = PEAK_TFLOPS[args.dtype]
+        ridge = peak * 1e12 / (HBM_PEAK_GBS * 1e9)
+        out = []
+        for r in raw:
+            if r["name"].split("|")[0] != kernel or "|" not in r["name"] or not r["total_ms"]:
+                continue
+            t = r["total_ms"] * 1e-3
+            tf, gbs = r["flops"] / t / 1e12, r["bytes"] / t / 1e9
+            intensity = r["flops"] / max(r["bytes"], 1.0)
+            out.append({"role": r["name"].split("|")[1], "calls_per_step": r["calls"] / args.steps,
+                        "avg_launch_us": round(r["total_ms"] * 1e3 / r["calls"], 2), "tflops": round(tf, 1),
+                        "algorithmic_GBps": round(gbs, 1), "flop_per_byte": round(intensity, 1),
+                        "bound": "hbm" if intensity < ridge else "mfma",
+                        "frac": round(gbs / HBM_PEAK_GBS, 4) if intensity < ridge else round(tf / peak, 4),
+                        "frac_mfma": round(tf / peak, 4), "frac_hbm": round(gbs / HBM_PEAK_GBS, 4)})
+        return sorted(out, key=lambda x: -x["calls_per_step"] * x["avg_launch_us"])
+
     roofline = None
     kernels = []
     roofline_1s = None
+    roles = None
     if not args.no_profile:
-        rows = profile_pass(bool(args.overlap))
+        rows, raw = profile_pass(bool(args.overlap))
         total = sum(r["total_ms"] for r in rows) or 1.0
         kernels = [{"name": r["name"], "calls_per_step": r["calls"] / args.steps,
                     "ms_per_step": round(r["total_ms"] / args.steps, 4), "share": round(r["total_ms"] / total, 4),
@@ -277,8 +308,13 @@ def main():
             if tr:
                 roofline["traffic"] = tr["bytes_per_launch"]
                 roofline["traffic_note"] = tr["note"]
+        if roofline and not args.overlap:
+            roles = by_role(raw, roofline["kernel"])
         if args.overlap and roofline:
-            roofline_1s = roofline_of(profile_pass(False))
+            rows1, raw1 = profile_pass(False)
+            roofline_1s = roofline_of(rows1)
+            if roofline_1s:
+                roles = by_role(raw1, roofline_1s["kernel"])
             if roofline_1s:
                 tr = load_pmc_traffic(roofline_1s["kernel"])
                 if tr:
@@ -309,6 +345,10 @@ def main():
         "algorithmic_tflops": round(value * cfg.pair_flops() / 1e12, 2),
         "roofline": roofline,
         "roofline_single_stream": roofline_1s,
+        "roofline_by_role": {"note": "launches of the single-stream dominant kernel symbol split by what they compute, each priced "
+                                     "against the bound its arithmetic intensity puts it under (ridge 312 FLOP/B at 2.5 PF / 8 TB/s); "
+                                     "bytes are algorithmic (operands once, fp32 residual read + write, bf16 copy)",
+                             "roles": roles} if roles else None,
         "kernels": kernels,
     }
     try:

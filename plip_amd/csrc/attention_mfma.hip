@@ -89,8 +89,9 @@ __global__ __launch_bounds__(64 * KT) void attention_mfma_kernel(const bf16_t* _
   };
   const int bh0 = blockIdx.x * PAIRS;
   fetch(bh0);
+  const int npairs = PAIRS == 1 ? 1 : pairs;   // PAIRS == 1: a compile-time single trip, the loop folds away (64 / 80 VGPRs)
 #pragma unroll 1
-  for (int pp = 0; pp < pairs; ++pp) {
+  for (int pp = 0; pp < npairs; ++pp) {
     const int bh = bh0 + pp;
     if (bh >= n_problems) break;                    // uniform
     // Everything below that depends only on the lane (query index, key slots) is loop-invariant; hoisted out of the loop
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(64 * KT) void attention_mfma_kernel(const bf16_t* _
       for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const u32x4*>(qrow + (ks * 2 + hi) * 8);
     }
     __syncthreads();
-    if (pp + 1 < pairs && bh + 1 < n_problems) fetch(bh + 1);   // in flight during this problem's arithmetic
+    if (pp + 1 < npairs && bh + 1 < n_problems) fetch(bh + 1);   // in flight during this problem's arithmetic
 
     // scores^T tiles
     f32x16 sc[KT];
@@ -213,7 +214,7 @@ __global__ __launch_bounds__(64 * KT) void attention_mfma_kernel(const bf16_t* _
         if (r < S) *reinterpret_cast<u32x4*>(out + ((size_t)b * S + r) * D + h * 64 + c * 8) = v;
       }
     }
-    if (pp + 1 < pairs) __syncthreads();   // the next problem overwrites Ks / Vs / mk
+    if (pp + 1 < npairs) __syncthreads();   // the next problem overwrites Ks / Vs / mk
   }
 }
 

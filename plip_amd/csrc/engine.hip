@@ -261,8 +261,17 @@ int pack_tower(plipmi_engine* e, Tower& t, const plipmi_layer_weights* src, hipS
   return PLIPMI_OK;
 }
 
+// "kernel name|role": the profile keeps the launches of one kernel symbol apart by what they compute (out-proj and fc2
+// share a symbol but not a roofline: one is HBM-bound, the other MFMA-bound); bench.py merges them back per symbol.
+const char* name_with_role(const char* name, const char* role) {
+  static thread_local std::map<std::pair<const char*, const char*>, std::string> cache;
+  std::string& v = cache[std::make_pair(name, role)];
+  if (v.empty()) v = std::string(name) + "|" + role;
+  return v.c_str();
+}
+
 int run_gemm(plipmi_engine* e, int epi, const void* A, const void* W, void* C, const float* bias, int M, int N, int K,
-             int ldc, int np, hipStream_t s, const LnArgs* ln = nullptr) {
+             int ldc, int np, hipStream_t s, const char* role, const LnArgs* ln = nullptr) {
   GemmParams p;
   p.A = A; p.W = W; p.C = C; p.bias = bias;
   p.M = M; p.N = N; p.K = K; p.lda = K; p.ldw = K; p.ldc = ldc; p.alpha = 1.f; p.np = np;
@@ -276,7 +285,7 @@ int run_gemm(plipmi_engine* e, int epi, const void* A, const void* W, void* C, c
                            : (double)M * N * (epi_is_resid(epi) ? 8.0 : 4.0) + (epi == EPI_RESID_EMIT ? (double)M * N * 2.0 : 0.0);
   Scope sc(e, s, name, 2.0 * M * N * (double)K, ((double)M * K + (double)N * K) * e->esz + out_bytes);
   const int rc = gemm_launch(e->dtype, epi, -1, p, s, &name, e->gemm_policy);
-  sc.rename(name);
+  if (e->prof) sc.rename(name_with_role(name, role));
   if (rc != 0) return fail(PLIPMI_ERR_HIP, "gemm launch (%s, M=%d N=%d K=%d) failed: %s", name, M, N, K,
                            hipGetErrorString((hipError_t)rc));
   return PLIPMI_OK;
@@ -316,12 +325,12 @@ int run_layers(plipmi_engine* e, Tower& t, int B, int n_layers, int causal, cons
     LnArgs emit; emit.xb_out = t.h; emit.st_out = t.st;
     for (int l = 0; l < n_layers; ++l) {
       const LayerW& w = t.layers[l];
-      RUN(run_gemm(e, EPI_BIAS_LN, t.h, w.wqkv, t.qkv, w.bqkv, M, 3 * D, D, 3 * D, 0, s, &use));
+      RUN(run_gemm(e, EPI_BIAS_LN, t.h, w.wqkv, t.qkv, w.bqkv, M, 3 * D, D, 3 * D, 0, s, "qkv", &use));
       RUN(attention());
-      RUN(run_gemm(e, EPI_RESID_EMIT, t.att, w.wo, t.x, w.bo, M, D, D, D, 0, s, &emit));
-      RUN(run_gemm(e, EPI_QGELU_LN, t.h, w.w1, t.mlp, w.b1, M, F, D, F, 0, s, &use));
-      if (l + 1 < n_layers) RUN(run_gemm(e, EPI_RESID_EMIT, t.mlp, w.w2, t.x, w.b2, M, D, F, D, 0, s, &emit));
-      else RUN(run_gemm(e, EPI_BIAS_RESID, t.mlp, w.w2, t.x, w.b2, M, D, F, D, 0, s));   // nothing reads LN partials after the last block
+      RUN(run_gemm(e, EPI_RESID_EMIT, t.att, w.wo, t.x, w.bo, M, D, D, D, 0, s, "out_proj", &emit));
+      RUN(run_gemm(e, EPI_QGELU_LN, t.h, w.w1, t.mlp, w.b1, M, F, D, F, 0, s, "fc1", &use));
+      if (l + 1 < n_layers) RUN(run_gemm(e, EPI_RESID_EMIT, t.mlp, w.w2, t.x, w.b2, M, D, F, D, 0, s, "fc2", &emit));
+      else RUN(run_gemm(e, EPI_BIAS_RESID, t.mlp, w.w2, t.x, w.b2, M, D, F, D, 0, s, "fc2"));   // nothing reads LN partials after the last block
     }
     return PLIPMI_OK;
   }
@@ -334,10 +343,10 @@ int run_layers(plipmi_engine* e, Tower& t, int B, int n_layers, int causal, cons
     } else {
       { Scope sc(e, s, "layernorm", 0, (double)M * D * (4 + e->esz));
         HIP_TRY(launch_layernorm(t.x, D, w.ln1w, w.ln1b, t.h, e->dtype, M, D, eps, s)); }
-      RUN(run_gemm(e, EPI_BIAS, t.h, w.wqkv, t.qkv, w.bqkv, M, 3 * D, D, 3 * D, 0, s));
+      RUN(run_gemm(e, EPI_BIAS, t.h, w.wqkv, t.qkv, w.bqkv, M, 3 * D, D, 3 * D, 0, s, "qkv"));
     }
     RUN(attention());
-    RUN(run_gemm(e, EPI_BIAS_RESID, t.att, w.wo, t.x, w.bo, M, D, D, D, 0, s));
+    RUN(run_gemm(e, EPI_BIAS_RESID, t.att, w.wo, t.x, w.bo, M, D, D, D, 0, s, "out_proj"));
     if (e->fp8w) {
       { Scope sc(e, s, "layernorm_fp8", 0, (double)M * D * 5);
         HIP_TRY(launch_layernorm_fp8(t.x, D, w.ln2w, w.ln2b, t.h8, t.hs, M, D, eps, s)); }
@@ -345,9 +354,9 @@ int run_layers(plipmi_engine* e, Tower& t, int B, int n_layers, int causal, cons
     } else {
       { Scope sc(e, s, "layernorm", 0, (double)M * D * (4 + e->esz));
         HIP_TRY(launch_layernorm(t.x, D, w.ln2w, w.ln2b, t.h, e->dtype, M, D, eps, s)); }
-      RUN(run_gemm(e, EPI_BIAS_QGELU, t.h, w.w1, t.mlp, w.b1, M, F, D, F, 0, s));
+      RUN(run_gemm(e, EPI_BIAS_QGELU, t.h, w.w1, t.mlp, w.b1, M, F, D, F, 0, s, "fc1"));
     }
-    RUN(run_gemm(e, EPI_BIAS_RESID, t.mlp, w.w2, t.x, w.b2, M, D, F, D, 0, s));
+    RUN(run_gemm(e, EPI_BIAS_RESID, t.mlp, w.w2, t.x, w.b2, M, D, F, D, 0, s, "fc2"));
   }
   return PLIPMI_OK;
 }
@@ -364,7 +373,7 @@ int vision_embed(plipmi_engine* e, const float* pixels, const uint8_t* tiles_u8,
     HIP_TRY(launch_unfold_patches(pixels, e->patches, e->dtype, B, g.image_size, g.patch_size, e->kpad, s)); }
   { Scope sc(e, s, "cls_rows", 0, (double)B * t.D * 4);
     HIP_TRY(launch_cls_rows(e->cls, e->vpos, t.x, B, t.S, t.D, s)); }
-  RUN(run_gemm(e, EPI_PATCH, e->patches, e->patch_w, t.x, e->vpos, B * e->np, t.D, e->kpad, t.D, e->np, s));
+  RUN(run_gemm(e, EPI_PATCH, e->patches, e->patch_w, t.x, e->vpos, B * e->np, t.D, e->kpad, t.D, e->np, s, "patch_embed"));
   if (e->ln_fold) {   // the tower's one LayerNorm pass; it also hands the first block bf16(x) and the row statistics
     Scope sc(e, s, "layernorm", 0, (double)B * t.S * t.D * 10.2);
     HIP_TRY(launch_layernorm_emit(t.x, e->pre_w, e->pre_b, t.h, t.st, B * t.S, t.D, g.layer_norm_eps, s));

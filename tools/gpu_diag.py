@@ -484,12 +484,12 @@ def sec_policy():
     ids_np, mask_np = W.synthetic_ids(cfg, B, 2)
     ids, mask = torch.from_numpy(ids_np).to(dev), torch.from_numpy(mask_np).to(dev)
     model = PlipModel(cfg, sd, dtype="bf16", max_batch=B)
-    pols = [-1, -12, -13]            # -1: cost model / pair policy 1, -12: cost model / pair policy 2 (hybrid)
+    pols = [-10, -1, -12, -13]       # one stream: always the cost model; two streams: pair policy 0 (cost model) / 1 / 2 / 3
     res = {(p, ov): [] for p in pols for ov in (False, True)}
     for rep in range(4):
         for pol in pols:
             lib.plipmi_set_gemm_variant(pol if pol >= 0 else -1)
-            model.engine.pair_policy = {-12: 2, -13: 3}.get(pol, 1)
+            model.engine.pair_policy = {-10: 0, -12: 2, -13: 3}.get(pol, 1)
             for ov in (False, True):
                 ms = _time(lambda: sharded_pair_logits(model, px, ids, mask, overlap=ov), iters=10, warm=2)
                 if rep:                      # rep 0 = warm-up of clocks / caches
@@ -498,7 +498,8 @@ def sec_policy():
     names = gemm_variants()
     for pol in pols:
         a, b = res[(pol, False)], res[(pol, True)]
-        label = {-1: "cost model/pair policy 1", -12: "cost model/pair policy 2", -13: "cost model/pair policy 3"}.get(pol) or names[pol]
+        label = {-10: "cost model/pair policy 0", -1: "cost model/pair policy 1", -12: "cost model/pair policy 2",
+                 -13: "cost model/pair policy 3"}.get(pol) or names[pol]
         print(f"policy {label:34s} one stream {np.median(a):6.3f} ms (min {min(a):6.3f})   "
               f"two streams {np.median(b):6.3f} ms (min {min(b):6.3f})  -> {B / np.median(b) * 1e3:7.0f} pairs/s")
 
