@@ -149,6 +149,22 @@ def cpu_baseline(cfg, sd, seconds):
     return res
 
 
+def executed_gflop_per_pair(cfg, args):
+    """`algorithmic_tflops` prices a pair at SURVEY.md section 8d's dense figure (14.777 GFLOP for ViT-B/32: every token
+    through every Linear).  The bf16 engine runs the LAST block's out_proj / fc1 / fc2 only on the row that is pooled
+    afterwards (CLS / EOS) -- the other rows of that block cannot reach get_image_features / get_text_features -- so it
+    executes slightly fewer FLOPs than that; kernel rooflines always use executed FLOPs."""
+    full = cfg.pair_flops()
+    pooled = args.dtype == "bf16" and os.environ.get("PLIPMI_POOLED_LAST_BLOCK", "1") != "0" and \
+        os.environ.get("PLIPMI_LN_FOLD", "1") != "0"
+    saved = 0.0
+    if pooled:
+        for tokens, D, F in ((cfg.v_tokens, cfg.v_width, cfg.v_mlp), (cfg.context_length, cfg.t_width, cfg.t_mlp)):
+            saved += (tokens - 1) * (2.0 * D * D + 4.0 * D * F)
+    return {"dense_reference": round(full / 1e9, 4), "executed": round((full - saved) / 1e9, 4),
+            "pooled_last_block": bool(pooled)}
+
+
 def logits_error_vs_hf_golden(model, cfg, sd, px, ids, mask, B, args):
     """BASELINE.json metric, second half: "logits max-abs-err vs HF".  Rank 0's timed batch (weights seed 0, pixels seed
     1000, ids seed 2000, bs=256, ViT-B/32) is exactly the input of tests/golden/vitb32_b256.npz, whose logits come from
@@ -343,6 +359,7 @@ def main():
                    "collective": "none" if world == 1 else "RCCL all-gather of [B,512] fp32 image+text embeddings",
                    "streams": 2 if args.overlap else 1, "device": model.engine.device_name},
         "algorithmic_tflops": round(value * cfg.pair_flops() / 1e12, 2),
+        "executed_gflop_per_pair": executed_gflop_per_pair(cfg, args),
         "roofline": roofline,
         "roofline_single_stream": roofline_1s,
         "roofline_by_role": {"note": "launches of the single-stream dominant kernel symbol split by what they compute, each priced "

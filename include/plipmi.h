@@ -204,7 +204,8 @@ int plipmi_debug_hidden(plipmi_handle h, int tower, int layer, const void* input
  *            2: C(f32) += acc + bias         3: C(f32)   = alpha * acc
  *   variant  -1 = the engine's own choice, >= 0 = a specific tile configuration
  *            (plipmi_gemm_variant_name lists them; NULL past the end);
- *            variant -2 = the naive one-thread-per-output checker kernel. */
+ *            variant -2 = the naive one-thread-per-output checker kernel;
+ *            variant -3 = the small-M split-K kernel (bf16; epilogues 0..2; N % 64 == 0, K % 256 == 0). */
 int plipmi_gemm_nt(int dtype, int epilogue, int variant, int M, int N, int K, const void* A, const void* W,
                    const float* bias, float alpha, void* C, void* stream);
 const char* plipmi_gemm_variant_name(int variant);

@@ -64,6 +64,8 @@ struct Tower {
   void* h8 = nullptr;   // fp8-weights mode: LayerNorm output as fp8 rows ...
   float* hs = nullptr;  // ... with one dynamic scale per row
   float* st = nullptr;  // LayerNorm-folded engine: statistics partials of the residual rows [M, D/64, 2]; h = bf16(x)
+  // last block, pooled rows only (one row per sample): residual row, attention output, bf16 copy, MLP hidden, partials
+  float* xp = nullptr; void *attp = nullptr, *hp = nullptr, *mlpp = nullptr; float* stp = nullptr;
 };
 struct LnArgs {         // the LayerNorm side of a folded GEMM (gemm.h EPI_*_LN / EPI_RESID_EMIT)
   const float* stats = nullptr; int ns = 0; float inv_d = 0.f, eps = 0.f;   // consumer
@@ -93,6 +95,10 @@ struct plipmi_engine {
   // bf16 engine: the 2 x L LayerNorms of the blocks are folded into the GEMMs around them (no LayerNorm pass, no
   // normalised activations in memory); PLIPMI_LN_FOLD=0 restores the separate LayerNorm kernels for A/B runs
   bool ln_fold = false;
+  // The last block's out_proj / fc1 / fc2 (and both of its residual adds) only ever reach the output through the row that
+  // is pooled afterwards (CLS / EOS): the encode paths run them on that one row per sample (PLIPMI_POOLED_LAST_BLOCK=0
+  // computes all rows, as plipmi_debug_hidden always does).  bf16 LayerNorm-folded engine only.
+  bool pooled_last = false;
   int gemm_policy = 0;  // tile policy of this handle's GEMMs (plipmi_set_gemm_policy)
   // small-batch hipGraph replay (plipmi_set_graph_batch; PLIPMI_GRAPH_BATCH): batches of at most this many samples
   int graph_batch = 0;
@@ -202,6 +208,10 @@ void carve(plipmi_engine* e, Carver& c) {
     t->h = c.take<void>(M * D, es);
     if (e->fp8w) { t->h8 = c.take<void>(M * D, 1); t->hs = c.take<float>(M, 4); }
     if (e->ln_fold) t->st = c.take<float>(M * (D / kLnSlice) * 2, 4);
+    if (e->pooled_last) {
+      t->xp = c.take<float>(B * D, 4); t->attp = c.take<void>(B * D, es); t->hp = c.take<void>(B * D, es);
+      t->mlpp = c.take<void>(B * F, es); t->stp = c.take<float>(B * (D / kLnSlice) * 2, 4);
+    }
     t->qkv = c.take<void>(M * 3 * D, es);
     t->att = c.take<void>(M * D, es);
     t->mlp = c.take<void>(M * F, es);
@@ -279,12 +289,16 @@ int run_gemm(plipmi_engine* e, int epi, const void* A, const void* W, void* C, c
     p.ln_stats = ln->stats; p.ln_ns = ln->ns; p.ln_inv_d = ln->inv_d; p.ln_eps = ln->eps;
     p.xb_out = ln->xb_out; p.st_out = ln->st_out;
   }
+  const bool skinny = role[0] == '~';     // '~role': pooled-row GEMM of the last block -> the small-M split-K kernel when it fits
+  if (skinny) ++role;
   const char* name = "gemm_nt";
   // algorithmic bytes: operands once, output once (bf16 outputs 2 B, fp32 residual read + written, + bf16 copy when emitted)
   const double out_bytes = epi_is_colwise(epi) ? (double)M * N * e->esz
                            : (double)M * N * (epi_is_resid(epi) ? 8.0 : 4.0) + (epi == EPI_RESID_EMIT ? (double)M * N * 2.0 : 0.0);
   Scope sc(e, s, name, 2.0 * M * N * (double)K, ((double)M * K + (double)N * K) * e->esz + out_bytes);
-  const int rc = gemm_launch(e->dtype, epi, -1, p, s, &name, e->gemm_policy);
+  const int rc = (skinny && e->dtype == PLIPMI_BF16 && gemm_skinny_supports(epi, M, N, K))
+                     ? gemm_launch_skinny(epi, p, s, &name)
+                     : gemm_launch(e->dtype, epi, -1, p, s, &name, e->gemm_policy);
   if (e->prof) sc.rename(name_with_role(name, role));
   if (rc != 0) return fail(PLIPMI_ERR_HIP, "gemm launch (%s, M=%d N=%d K=%d) failed: %s", name, M, N, K,
                            hipGetErrorString((hipError_t)rc));
@@ -307,7 +321,8 @@ int run_gemm_fp8(plipmi_engine* e, int epi, const void* A8, const float* row_sca
 #define RUN(expr) do { int rc_ = (expr); if (rc_ != PLIPMI_OK) return rc_; } while (0)
 
 // n_layers pre-LN residual blocks over the tower's residual stream x (CLIPEncoderLayer, modeling_clip.py:362-383)
-int run_layers(plipmi_engine* e, Tower& t, int B, int n_layers, int causal, const int64_t* key_mask, hipStream_t s) {
+int run_layers(plipmi_engine* e, Tower& t, int B, int n_layers, int causal, const int64_t* key_mask, hipStream_t s,
+               bool more_follow = false) {
   const int M = B * t.S, D = t.D, F = t.F;
   const float eps = e->cfg.layer_norm_eps;
   const int impl = (&t == &e->vis) ? e->attn_impl_vis : e->attn_impl_txt;
@@ -329,7 +344,7 @@ int run_layers(plipmi_engine* e, Tower& t, int B, int n_layers, int causal, cons
       RUN(attention());
       RUN(run_gemm(e, EPI_RESID_EMIT, t.att, w.wo, t.x, w.bo, M, D, D, D, 0, s, "out_proj", &emit));
       RUN(run_gemm(e, EPI_QGELU_LN, t.h, w.w1, t.mlp, w.b1, M, F, D, F, 0, s, "fc1", &use));
-      if (l + 1 < n_layers) RUN(run_gemm(e, EPI_RESID_EMIT, t.mlp, w.w2, t.x, w.b2, M, D, F, D, 0, s, "fc2", &emit));
+      if (l + 1 < n_layers || more_follow) RUN(run_gemm(e, EPI_RESID_EMIT, t.mlp, w.w2, t.x, w.b2, M, D, F, D, 0, s, "fc2", &emit));
       else RUN(run_gemm(e, EPI_BIAS_RESID, t.mlp, w.w2, t.x, w.b2, M, D, F, D, 0, s, "fc2"));   // nothing reads LN partials after the last block
     }
     return PLIPMI_OK;
@@ -358,6 +373,31 @@ int run_layers(plipmi_engine* e, Tower& t, int B, int n_layers, int causal, cons
     }
     RUN(run_gemm(e, EPI_BIAS_RESID, t.mlp, w.w2, t.x, w.b2, M, D, F, D, 0, s, "fc2"));
   }
+  return PLIPMI_OK;
+}
+
+// The last block on the pooled rows only.  CLIPModel.get_image_features / get_text_features (modeling_clip.py:683-753) hand
+// back the projection of ONE row per sample -- CLS after post_layernorm (:650), the EOS row after final_layer_norm
+// (:559-581) -- so of the last block's work only q/k/v + attention need every token (keys and values); its out_proj, both
+// residual adds, LayerNorm 2, fc1 and fc2 are row-wise and reach the output through that one row.  The reference computes
+// them for all 50 / 77 tokens because CLIPModel also returns last_hidden_state, which this path does not.  Results are
+// those of the full computation on the pooled rows (same arithmetic, row by row); plipmi_debug_hidden runs the full block.
+int run_last_block_pooled(plipmi_engine* e, Tower& t, int B, int causal, const int64_t* key_mask, const int64_t* ids,
+                          int eos_id, hipStream_t s) {
+  const int M = B * t.S, D = t.D, F = t.F;
+  const LayerW& w = t.layers[t.L - 1];
+  const int impl = (&t == &e->vis) ? e->attn_impl_vis : e->attn_impl_txt;
+  LnArgs use; use.stats = t.st; use.ns = D / kLnSlice; use.inv_d = 1.0f / (float)D; use.eps = e->cfg.layer_norm_eps;
+  RUN(run_gemm(e, EPI_BIAS_LN, t.h, w.wqkv, t.qkv, w.bqkv, M, 3 * D, D, 3 * D, 0, s, "qkv", &use));
+  { Scope sc(e, s, impl ? "attention_mfma" : "attention_valu", 4.0 * B * t.H * (double)t.S * t.S * 64, (double)M * 4 * D * e->esz);
+    HIP_TRY(launch_attention(t.qkv, t.att, e->dtype, B, t.S, t.H, causal, key_mask, impl, s)); }
+  { Scope sc(e, s, "pool_gather", 0, (double)B * D * (2 * e->esz + 8));
+    HIP_TRY(launch_pool_gather(t.att, t.x, t.S, D, ids, eos_id, t.attp, t.xp, B, s)); }
+  LnArgs emit; emit.xb_out = t.hp; emit.st_out = t.stp;
+  RUN(run_gemm(e, EPI_RESID_EMIT, t.attp, w.wo, t.xp, w.bo, B, D, D, D, 0, s, "~out_proj_pooled", &emit));
+  use.stats = t.stp;
+  RUN(run_gemm(e, EPI_QGELU_LN, t.hp, w.w1, t.mlpp, w.b1, B, F, D, F, 0, s, "~fc1_pooled", &use));
+  RUN(run_gemm(e, EPI_BIAS_RESID, t.mlpp, w.w2, t.xp, w.b2, B, D, F, D, 0, s, "~fc2_pooled"));
   return PLIPMI_OK;
 }
 
@@ -395,19 +435,19 @@ int text_embed(plipmi_engine* e, const int64_t* ids, int B, hipStream_t s) {
 // pooled row -> LayerNorm -> bias-free projection (-> L2 normalise).  Widths that are multiples of 32 (every
 // config plipmi_create accepts today) run the projection on the split-K exact-fp32 MFMA head kernel; the fused
 // one-block-per-sample kernel covers anything else.
-int run_head(plipmi_engine* e, Tower& t, const int64_t* ids, int eos_id, const float* ln_w, const float* ln_b,
-             const float* W, const float* Wt, float* pooled, float* out, int B, int normalize, hipStream_t s) {
+int run_head(plipmi_engine* e, Tower& t, const float* x, int S, const int64_t* ids, int eos_id, const float* ln_w,
+             const float* ln_b, const float* W, const float* Wt, float* pooled, float* out, int B, int normalize, hipStream_t s) {
   const int P = e->cfg.projection_dim, D = t.D;
   if (P % 32 == 0 && D % 32 == 0) {
     { Scope sc(e, s, "pool_layernorm", 0, (double)B * D * 8);
-      HIP_TRY(launch_pool_layernorm(t.x, t.S, D, ids, eos_id, ln_w, ln_b, e->cfg.layer_norm_eps, pooled, B, s)); }
+      HIP_TRY(launch_pool_layernorm(x, S, D, ids, eos_id, ln_w, ln_b, e->cfg.layer_norm_eps, pooled, B, s)); }
     { Scope sc(e, s, "head_gemm", 2.0 * B * P * (double)D, ((double)B * D + (double)P * D + (double)B * P) * 4);
       HIP_TRY(launch_head_gemm(pooled, W, out, B, P, D, s)); }
     if (normalize) { Scope sc(e, s, "l2_normalize", 0, (double)B * P * 8); HIP_TRY(launch_l2_normalize(out, B, P, s)); }
     return PLIPMI_OK;
   }
   Scope sc(e, s, "pool_head", 2.0 * B * D * P, (double)D * P * 4);
-  HIP_TRY(launch_pool_head(t.x, t.S, D, ids, eos_id, ln_w, ln_b, e->cfg.layer_norm_eps, Wt, P, out, B, normalize, s));
+  HIP_TRY(launch_pool_head(x, S, D, ids, eos_id, ln_w, ln_b, e->cfg.layer_norm_eps, Wt, P, out, B, normalize, s));
   return PLIPMI_OK;
 }
 
@@ -422,14 +462,24 @@ int check_batch(plipmi_engine* e, int B) {
 int image_forward(plipmi_handle h, const float* pixels, const uint8_t* tiles, int B, float* out, int normalize,
                          hipStream_t s) {
   RUN(vision_embed(h, pixels, tiles, B, s));
+  if (h->pooled_last) {
+    RUN(run_layers(h, h->vis, B, h->vis.L - 1, 0, nullptr, s, /*more_follow=*/true));
+    RUN(run_last_block_pooled(h, h->vis, B, 0, nullptr, nullptr, -1, s));
+    return run_head(h, h->vis, h->vis.xp, 1, nullptr, -1, h->post_w, h->post_b, h->vproj, h->vproj_t, h->vpooled, out, B, normalize, s);
+  }
   RUN(run_layers(h, h->vis, B, h->vis.L, 0, nullptr, s));
-  return run_head(h, h->vis, nullptr, -1, h->post_w, h->post_b, h->vproj, h->vproj_t, h->vpooled, out, B, normalize, s);
+  return run_head(h, h->vis, h->vis.x, h->vis.S, nullptr, -1, h->post_w, h->post_b, h->vproj, h->vproj_t, h->vpooled, out, B, normalize, s);
 }
 int text_forward(plipmi_handle h, const int64_t* ids, const int64_t* mask, int B, int eos_token_id, float* out,
                         int normalize, hipStream_t s) {
   RUN(text_embed(h, ids, B, s));
+  if (h->pooled_last) {
+    RUN(run_layers(h, h->txt, B, h->txt.L - 1, 1, mask, s, /*more_follow=*/true));
+    RUN(run_last_block_pooled(h, h->txt, B, 1, mask, ids, eos_token_id, s));
+    return run_head(h, h->txt, h->txt.xp, 1, nullptr, -1, h->fin_w, h->fin_b, h->tproj, h->tproj_t, h->tpooled, out, B, normalize, s);
+  }
   RUN(run_layers(h, h->txt, B, h->txt.L, 1, mask, s));
-  return run_head(h, h->txt, ids, eos_token_id, h->fin_w, h->fin_b, h->tproj, h->tproj_t, h->tpooled, out, B, normalize, s);
+  return run_head(h, h->txt, h->txt.x, h->txt.S, ids, eos_token_id, h->fin_w, h->fin_b, h->tproj, h->tproj_t, h->tpooled, out, B, normalize, s);
 }
 
 // Small batches: replay a captured graph of the same launches.  kind 0 = fp32 pixels, 1 = uint8 tiles, 2 = text.
@@ -506,7 +556,9 @@ int plipmi_create(const plipmi_config* cfg, const plipmi_weights* w, void* strea
   e->dtype = e->fp8w ? PLIPMI_BF16 : g.compute_dtype;
   e->esz = e->dtype == PLIPMI_BF16 ? 2 : 4;
   { const char* lf = getenv("PLIPMI_LN_FOLD");
-    e->ln_fold = e->dtype == PLIPMI_BF16 && !e->fp8w && !(lf && atoi(lf) == 0); }
+    e->ln_fold = e->dtype == PLIPMI_BF16 && !e->fp8w && !(lf && atoi(lf) == 0);
+    const char* pl = getenv("PLIPMI_POOLED_LAST_BLOCK");
+    e->pooled_last = e->ln_fold && !(pl && atoi(pl) == 0); }
   { const char* gb = getenv("PLIPMI_GRAPH_BATCH");
     e->graph_batch_cap = std::min(g.max_batch, 32);
     e->graph_batch = gb ? std::max(0, std::min(atoi(gb), e->graph_batch_cap)) : e->graph_batch_cap; }
@@ -775,7 +827,9 @@ int plipmi_gemm_nt_traced(int dtype, int epilogue, int variant, int M, int N, in
   p.A = A; p.W = W; p.C = C; p.bias = bias; p.M = M; p.N = N; p.K = K; p.lda = K; p.ldw = K; p.ldc = N;
   p.alpha = alpha; p.np = 1;
   p.trace = reinterpret_cast<unsigned long long*>(trace);
-  const int rc = gemm_launch(dtype, epilogue, variant, p, reinterpret_cast<hipStream_t>(stream), nullptr);
+  const int rc = (variant == -3 && dtype == PLIPMI_BF16)     // -3: the small-M split-K kernel (gemm_skinny.hip)
+                     ? gemm_launch_skinny(epilogue, p, reinterpret_cast<hipStream_t>(stream), nullptr)
+                     : gemm_launch(dtype, epilogue, variant, p, reinterpret_cast<hipStream_t>(stream), nullptr);
   if (rc != 0) return fail(PLIPMI_ERR_HIP, "gemm launch failed (variant %d, M=%d N=%d K=%d): %s", variant, M, N, K,
                            hipGetErrorString((hipError_t)rc));
   return PLIPMI_OK;
@@ -791,7 +845,8 @@ int plipmi_gemm_nt_ln(int mode, int variant, int M, int N, int K, const void* A,
   p.ln_stats = stats; p.ln_ns = ns; p.ln_inv_d = ns > 0 ? 1.0f / (float)(ns * kLnSlice) : 0.f; p.ln_eps = eps;
   p.xb_out = xb_out; p.st_out = st_out;
   const int epi = mode == 0 ? EPI_BIAS_LN : mode == 1 ? EPI_QGELU_LN : EPI_RESID_EMIT;
-  const int rc = gemm_launch(PLIPMI_BF16, epi, variant, p, reinterpret_cast<hipStream_t>(stream), nullptr);
+  const int rc = variant == -3 ? gemm_launch_skinny(epi, p, reinterpret_cast<hipStream_t>(stream), nullptr)
+                               : gemm_launch(PLIPMI_BF16, epi, variant, p, reinterpret_cast<hipStream_t>(stream), nullptr);
   if (rc != 0) return fail(PLIPMI_ERR_HIP, "gemm launch failed (LN mode %d, variant %d, M=%d N=%d K=%d): %s", mode, variant, M, N, K,
                            hipGetErrorString((hipError_t)rc));
   return PLIPMI_OK;

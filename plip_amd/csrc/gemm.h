@@ -856,6 +856,9 @@ int gemm_launch(int dtype, int epi, int variant, const GemmParams& p, hipStream_
 int gemm_default_variant(int dtype, int M, int N, int K, int epi = -1, int policy = 0);
 bool gemm_variant_is_built(int dtype, int variant);
 int gemm_launch_fp8(int epi, int variant, const GemmParams& p, hipStream_t stream);  // experimental test hook
+// small-M bf16 kernel (gemm_skinny.hip): 32 x 64 output tile per workgroup, K split over its four waves, operands from L2
+bool gemm_skinny_supports(int epi, int M, int N, int K);
+int gemm_launch_skinny(int epi, const GemmParams& p, hipStream_t stream, const char** kernel_name);
 void gemm_set_default_override(int variant);  // PLIPMI_GEMM_VARIANT / tests (process-wide A/B hook, not a product knob)
 
 }  // namespace plipmi

@@ -1,0 +1,198 @@
+// gemm_skinny.hip -- the NT GEMM for SMALL M (latency regime):  C = epilogue(A[M,K] . W[N,K]^T), bf16 operands.
+//
+// Where the big-tile kernel (gemm.h) walks K one 64-deep tile after the other on a handful of workgroups -- M = 256
+// rows x N = 768 is 12 workgroups of 128x128, each 48 dependent K iterations for fc2 = 35-55 us -- this kernel spends
+// the chip's width on N, on M and on K at once:
+//   * one workgroup (NW = 4 or 8 waves) owns a 32 x 64 output tile and its waves split K NW ways (fixed-order reduction
+//     through LDS: deterministic, independent of M); a wave requests NB 64-deep blocks of both operands (all of its share
+//     when that is <= 3 blocks) before the first MFMA, so its K walk is 1-3 memory round trips, not one per block;
+//   * operands come straight from L2 as MFMA fragments -- no LDS staging, nothing to synchronise in the K loop.  The k
+//     index inside an MFMA may be permuted freely as long as both operands share the permutation, so a lane fetches 64
+//     CONTIGUOUS bytes of its row per 64-deep block (lanes l and l+32 together one whole 128-byte line) and feeds
+//     MFMA t of the block from the t-th 16-byte piece;
+//   * the same fused epilogues as the big kernel's LayerNorm-folded family: rstd * acc + c2 (-> bf16, optional
+//     QuickGELU), and the in-place fp32 residual update that also emits bf16(x) and the row's {sum, centred M2} of the
+//     64-column slice (= exactly this tile's width).
+// Used by the bf16 engine (a) for every Linear of a small batch (B <= ~10 images: zero_shot_classification runs at 8,
+// plip.py:90-91) and (b) for the LAST block of each tower, whose out_proj / fc1 / fc2 only ever matter for the pooled
+// row of each sample (engine.hip: run_last_block_pooled).
+#include "gemm.h"
+
+namespace plipmi {
+
+namespace {
+
+constexpr int SK_BM = 32, SK_BN = 64, SK_PITCH = 68;   // floats per LDS row of a partial tile (272 B: conflict-free b128)
+
+__device__ __forceinline__ float row8_sum(float v) {    // sum over the 8 lanes 8r .. 8r+7, result in all of them
+  v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141>(v);  // row_half_mirror: lane i <-> 7 - i inside each 8-lane half of a DPP row
+  return v;
+}
+
+template <int EPI, int NW, int NB>
+__global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(const GemmParams p) {
+  __shared__ __attribute__((aligned(16))) float part[NW][SK_BM][SK_PITCH];
+  __shared__ float rs_s[SK_BM];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lrow = lane & 31, hi = lane >> 5;
+  const int n0 = blockIdx.x * SK_BN, m0 = blockIdx.y * SK_BM;
+  const int kw = p.K / NW;                                   // this wave's share of K (a multiple of 64 * NB)
+  const int mr = m0 + lrow < p.M ? m0 + lrow : p.M - 1;      // M edge: re-read the last row, stores are masked
+  const bf16_t* ap = reinterpret_cast<const bf16_t*>(p.A) + (size_t)mr * p.lda + wave * kw + 32 * hi;
+  const bf16_t* w0 = reinterpret_cast<const bf16_t*>(p.W) + (size_t)(n0 + lrow) * p.ldw + wave * kw + 32 * hi;
+  const bf16_t* w1 = w0 + (size_t)32 * p.ldw;
+
+  if constexpr (epi_is_ln(EPI)) {                            // rstd of the tile's rows, while the first operands travel
+    if (tid < SK_BM) {
+      const int r = m0 + tid < p.M ? m0 + tid : p.M - 1;
+      float mu, rs;
+      ln_combine(p.ln_stats + (size_t)r * p.ln_ns * 2, p.ln_ns, p.ln_inv_d, p.ln_eps, mu, rs);
+      rs_s[tid] = rs;
+    }
+  }
+
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
+#pragma unroll 1
+  for (int kk = 0; kk < kw; kk += 64 * NB) {
+    u32x4 xa[NB][4], wa[NB][4], wb[NB][4];
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        xa[b][t] = *reinterpret_cast<const u32x4*>(ap + kk + 64 * b + 8 * t);
+        wa[b][t] = *reinterpret_cast<const u32x4*>(w0 + kk + 64 * b + 8 * t);
+        wb[b][t] = *reinterpret_cast<const u32x4*>(w1 + kk + 64 * b + 8 * t);
+      }
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wa[b][t]), __builtin_bit_cast(bf16x8, xa[b][t]), acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wb[b][t]), __builtin_bit_cast(bf16x8, xa[b][t]), acc1, 0, 0, 0);
+      }
+  }
+  // partial tile of this wave, row-major: acc[4q+e] = C[m = lrow][n = 8q + 4hi + e] of its 32-column half
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    *reinterpret_cast<f32x4*>(&part[wave][lrow][8 * q + 4 * hi]) = f32x4{acc0[4 * q], acc0[4 * q + 1], acc0[4 * q + 2], acc0[4 * q + 3]};
+    *reinterpret_cast<f32x4*>(&part[wave][lrow][32 + 8 * q + 4 * hi]) = f32x4{acc1[4 * q], acc1[4 * q + 1], acc1[4 * q + 2], acc1[4 * q + 3]};
+  }
+  __syncthreads();
+  // threads 0..255 -> row r, 8 consecutive columns; the NW K partials are added in a fixed order (pairs, then pairs of pairs)
+  if (tid >= 256) return;                          // waves 4.. (NW = 8) have handed their partials over
+  const int r = tid >> 3, c8 = (tid & 7) * 8;
+  float v[8];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    f32x4 sum4[NW / 4];
+#pragma unroll
+    for (int g = 0; g < NW / 4; ++g) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(&part[4 * g + 0][r][c8 + 4 * h]), b = *reinterpret_cast<const f32x4*>(&part[4 * g + 1][r][c8 + 4 * h]);
+      const f32x4 c = *reinterpret_cast<const f32x4*>(&part[4 * g + 2][r][c8 + 4 * h]), d = *reinterpret_cast<const f32x4*>(&part[4 * g + 3][r][c8 + 4 * h]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sum4[g][e] = (a[e] + b[e]) + (c[e] + d[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[4 * h + e] = NW == 8 ? sum4[0][e] + sum4[NW / 4 - 1][e] : sum4[0][e];
+  }
+  const int m = m0 + r, n = n0 + c8;
+  const bool in_range = m < p.M;
+  const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n), b1 = *reinterpret_cast<const float4*>(p.bias + n + 4);
+  const float bias[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+  typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8v;
+  if constexpr (epi_is_colwise(EPI)) {
+    const float rs = epi_is_ln(EPI) ? rs_s[r] : 1.0f;
+    bf16x8v o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float y = fmaf(rs, v[e], bias[e]);
+      if constexpr (EPI == EPI_BIAS_QGELU || EPI == EPI_QGELU_LN) y = quick_gelu<false>(y);
+      o[e] = (bf16_t)y;
+    }
+    if (in_range) *reinterpret_cast<bf16x8v*>(reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + n) = o;
+  } else {
+    static_assert(epi_is_resid(EPI), "skinny epilogues: bias / QuickGELU (optionally LayerNorm-folded) and the residual forms");
+    float* crow = reinterpret_cast<float*>(p.C) + (size_t)(in_range ? m : p.M - 1) * p.ldc + n;
+    const float4 x0 = *reinterpret_cast<const float4*>(crow), x1 = *reinterpret_cast<const float4*>(crow + 4);
+    const float xo[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+    float o[8], s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { o[e] = xo[e] + (v[e] + bias[e]); s += o[e]; }   // same association as the big kernel: x + (acc + bias)
+    if (in_range) {
+      *reinterpret_cast<float4*>(crow) = make_float4(o[0], o[1], o[2], o[3]);
+      *reinterpret_cast<float4*>(crow + 4) = make_float4(o[4], o[5], o[6], o[7]);
+    }
+    if constexpr (EPI == EPI_RESID_EMIT) {
+      const float ssum = row8_sum(s);                          // the tile is one 64-column slice wide: 8 lanes per row
+      const float mj = ssum * (1.0f / kLnSlice);
+      float q = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = o[e] - mj; q += d * d; }
+      const float m2 = row8_sum(q);
+      if (in_range) {
+        bf16x8v ob;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ob[e] = (bf16_t)o[e];
+        *reinterpret_cast<bf16x8v*>(reinterpret_cast<bf16_t*>(p.xb_out) + (size_t)m * p.ldc + n) = ob;
+        if ((tid & 7) == 0) *reinterpret_cast<float2*>(p.st_out + ((size_t)m * (p.N / kLnSlice) + n0 / kLnSlice) * 2) = make_float2(ssum, m2);
+      }
+    }
+  }
+}
+
+template <int EPI, int NW, int NB>
+int launch_skinny_nb(const GemmParams& p, hipStream_t s) {
+  const dim3 grid(p.N / SK_BN, (p.M + SK_BM - 1) / SK_BM);
+  hipLaunchKernelGGL((gemm_skinny_kernel<EPI, NW, NB>), grid, dim3(64 * NW), 0, s, p);
+  return (int)hipGetLastError();
+}
+// K split: 8 waves when each still gets whole 64-deep blocks, else 4; blocks requested together: 3, 2 or 1.  The choice
+// depends on K only (never on M): a row's bits do not depend on the batch it arrives in.
+template <int EPI>
+int launch_skinny(const GemmParams& p, hipStream_t s) {
+  const int blocks = p.K / 64;
+  if (blocks % 8 == 0) {
+    const int nb = blocks / 8;
+    if (nb % 3 == 0) return launch_skinny_nb<EPI, 8, 3>(p, s);
+    if (nb % 2 == 0) return launch_skinny_nb<EPI, 8, 2>(p, s);
+    return launch_skinny_nb<EPI, 8, 1>(p, s);
+  }
+  const int nb = blocks / 4;
+  if (nb % 3 == 0) return launch_skinny_nb<EPI, 4, 3>(p, s);
+  if (nb % 2 == 0) return launch_skinny_nb<EPI, 4, 2>(p, s);
+  return launch_skinny_nb<EPI, 4, 1>(p, s);
+}
+
+}  // namespace
+
+bool gemm_skinny_supports(int epi, int M, int N, int K) {
+  const bool epi_ok = epi == EPI_BIAS || epi == EPI_BIAS_QGELU || epi == EPI_BIAS_RESID || epi == EPI_BIAS_LN ||
+                      epi == EPI_QGELU_LN || epi == EPI_RESID_EMIT;
+  return epi_ok && M > 0 && N % SK_BN == 0 && K % 256 == 0;
+}
+
+int gemm_launch_skinny(int epi, const GemmParams& p, hipStream_t s, const char** kernel_name) {
+  if (p.M <= 0) return 0;
+  if (!gemm_skinny_supports(epi, p.M, p.N, p.K) || p.lda % 8 || p.ldw % 8) return (int)hipErrorInvalidValue;
+  static const char* names[EPI_COUNT] = {"gemm_skinny<bf16,32x64_splitk,bias>", "gemm_skinny<bf16,32x64_splitk,bias_qgelu>",
+                                         "gemm_skinny<bf16,32x64_splitk,bias_resid>", nullptr, nullptr,
+                                         "gemm_skinny<bf16,32x64_splitk,ln_bias>", "gemm_skinny<bf16,32x64_splitk,ln_qgelu>",
+                                         "gemm_skinny<bf16,32x64_splitk,resid_emit>"};
+  if (kernel_name) *kernel_name = names[epi];
+  switch (epi) {
+    case EPI_BIAS: return launch_skinny<EPI_BIAS>(p, s);
+    case EPI_BIAS_QGELU: return launch_skinny<EPI_BIAS_QGELU>(p, s);
+    case EPI_BIAS_RESID: return launch_skinny<EPI_BIAS_RESID>(p, s);
+    case EPI_BIAS_LN: return launch_skinny<EPI_BIAS_LN>(p, s);
+    case EPI_QGELU_LN: return launch_skinny<EPI_QGELU_LN>(p, s);
+    case EPI_RESID_EMIT: return launch_skinny<EPI_RESID_EMIT>(p, s);
+    default: return (int)hipErrorInvalidValue;
+  }
+}
+
+}  // namespace plipmi

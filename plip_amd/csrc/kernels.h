@@ -55,6 +55,11 @@ hipError_t launch_pool_head(const float* x, int S, int D, const int64_t* ids, in
 hipError_t launch_pool_layernorm(const float* x, int S, int D, const int64_t* ids, int eos_id, const float* ln_w,
                                  const float* ln_b, float eps, float* out, int B, hipStream_t s);
 
+// pooled row of every sample (CLS when ids == nullptr, else the caption's EOS row): attention output (bf16) and residual
+// row (fp32) copied to compact [B, D] buffers -- the inputs of the last block's pooled-row-only out_proj / fc1 / fc2
+hipError_t launch_pool_gather(const void* att, const float* x, int S, int D, const int64_t* ids, int eos_id, void* attp,
+                              float* xp, int B, hipStream_t s);
+
 hipError_t launch_l2_normalize(float* x, int N, int D, hipStream_t s);
 // C[M,N] = A[M,K] . W[N,K]^T, exact fp32 MFMA, split-K over the four waves of a 32x32-tile workgroup (N, K % 32 == 0)
 // (also the MFMA form of the logits: C = scale * A . W^T; exchanging A and W gives the bit-exact transpose)

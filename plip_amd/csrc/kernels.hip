@@ -507,6 +507,7 @@ hipError_t launch_text_embed_emit(const int64_t* ids, const float* tok, const fl
 // row (:559-581); LayerNorm is row-wise, so picking first is exact and 77x cheaper.
 // ---------------------------------------------------------------------------------
 constexpr int kHeadMaxD = 2048, kHeadMaxOut = 4;  // P <= 1024
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
 
 __device__ __forceinline__ float block_sum_256(float v, float* red) {
   v = wave_sum(v);
@@ -617,6 +618,32 @@ __device__ __forceinline__ int eos_position(const int64_t* row, int S, int eos_i
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) best = min(best, __shfl_xor(best, o, 64));
   return best;
+}
+
+// The LAST block of a tower only matters for the row that is pooled afterwards (CLS, or the caption's EOS row): one
+// wavefront per sample picks that row and copies its attention output (bf16) and residual row (fp32) into compact [B, D]
+// buffers, on which out_proj / fc1 / fc2 of the last block then run (engine.hip run_last_block_pooled).
+__global__ __launch_bounds__(256) void pool_gather_kernel(const bf16_t* __restrict__ att, const float* __restrict__ x, int S, int D,
+                                                          const int64_t* __restrict__ ids, int eos_id, bf16_t* __restrict__ attp,
+                                                          float* __restrict__ xp, int B) {
+  const int lane = threadIdx.x & 63;
+  const int smp = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (smp >= B) return;
+  const int pos = ids ? eos_position(ids + (size_t)smp * S, S, eos_id, lane) : 0;
+  const size_t src = ((size_t)smp * S + pos) * D, dst = (size_t)smp * D;
+  for (int i = lane * 8; i < D; i += 512) {     // D % 8 == 0 (widths are multiples of 128)
+    *reinterpret_cast<u32x4_t*>(attp + dst + i) = *reinterpret_cast<const u32x4_t*>(att + src + i);
+    *reinterpret_cast<float4*>(xp + dst + i) = *reinterpret_cast<const float4*>(x + src + i);
+    *reinterpret_cast<float4*>(xp + dst + i + 4) = *reinterpret_cast<const float4*>(x + src + i + 4);
+  }
+}
+hipError_t launch_pool_gather(const void* att, const float* x, int S, int D, const int64_t* ids, int eos_id, void* attp,
+                              float* xp, int B, hipStream_t s) {
+  if (B <= 0) return hipSuccess;
+  if (D % 8) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(pool_gather_kernel, dim3((B + 3) / 4), dim3(256), 0, s, (const bf16_t*)att, x, S, D, ids, eos_id,
+                     (bf16_t*)attp, xp, B);
+  return hipGetLastError();
 }
 
 // one wavefront per sample: pick the pooled row, LayerNorm it, write fp32 [B, D]

@@ -150,7 +150,7 @@ def _slice_stats(x):
     return torch.stack((s, m2), dim=-1).float().contiguous()
 
 
-@pytest.mark.parametrize("variant", [1, 36, 37, 41, 42, -1])
+@pytest.mark.parametrize("variant", [1, 36, 37, 41, 42, -1, -3])
 @pytest.mark.parametrize("mode", [0, 1])
 def test_layernorm_folded_consumer_epilogue(variant, mode):
     """y = [quickgelu](Linear(LayerNorm(x))) computed as rstd * (bf16(x) @ W'^T) + c2 with W' = bf16(W * g, rows centred)
@@ -161,6 +161,8 @@ def test_layernorm_folded_consumer_epilogue(variant, mode):
     dev = torch.device("cuda:0")
     g0 = torch.Generator().manual_seed(100 + variant + 10 * mode)
     for (M, N, D) in [(1, 256, 128), (77, 512, 512), (300, 768, 768), (1200, 256, 1024)]:
+        if variant == -3 and D % 256:
+            continue                            # the split-K small-M kernel needs K % 256 == 0
         x = torch.randn(M, D, generator=g0) + 1.5
         x[:, 5] += 60.0
         W = torch.randn(N, D, generator=g0) / D ** 0.5
@@ -192,7 +194,7 @@ def test_layernorm_folded_consumer_epilogue(variant, mode):
         assert (y.double() - book).abs().max().item() < 4e-2 * max(1.0, book.abs().max().item())
 
 
-@pytest.mark.parametrize("variant", [1, 36, 37, 41, 42, -1])
+@pytest.mark.parametrize("variant", [1, 36, 37, 41, 42, -1, -3])
 def test_layernorm_folded_producer_epilogue(variant):
     """x += A @ W^T + bias in place (fp32), plus the bf16 copy and the per-slice {sum, centred M2} of the updated rows,
     the latter against fp64 statistics of the kernel's OWN fp32 output (so the check is exact to fp32 round-off)."""
@@ -200,6 +202,8 @@ def test_layernorm_folded_producer_epilogue(variant):
     dev = torch.device("cuda:0")
     g0 = torch.Generator().manual_seed(200 + variant)
     for (M, N, K) in [(1, 256, 64), (50, 512, 512), (515, 768, 3072), (1300, 1024, 256)]:
+        if variant == -3 and K % 256:
+            continue
         a = torch.randn(M, K, generator=g0).to(dev).bfloat16()
         w = (torch.randn(N, K, generator=g0) / K ** 0.5).to(dev).bfloat16()
         bias = torch.randn(N, generator=g0).to(dev)
@@ -214,3 +218,26 @@ def test_layernorm_folded_producer_epilogue(variant):
         assert (st[..., 0] - want[..., 0]).abs().max().item() < 1e-3           # sums of 64 values around |x| ~ 10..100
         rel = ((st[..., 1] - want[..., 1]).abs() / want[..., 1].clamp(min=1e-3)).max().item()
         assert rel < 1e-4, rel
+
+
+@pytest.mark.parametrize("epi", [0, 1, 2])
+def test_small_m_split_k_gemm(epi):
+    """gemm_skinny.hip (variant -3): 32 x 64 tile per workgroup, K split over its four waves with a k permutation shared by
+    both operands, operands straight from L2 -- against fp64 and, bit for bit across batch sizes, against itself (a row's
+    result must not depend on how many other rows the call carries: the pooled last block relies on it)."""
+    from plip_amd.engine import gemm_nt
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(31 + epi)
+    for (M, N, K) in [(1, 64, 256), (8, 768, 768), (256, 768, 3072), (256, 2048, 512), (333, 512, 2048)]:
+        a = torch.randn(M, K, generator=g).to(dev).bfloat16()
+        w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev).bfloat16()      # asymmetric operands
+        bias = torch.randn(N, generator=g).to(dev)
+        c0 = torch.randn(M, N, generator=g).to(dev)
+        y = gemm_nt(a, w, bias, epilogue=epi, variant=-3, out=c0.clone() if epi == 2 else None)
+        torch.cuda.synchronize()
+        ref = _ref(a, w, bias, epi, 1.0, c0)
+        tol = 2e-4 if y.dtype == torch.float32 else 4e-3 * max(1.0, ref.abs().max().item())
+        assert (y.double() - ref).abs().max().item() < tol, (epi, M, N, K)
+        if M >= 8:                                  # rows 3..7 alone give the same bits
+            y2 = gemm_nt(a[3:8].contiguous(), w, bias, epilogue=epi, variant=-3, out=c0[3:8].clone() if epi == 2 else None)
+            assert torch.equal(y2, y[3:8])

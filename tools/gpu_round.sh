@@ -17,6 +17,8 @@ for s in $SECTIONS; do
     libprof) (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/gpurun_out/proflib" -o lib -- python "$OLDPWD/tools/gpu_diag.py" libgemm > "$OLDPWD/gpurun_out/libprof.log" 2>&1) ;;
     benchnofold) PLIPMI_LN_FOLD=0 timeout 600 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-fp32-tower > gpurun_out/bench_nofold.json 2>> gpurun_out/bench.err
                  PLIPMI_LN_FOLD=0 timeout 600 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-fp32-tower --overlap 0 --no-profile > gpurun_out/bench_nofold_1stream.json 2>> gpurun_out/bench.err ;;
+    benchnopool) PLIPMI_POOLED_LAST_BLOCK=0 timeout 600 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-fp32-tower --no-profile > gpurun_out/bench_nopool.json 2>> gpurun_out/bench.err
+                 PLIPMI_POOLED_LAST_BLOCK=0 timeout 600 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-fp32-tower --overlap 0 --no-profile > gpurun_out/bench_nopool_1stream.json 2>> gpurun_out/bench.err ;;
     bench1s) timeout 600 python bench.py --steps 20 --warmup 3 --overlap 0 --no-cpu-baseline > gpurun_out/bench_1stream.json 2>> gpurun_out/bench.err ;;
     pmc)     # hardware counters of the dominant GEMM (own passes, kernel-trace only -- see MI355X_MICROARCH rocprofv3 notes)
              for pass in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_VALU_MFMA_BUSY_CYCLES" \
