@@ -13,9 +13,10 @@
 //   * the same fused epilogues as the big kernel's LayerNorm-folded family: rstd * acc + c2 (-> bf16, optional
 //     QuickGELU), and the in-place fp32 residual update that also emits bf16(x) and the row's {sum, centred M2} of the
 //     64-column slice (= exactly this tile's width).
-// Used by the bf16 engine (a) for every Linear of a small batch (B <= ~10 images: zero_shot_classification runs at 8,
-// plip.py:90-91) and (b) for the LAST block of each tower, whose out_proj / fc1 / fc2 only ever matter for the pooled
-// row of each sample (engine.hip: run_last_block_pooled).
+// Used by the bf16 engine for the LAST block of each tower, whose out_proj / fc1 / fc2 only ever matter for the pooled row
+// of each sample (engine.hip: run_last_block_pooled): M = batch size.  (Not used for the other blocks of small batches:
+// its K-split summation order differs from the big kernel's, and a row's embedding is kept bit-identical across batch
+// sizes -- every batch size takes the same kernel family per block.)
 #include "gemm.h"
 
 namespace plipmi {
@@ -68,6 +69,9 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(const GemmParams p
         wa[b][t] = *reinterpret_cast<const u32x4*>(w0 + kk + 64 * b + 8 * t);
         wb[b][t] = *reinterpret_cast<const u32x4*>(w1 + kk + 64 * b + 8 * t);
       }
+    // keep every request of the batch AHEAD of the first MFMA (left alone the scheduler sinks each load next to its use:
+    // one memory round trip per block instead of one per batch)
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int b = 0; b < NB; ++b)
 #pragma unroll

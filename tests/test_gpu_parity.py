@@ -307,3 +307,36 @@ def test_fp8_weights_engine_stated_tolerance(engines, golden):
         model.engine.close()
     with pytest.raises(PlipmiError):                      # 3 * 128 columns is not a whole number of 256-wide fp8 tiles
         PlipModel(get_config("tiny"), W.synthetic_state_dict(get_config("tiny"), 0), dtype="fp8", max_batch=2)
+
+
+@pytest.mark.parametrize("name", ["vitb32_b4", "tiny_b6"])
+def test_pooled_last_block_equals_the_full_block(name, engines, monkeypatch):
+    """The encode paths run the last block's out_proj / fc1 / fc2 on the pooled row of each sample only (CLS / EOS; the
+    other rows of that block cannot reach get_*_features).  Against an engine that computes every row
+    (PLIPMI_POOLED_LAST_BLOCK=0) the embeddings agree to the rounding noise of a different fp32 summation order in
+    three GEMMs (bf16 operands identical), far inside the parity tolerance; hidden states are the full block's either way."""
+    from plip_amd.model import PlipModel
+    model, cfg, sd, px, ids, mask = engines(name, "bf16")
+    monkeypatch.setenv("PLIPMI_POOLED_LAST_BLOCK", "0")
+    full = PlipModel(cfg, sd, dtype="bf16", max_batch=8)
+    monkeypatch.delenv("PLIPMI_POOLED_LAST_BLOCK")
+    try:
+        tpx, tids, tm = torch.from_numpy(px), torch.from_numpy(ids), torch.from_numpy(mask)
+        a = model(input_ids=tids, pixel_values=tpx, attention_mask=tm)
+        b = full(input_ids=tids, pixel_values=tpx, attention_mask=tm)
+        assert (a.image_embeds - b.image_embeds).abs().max().item() < 5e-4
+        assert (a.text_embeds - b.text_embeds).abs().max().item() < 5e-4
+        h1 = model.engine.hidden("vision", cfg.v_layers, tpx)
+        h2 = full.engine.hidden("vision", cfg.v_layers, tpx)
+        assert torch.equal(h1, h2)                      # debug_hidden always runs the full block
+        assert any("pooled" in r["name"] for r in _profile(model, tpx))
+        assert not any("pooled" in r["name"] for r in _profile(full, tpx))
+    finally:
+        full.engine.close()
+
+
+def _profile(model, tpx):
+    rows = []
+    with model.engine.profile(rows):
+        model.get_image_features(pixel_values=tpx)
+    return rows
