@@ -373,6 +373,30 @@ def main():
         res["csrc_sha16"] = source_digest()
     except Exception:  # pragma: no cover
         pass
+    if world == 1 and not args.no_fp32_tower and args.dtype == "bf16" and res["executed_gflop_per_pair"]["pooled_last_block"]:
+        # A/B: the same step with the last block computed on EVERY token (as HF does), i.e. the dense 14.777 GFLOP per pair
+        try:
+            os.environ["PLIPMI_POOLED_LAST_BLOCK"] = "0"
+            md = PlipModel(cfg, sd, device=dev, dtype=args.dtype, max_batch=B)
+            del os.environ["PLIPMI_POOLED_LAST_BLOCK"]
+            for _ in range(args.warmup):
+                sharded_pair_logits(md, px, ids, mask, overlap=bool(args.overlap), equal_shards=True)
+            torch.cuda.synchronize(dev)
+            t3 = time.perf_counter()
+            for _ in range(args.steps):
+                od = sharded_pair_logits(md, px, ids, mask, overlap=bool(args.overlap), equal_shards=True)
+            torch.cuda.synchronize(dev)
+            dtd = (time.perf_counter() - t3) / args.steps
+            res["dense_last_block"] = {
+                "note": "same step, PLIPMI_POOLED_LAST_BLOCK=0: the last block's out_proj / fc1 / fc2 on all tokens instead of the "
+                        "pooled row only (identical embeddings up to fp32 summation order)",
+                "pairs_per_s": round(B / dtd, 1), "ms_per_step": round(dtd * 1e3, 3),
+                "max_abs_diff_of_logits_vs_pooled_path": float((od[0] - logits).abs().max())}
+            md.engine.close()
+            del md
+        except Exception as e:  # pragma: no cover
+            os.environ.pop("PLIPMI_POOLED_LAST_BLOCK", None)
+            res["dense_last_block"] = {"error": repr(e)}
     if world == 1 and not args.no_fp32_tower and args.dtype == "bf16":
         # BASELINE.json configs[1]: ViT-B/32 image tower only, bs=256, fp32 (exact-fp32 MFMA engine), same pixels
         try:
