@@ -190,7 +190,18 @@ class Engine:
         side.wait_stream(main)                      # inputs produced on the main stream are ready
         with torch.cuda.stream(side):
             txt = self.encode_text(input_ids, attention_mask, normalize)
-        img = self.encode_image(pixels, normalize)
+        if getattr(self, "pair_vision_priority", False):
+            # experiment (tools/gpu_diag.py prio): the longer tower on a high-priority stream of its own, the shorter one
+            # filling the gaps -- see profiles/r02_two_stream_priority.txt for what it measured
+            if getattr(self, "_vis", None) is None:
+                self._vis = torch.cuda.Stream(device=self.device, priority=-1)
+            self._vis.wait_stream(main)
+            with torch.cuda.stream(self._vis):
+                img = self.encode_image(pixels, normalize)
+            main.wait_stream(self._vis)
+            img.record_stream(main)
+        else:
+            img = self.encode_image(pixels, normalize)
         main.wait_stream(side)
         txt.record_stream(main)
         return img, txt

@@ -249,6 +249,28 @@ def sec_latency():
     model.engine.close()
 
 
+def sec_prio():
+    """Two-stream step with the vision tower on a high-priority stream vs the default arrangement (in-process, interleaved)."""
+    from plip_amd.dist import sharded_pair_logits
+    cfg = get_config("ViT-B/32")
+    sd = W.synthetic_state_dict(cfg, 0)
+    B = 256
+    px = torch.from_numpy(W.synthetic_pixels(cfg, B, 1)).to(dev)
+    ids_np, mask_np = W.synthetic_ids(cfg, B, 2)
+    ids, mask = torch.from_numpy(ids_np).to(dev), torch.from_numpy(mask_np).to(dev)
+    model = PlipModel(cfg, sd, dtype="bf16", max_batch=B)
+    res = {False: [], True: []}
+    for rep in range(5):
+        for prio in (False, True):
+            model.engine.pair_vision_priority = prio
+            ms = _time(lambda: sharded_pair_logits(model, px, ids, mask, overlap=True), iters=10, warm=2)
+            if rep:
+                res[prio].append(ms)
+    for prio in (False, True):
+        print(f"vision tower on a high-priority stream = {prio}: two streams {np.median(res[prio]):6.3f} ms (min {min(res[prio]):6.3f})")
+    model.engine.close()
+
+
 def sec_libgemm():
     """Calibration only (never used by the product): what the vendor GEMM library (hipBLASLt/rocBLAS behind
     torch.nn.functional.linear) reaches on the production shapes -- an external yardstick for gemm_nt."""
@@ -582,6 +604,6 @@ def sec_e2e():
 
 if __name__ == "__main__":
     t0 = time.time()
-    {"gemm": sec_gemm, "attn": sec_attn, "tiny": sec_tiny, "vitb32": sec_vitb32, "gemmbench": sec_gemmbench, "lnbench": sec_lnbench, "latency": sec_latency, "libgemm": sec_libgemm, "fp8": sec_fp8, "fp8w": sec_fp8w, "towerswap": sec_towerswap, "e2e": sec_e2e, "gemmone": sec_gemmone, "policy": sec_policy, "ldpad": sec_ldpad, "gemmtrace": sec_gemmtrace,
+    {"gemm": sec_gemm, "attn": sec_attn, "tiny": sec_tiny, "vitb32": sec_vitb32, "gemmbench": sec_gemmbench, "lnbench": sec_lnbench, "latency": sec_latency, "prio": sec_prio, "libgemm": sec_libgemm, "fp8": sec_fp8, "fp8w": sec_fp8w, "towerswap": sec_towerswap, "e2e": sec_e2e, "gemmone": sec_gemmone, "policy": sec_policy, "ldpad": sec_ldpad, "gemmtrace": sec_gemmtrace,
      "overlap": sec_overlap}[sys.argv[1]]()
     print(f"[{sys.argv[1]} done in {time.time() - t0:.1f} s]")
