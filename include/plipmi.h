@@ -234,7 +234,11 @@ int plipmi_gemm_nt_traced(int dtype, int epilogue, int variant, int M, int N, in
  *   mode 1: C(bf16) = quickgelu(that)                 {sum, centred M2} of the LayerNorm input rows (D = 64 * ns), eps as
  *                                                     given; W is expected to carry LayerNorm's gain with CENTRED rows
  *                                                     (sum_k W[n,k] = 0), which is what subtracts the row mean
- *   mode 2: C(f32) += A.W^T + bias;  xb_out(bf16)[M,N] = C;  st_out [M, N/64, 2] = partials of the updated rows */
+ *   mode 2: C(f32) += A.W^T + bias;  xb_out(bf16)[M,N] = C;  st_out [M, N/64, 2] = partials of the updated rows
+ *   mode 3: the same update on a residual kept as two 16-bit planes, xb_out = hi (uint16: the value rounded to bf16,
+ *           ties away from zero) and C = lo (int16), bits(x) == (hi << 16) + lo: both read and written in place;
+ *           st_out as in mode 2.  This is the form the engine runs (an fp32 stream at 8 bytes per element of epilogue
+ *           traffic, whose hi plane is the next GEMM's A operand) */
 int plipmi_gemm_nt_ln(int mode, int variant, int M, int N, int K, const void* A, const void* W, const float* bias,
                       const float* stats, int ns, float eps, void* C, void* xb_out, float* st_out, void* stream);
 

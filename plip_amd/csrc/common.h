@@ -68,6 +68,30 @@ __device__ __forceinline__ float row16_sum(float v) {
 
 // LayerNorm statistics travel as per-row PARTIALS over 64-column slices: {sum, M2 = sum (x - sum/64)^2}.  Folding
 // NS slices with Chan's update gives the row mean and the (biased) variance without ever forming E[x^2] - mean^2.
+// The LayerNorm-folded bf16 engine keeps its fp32 residual stream as two 16-bit planes: hi = the value rounded to bf16
+// (nearest, ties away from zero) -- which IS the next GEMM's A operand -- and lo = the signed 16-bit remainder of the bit
+// pattern, so that bits(x) == (hi << 16) + lo exactly.  No precision is given up against a plain fp32 array; a residual
+// GEMM's epilogue moves 4 + 4 bytes per element instead of 4 + 4 + 2 (fp32 in place plus a separate bf16 copy).
+__device__ __forceinline__ void split_f32(float x, unsigned& hi16, unsigned& lo16) {
+  const unsigned u = __builtin_bit_cast(unsigned, x), t = u + 0x8000u;
+  hi16 = t >> 16;
+  lo16 = (u - (t & 0xffff0000u)) & 0xffffu;
+}
+__device__ __forceinline__ float join_f32(unsigned hi16, unsigned lo16) {   // both in the low 16 bits of their words
+  return __builtin_bit_cast(float, (hi16 << 16) + (unsigned)(((int)(lo16 << 16)) >> 16));
+}
+__device__ __forceinline__ void store4_split(unsigned short* hi, unsigned short* lo, float a, float b, float c, float d) {
+  unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+  split_f32(a, h0, l0); split_f32(b, h1, l1); split_f32(c, h2, l2); split_f32(d, h3, l3);
+  *reinterpret_cast<uint2*>(hi) = make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));
+  *reinterpret_cast<uint2*>(lo) = make_uint2(l0 | (l1 << 16), l2 | (l3 << 16));
+}
+__device__ __forceinline__ float4 load4_split(const unsigned short* hi, const unsigned short* lo) {
+  const uint2 h = *reinterpret_cast<const uint2*>(hi), l = *reinterpret_cast<const uint2*>(lo);
+  return make_float4(join_f32(h.x & 0xffffu, l.x & 0xffffu), join_f32(h.x >> 16, l.x >> 16),
+                     join_f32(h.y & 0xffffu, l.y & 0xffffu), join_f32(h.y >> 16, l.y >> 16));
+}
+
 constexpr int kLnSlice = 64;
 __device__ __forceinline__ void ln_combine(const float* __restrict__ st, int ns, float inv_d, float eps, float& mean,
                                            float& rstd) {

@@ -63,13 +63,18 @@ struct Tower {
   void *h = nullptr, *qkv = nullptr, *att = nullptr, *mlp = nullptr;
   void* h8 = nullptr;   // fp8-weights mode: LayerNorm output as fp8 rows ...
   float* hs = nullptr;  // ... with one dynamic scale per row
-  float* st = nullptr;  // LayerNorm-folded engine: statistics partials of the residual rows [M, D/64, 2]; h = bf16(x)
+  // LayerNorm-folded engine: the residual stream lives as two 16-bit planes (common.h split_f32): h = its bf16 plane (the
+  // A operand of the q/k/v and fc1 GEMMs), lo = the int16 remainder (h + lo == the fp32 value exactly); x only holds the
+  // embedding rows before the first LayerNorm and a joined copy where something needs plain fp32.  st = the rows'
+  // statistics partials [M, D/64, 2]
+  float* st = nullptr;
+  void* lo = nullptr;
   // last block, pooled rows only (one row per sample): residual row, attention output, bf16 copy, MLP hidden, partials
   float* xp = nullptr; void *attp = nullptr, *hp = nullptr, *mlpp = nullptr; float* stp = nullptr;
 };
 struct LnArgs {         // the LayerNorm side of a folded GEMM (gemm.h EPI_*_LN / EPI_RESID_EMIT)
   const float* stats = nullptr; int ns = 0; float inv_d = 0.f, eps = 0.f;   // consumer
-  void* xb_out = nullptr; float* st_out = nullptr;                                                        // producer
+  void* xb_out = nullptr; float* st_out = nullptr; void* lo_io = nullptr;     // producer (lo_io: EPI_RESID_SPLIT's lo plane)
 };
 // One captured tower forward (hipGraph) per (tower, input kind, batch, normalise, pooling rule, mask?): the ~170 launches
 // of a small-batch encode are replayed with ONE host call instead of being issued one by one (launch-bound at the
@@ -207,7 +212,7 @@ void carve(plipmi_engine* e, Carver& c) {
     t->x = c.take<float>(M * D, 4);
     t->h = c.take<void>(M * D, es);
     if (e->fp8w) { t->h8 = c.take<void>(M * D, 1); t->hs = c.take<float>(M, 4); }
-    if (e->ln_fold) t->st = c.take<float>(M * (D / kLnSlice) * 2, 4);
+    if (e->ln_fold) { t->st = c.take<float>(M * (D / kLnSlice) * 2, 4); t->lo = c.take<void>(M * D, 2); }
     if (e->pooled_last) {
       t->xp = c.take<float>(B * D, 4); t->attp = c.take<void>(B * D, es); t->hp = c.take<void>(B * D, es);
       t->mlpp = c.take<void>(B * F, es); t->stp = c.take<float>(B * (D / kLnSlice) * 2, 4);
@@ -287,12 +292,13 @@ int run_gemm(plipmi_engine* e, int epi, const void* A, const void* W, void* C, c
   p.M = M; p.N = N; p.K = K; p.lda = K; p.ldw = K; p.ldc = ldc; p.alpha = 1.f; p.np = np;
   if (ln) {
     p.ln_stats = ln->stats; p.ln_ns = ln->ns; p.ln_inv_d = ln->inv_d; p.ln_eps = ln->eps;
-    p.xb_out = ln->xb_out; p.st_out = ln->st_out;
+    p.xb_out = ln->xb_out; p.st_out = ln->st_out; p.lo_io = ln->lo_io;
   }
   const bool skinny = role[0] == '~';     // '~role': pooled-row GEMM of the last block -> the small-M split-K kernel when it fits
   if (skinny) ++role;
   const char* name = "gemm_nt";
-  // algorithmic bytes: operands once, output once (bf16 outputs 2 B, fp32 residual read + written, + bf16 copy when emitted)
+  // algorithmic bytes: operands once, output once (bf16 outputs 2 B, fp32 residual read + written -- as one array or as two
+  // 16-bit planes --, + bf16 copy when EPI_RESID_EMIT writes one)
   const double out_bytes = epi_is_colwise(epi) ? (double)M * N * e->esz
                            : (double)M * N * (epi_is_resid(epi) ? 8.0 : 4.0) + (epi == EPI_RESID_EMIT ? (double)M * N * 2.0 : 0.0);
   Scope sc(e, s, name, 2.0 * M * N * (double)K, ((double)M * K + (double)N * K) * e->esz + out_bytes);
@@ -332,20 +338,24 @@ int run_layers(plipmi_engine* e, Tower& t, int B, int n_layers, int causal, cons
     return PLIPMI_OK;
   };
   if (e->ln_fold) {
-    // LayerNorm never runs as a pass: t.h = bf16(x) and t.st = the rows' statistics partials arrive with x from its
-    // producer (embedding kernel, or the residual GEMM's epilogue); the consuming GEMMs carry LayerNorm's gain, centring
-    // and bias in their weights and apply rstd in their epilogues.  HF order (modeling_clip.py:370-381) is unchanged:
+    // LayerNorm never runs as a pass: the residual stream x = {t.h, t.lo} (bf16 plane + remainder plane, exact fp32) and
+    // t.st = the rows' statistics partials come from x's producer (embedding kernel, or the residual GEMM's epilogue); the
+    // consuming GEMMs read the bf16 plane as their A operand, carry LayerNorm's gain, centring and bias in their weights and
+    // apply rstd in their epilogues.  HF order (modeling_clip.py:370-381) is unchanged:
     // x += out_proj(attn(LN1(x))); x += fc2(quick_gelu(fc1(LN2(x)))).
     LnArgs use;  use.stats = t.st; use.ns = D / kLnSlice; use.inv_d = 1.0f / (float)D; use.eps = eps;
-    LnArgs emit; emit.xb_out = t.h; emit.st_out = t.st;
+    LnArgs emit; emit.xb_out = t.h; emit.st_out = t.st; emit.lo_io = t.lo;
     for (int l = 0; l < n_layers; ++l) {
       const LayerW& w = t.layers[l];
       RUN(run_gemm(e, EPI_BIAS_LN, t.h, w.wqkv, t.qkv, w.bqkv, M, 3 * D, D, 3 * D, 0, s, "qkv", &use));
       RUN(attention());
-      RUN(run_gemm(e, EPI_RESID_EMIT, t.att, w.wo, t.x, w.bo, M, D, D, D, 0, s, "out_proj", &emit));
+      RUN(run_gemm(e, EPI_RESID_SPLIT, t.att, w.wo, nullptr, w.bo, M, D, D, D, 0, s, "out_proj", &emit));
       RUN(run_gemm(e, EPI_QGELU_LN, t.h, w.w1, t.mlp, w.b1, M, F, D, F, 0, s, "fc1", &use));
-      if (l + 1 < n_layers || more_follow) RUN(run_gemm(e, EPI_RESID_EMIT, t.mlp, w.w2, t.x, w.b2, M, D, F, D, 0, s, "fc2", &emit));
-      else RUN(run_gemm(e, EPI_BIAS_RESID, t.mlp, w.w2, t.x, w.b2, M, D, F, D, 0, s, "fc2"));   // nothing reads LN partials after the last block
+      RUN(run_gemm(e, EPI_RESID_SPLIT, t.mlp, w.w2, nullptr, w.b2, M, D, F, D, 0, s, "fc2", &emit));
+    }
+    if (!more_follow) {   // a consumer of plain fp32 rows follows (the every-token head, plipmi_debug_hidden)
+      Scope sc(e, s, "join_planes", 0, (double)M * D * 8);
+      HIP_TRY(launch_join_planes(t.h, t.lo, t.x, (size_t)M * D, s));
     }
     return PLIPMI_OK;
   }
@@ -392,7 +402,7 @@ int run_last_block_pooled(plipmi_engine* e, Tower& t, int B, int causal, const i
   { Scope sc(e, s, impl ? "attention_mfma" : "attention_valu", 4.0 * B * t.H * (double)t.S * t.S * 64, (double)M * 4 * D * e->esz);
     HIP_TRY(launch_attention(t.qkv, t.att, e->dtype, B, t.S, t.H, causal, key_mask, impl, s)); }
   { Scope sc(e, s, "pool_gather", 0, (double)B * D * (2 * e->esz + 8));
-    HIP_TRY(launch_pool_gather(t.att, t.x, t.S, D, ids, eos_id, t.attp, t.xp, B, s)); }
+    HIP_TRY(launch_pool_gather(t.att, t.h, t.lo, t.S, D, ids, eos_id, t.attp, t.xp, B, s)); }
   LnArgs emit; emit.xb_out = t.hp; emit.st_out = t.stp;
   RUN(run_gemm(e, EPI_RESID_EMIT, t.attp, w.wo, t.xp, w.bo, B, D, D, D, 0, s, "~out_proj_pooled", &emit));
   use.stats = t.stp;
@@ -414,9 +424,9 @@ int vision_embed(plipmi_engine* e, const float* pixels, const uint8_t* tiles_u8,
   { Scope sc(e, s, "cls_rows", 0, (double)B * t.D * 4);
     HIP_TRY(launch_cls_rows(e->cls, e->vpos, t.x, B, t.S, t.D, s)); }
   RUN(run_gemm(e, EPI_PATCH, e->patches, e->patch_w, t.x, e->vpos, B * e->np, t.D, e->kpad, t.D, e->np, s, "patch_embed"));
-  if (e->ln_fold) {   // the tower's one LayerNorm pass; it also hands the first block bf16(x) and the row statistics
-    Scope sc(e, s, "layernorm", 0, (double)B * t.S * t.D * 10.2);
-    HIP_TRY(launch_layernorm_emit(t.x, e->pre_w, e->pre_b, t.h, t.st, B * t.S, t.D, g.layer_norm_eps, s));
+  if (e->ln_fold) {   // the tower's one LayerNorm pass: fp32 embedding rows in, the split residual stream + row statistics out
+    Scope sc(e, s, "layernorm", 0, (double)B * t.S * t.D * 8.2);
+    HIP_TRY(launch_layernorm_emit(t.x, e->pre_w, e->pre_b, t.h, t.lo, t.st, B * t.S, t.D, g.layer_norm_eps, s));
     return PLIPMI_OK;
   }
   { Scope sc(e, s, "layernorm", 0, (double)B * t.S * t.D * 8);
@@ -426,8 +436,8 @@ int vision_embed(plipmi_engine* e, const float* pixels, const uint8_t* tiles_u8,
 
 int text_embed(plipmi_engine* e, const int64_t* ids, int B, hipStream_t s) {
   Tower& t = e->txt;
-  Scope sc(e, s, "text_embed", 0, (double)B * t.S * t.D * (e->ln_fold ? 10.2 : 8.0));
-  if (e->ln_fold) HIP_TRY(launch_text_embed_emit(ids, e->tok, e->tpos, t.x, t.h, t.st, B, t.S, t.D, e->cfg.vocab_size, s));
+  Scope sc(e, s, "text_embed", 0, (double)B * t.S * t.D * (e->ln_fold ? 8.2 : 8.0));
+  if (e->ln_fold) HIP_TRY(launch_text_embed_emit(ids, e->tok, e->tpos, t.h, t.lo, t.st, B, t.S, t.D, e->cfg.vocab_size, s));
   else HIP_TRY(launch_text_embed(ids, e->tok, e->tpos, t.x, B, t.S, t.D, e->cfg.vocab_size, s));
   return PLIPMI_OK;
 }
@@ -837,14 +847,17 @@ int plipmi_gemm_nt_traced(int dtype, int epilogue, int variant, int M, int N, in
 
 int plipmi_gemm_nt_ln(int mode, int variant, int M, int N, int K, const void* A, const void* W, const float* bias,
                       const float* stats, int ns, float eps, void* C, void* xb_out, float* st_out, void* stream) {
-  if (mode < 0 || mode > 2 || M < 0 || N <= 0 || K <= 0 || !A || !W || !C || !bias) return fail(PLIPMI_ERR_INVALID, "bad argument");
+  if (mode < 0 || mode > 3 || M < 0 || N <= 0 || K <= 0 || !A || !W || !C || !bias) return fail(PLIPMI_ERR_INVALID, "bad argument");
   if (mode < 2 && (!stats || ns <= 0)) return fail(PLIPMI_ERR_INVALID, "mode 0/1 need the row statistics");
-  if (mode == 2 && (!xb_out || !st_out || N % kLnSlice)) return fail(PLIPMI_ERR_INVALID, "mode 2 needs xb_out, st_out and N % 64 == 0");
+  if (mode >= 2 && (!xb_out || !st_out || N % kLnSlice)) return fail(PLIPMI_ERR_INVALID, "mode 2/3 need xb_out, st_out and N % 64 == 0");
+  if (mode == 3 && variant == -3) return fail(PLIPMI_ERR_INVALID, "the small-M kernel has no split-plane epilogue");
   GemmParams p;
   p.A = A; p.W = W; p.C = C; p.bias = bias; p.M = M; p.N = N; p.K = K; p.lda = K; p.ldw = K; p.ldc = N; p.alpha = 1.f; p.np = 1;
   p.ln_stats = stats; p.ln_ns = ns; p.ln_inv_d = ns > 0 ? 1.0f / (float)(ns * kLnSlice) : 0.f; p.ln_eps = eps;
   p.xb_out = xb_out; p.st_out = st_out;
-  const int epi = mode == 0 ? EPI_BIAS_LN : mode == 1 ? EPI_QGELU_LN : EPI_RESID_EMIT;
+  if (mode == 3) { p.lo_io = C; p.C = nullptr; }
+  const int epi = mode == 0 ? EPI_BIAS_LN : mode == 1 ? EPI_QGELU_LN : mode == 2 ? EPI_RESID_EMIT : EPI_RESID_SPLIT;
+  { static int ab = -1; if (ab < 0) { const char* ev = getenv("PLIPMI_GEMM_ABLATE"); ab = ev ? atoi(ev) : 0; } p.ablate = ab; }   // test hook only
   const int rc = variant == -3 ? gemm_launch_skinny(epi, p, reinterpret_cast<hipStream_t>(stream), nullptr)
                                : gemm_launch(PLIPMI_BF16, epi, variant, p, reinterpret_cast<hipStream_t>(stream), nullptr);
   if (rc != 0) return fail(PLIPMI_ERR_HIP, "gemm launch failed (LN mode %d, variant %d, M=%d N=%d K=%d): %s", mode, variant, M, N, K,

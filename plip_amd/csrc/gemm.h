@@ -50,11 +50,18 @@ enum Epilogue : int {
   // ... and the producer of the NEXT LayerNorm's input: the in-place residual update also emits the bf16 copy of the
   // new rows (the next GEMM's A operand) and their statistics as per-64-column partials {sum, centred M2}
   EPI_RESID_EMIT = 7,  // C(f32) += acc + bias[n];  xb(bf16) = C;  st[m, n/64] = {sum, M2}
-  EPI_COUNT = 8
+  // The same update on a residual stream kept as TWO 16-bit planes: hi = the fp32 value rounded to bf16 (ties away), lo =
+  // the signed 16-bit remainder of its bit pattern, so that bits(x) == (hi << 16) + lo EXACTLY -- the stream stays fp32,
+  // its hi plane IS the next GEMM's bf16 A operand, and the epilogue moves 8 bytes per element (4 in, 4 out) like the
+  // plain fp32 residual instead of the 10 of EPI_RESID_EMIT (which writes fp32 and a separate bf16 copy).
+  EPI_RESID_SPLIT = 8, // {hi,lo} += acc + bias[n] (xb_out = hi, lo_io = lo);  st[m, n/64] = {sum, M2}
+  EPI_COUNT = 9
 };
 constexpr bool epi_is_ln(int e) { return e == EPI_BIAS_LN || e == EPI_QGELU_LN; }
 constexpr bool epi_is_colwise(int e) { return e == EPI_BIAS || e == EPI_BIAS_QGELU || epi_is_ln(e); }
-constexpr bool epi_is_resid(int e) { return e == EPI_BIAS_RESID || e == EPI_RESID_EMIT; }
+constexpr bool epi_is_resid(int e) { return e == EPI_BIAS_RESID || e == EPI_RESID_EMIT || e == EPI_RESID_SPLIT; }
+constexpr bool epi_emits_stats(int e) { return e == EPI_RESID_EMIT || e == EPI_RESID_SPLIT; }
+
 
 struct GemmParams {
   const void* A;
@@ -73,9 +80,11 @@ struct GemmParams {
   const float* ln_stats = nullptr;
   int ln_ns = 0;
   float ln_inv_d = 0.f, ln_eps = 0.f;
-  // EPI_RESID_EMIT producer: bf16 copy of the updated rows [M, ldc] and their partial statistics [M, N/64, 2]
+  // EPI_RESID_EMIT producer: bf16 copy of the updated rows [M, ldc] and their partial statistics [M, N/64, 2].
+  // EPI_RESID_SPLIT: xb_out is the hi plane (bf16, read AND written), lo_io the lo plane (int16, read and written)
   void* xb_out = nullptr;
   float* st_out = nullptr;
+  void* lo_io = nullptr;
   // Tile raster: the N tiles are cut in column groups `gw` tiles wide; logical tile ids run group by group,
   // M-major inside a group.  An XCD's contiguous id range is then a compact (rows x gw) patch whose W panels
   // (gw*BN rows of W) stay resident in its 4 MiB L2 while the A row panels stream through once.
@@ -195,6 +204,11 @@ struct EpilogueOp {
   __device__ __forceinline__ static float4 load(const GemmParams& p, int m, int n0) {
     if constexpr (epi_is_colwise(EPI)) {
       return *reinterpret_cast<const float4*>(p.bias + n0);
+    } else if constexpr (EPI == EPI_RESID_SPLIT) {
+      const float4 b = *reinterpret_cast<const float4*>(p.bias + n0);
+      const float4 r = load4_split(reinterpret_cast<const unsigned short*>(p.xb_out) + (size_t)m * p.ldc + n0,
+                                   reinterpret_cast<const unsigned short*>(p.lo_io) + (size_t)m * p.ldc + n0);
+      return make_float4(r.x + b.x, r.y + b.y, r.z + b.z, r.w + b.w);
     } else if constexpr (epi_is_resid(EPI)) {
       const float4 b = *reinterpret_cast<const float4*>(p.bias + n0);
       const float4 r = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.C) + (size_t)m * p.ldc + n0);
@@ -259,7 +273,7 @@ void gemm_nt_kernel(const GemmParams p) {
   using OutT = std::conditional_t<sizeof(T) == 4, float, bf16_t>;
   static_assert(sizeof(T) != 1 || ((EPI == EPI_BIAS || EPI == EPI_BIAS_QGELU) && GLDS && NSTAGE == 2 && L2PF == 0),
                 "the fp8 form exists for the bf16-output column-wise epilogues of the LDS-DMA kernels");
-  static_assert(!(epi_is_ln(EPI) || EPI == EPI_RESID_EMIT) || sizeof(T) == 2, "LayerNorm folding is a bf16-engine form");
+  static_assert(!(epi_is_ln(EPI) || epi_emits_stats(EPI)) || sizeof(T) == 2, "LayerNorm folding is a bf16-engine form");
   static_assert(!epi_is_ln(EPI) || NSTAGE == 2, "the row statistics are staged by the two-stage kernels' prologue");
   constexpr int BK = 8 * ELEMS16;          // 128-byte rows
   constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, STAGE = A_BYTES + W_BYTES;
@@ -792,19 +806,28 @@ void gemm_nt_kernel(const GemmParams p) {
         int m = m0 + wm * TM + i * 32 + it * 4 + rd_row;
         const bool in_range = m < p.M;
         if (p.ablate & 32) m &= 255;  // timeline experiment: every tile stores to the same 256 rows (L2-resident)
-        if constexpr (EPI == EPI_RESID_EMIT) {
+        if constexpr (epi_emits_stats(EPI)) {
           // the updated residual row piece (4 columns per lane, 16 lanes = one 64-column slice of one row): fp32 in
-          // place, its bf16 copy for the next GEMM's A operand, and the slice's LayerNorm partials {sum, centred M2}
+          // place + its bf16 copy for the next GEMM's A operand (EMIT), or the two 16-bit planes of the fp32 value (SPLIT);
+          // and the slice's LayerNorm partials {sum, centred M2}
           const float4 a4 = add[kAddBufs == 2 ? (i & 1) : 0][jp][it];
           const float o0 = a4.x + v[it][0], o1 = a4.y + v[it][1], o2 = a4.z + v[it][2], o3 = a4.w + v[it][3];
-          const float ssum = row16_sum((o0 + o1) + (o2 + o3));
-          const float mj = ssum * (1.0f / kLnSlice);
-          const float d0 = o0 - mj, d1 = o1 - mj, d2 = o2 - mj, d3 = o3 - mj;
-          const float m2 = row16_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
+          float ssum = 0.f, m2 = 0.f;
+          if (!(p.ablate & 128)) {   // (test hook: bit 7 skips the statistics, bit 6 the bf16 copy)
+            ssum = row16_sum((o0 + o1) + (o2 + o3));
+            const float mj = ssum * (1.0f / kLnSlice);
+            const float d0 = o0 - mj, d1 = o1 - mj, d2 = o2 - mj, d3 = o3 - mj;
+            m2 = row16_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
+          }
           if (in_range) {
-            store4(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n, o0, o1, o2, o3);
-            store4(reinterpret_cast<bf16_t*>(p.xb_out) + (size_t)m * p.ldc + n, o0, o1, o2, o3);
-            if ((lane & 15) == 0)
+            if constexpr (EPI == EPI_RESID_SPLIT) {
+              store4_split(reinterpret_cast<unsigned short*>(p.xb_out) + (size_t)m * p.ldc + n,
+                           reinterpret_cast<unsigned short*>(p.lo_io) + (size_t)m * p.ldc + n, o0, o1, o2, o3);
+            } else {
+              store4(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n, o0, o1, o2, o3);
+              if (!(p.ablate & 64)) store4(reinterpret_cast<bf16_t*>(p.xb_out) + (size_t)m * p.ldc + n, o0, o1, o2, o3);
+            }
+            if ((lane & 15) == 0 && !(p.ablate & 128))
               *reinterpret_cast<float2*>(p.st_out + ((size_t)m * (p.N / kLnSlice) + (n0 + wn * TN + jp * 64) / kLnSlice) * 2) =
                   make_float2(ssum, m2);
           }

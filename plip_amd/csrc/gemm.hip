@@ -130,7 +130,7 @@ int gemm_launch_fp8(int epi, int variant, const GemmParams& p, hipStream_t strea
 }
 
 static const char* kEpiNames[EPI_COUNT] = {"bias", "bias_qgelu", "bias_resid", "scale", "patch", "ln_bias", "ln_qgelu",
-                                           "resid_emit"};
+                                           "resid_emit", "resid_split"};
 
 int gemm_launch(int dtype, int epi, int variant, const GemmParams& p, hipStream_t stream, const char** kernel_name,
                 int policy) {

@@ -102,7 +102,7 @@ struct GemmTable {
   static GemmLaunchFn pick(int variant) {
     constexpr bool kB = sizeof(T) == 2, kF = sizeof(T) == 4;
     // LayerNorm-folded epilogues: bf16 product tiles only
-    constexpr bool kLn = epi_is_ln(EPI) || EPI == EPI_RESID_EMIT;
+    constexpr bool kLn = epi_is_ln(EPI) || epi_emits_stats(EPI);
     if constexpr (kLn && !kB) {
       return nullptr;
     } else {
@@ -173,6 +173,7 @@ struct GemmTable {
       case EPI_BIAS_LN: return pick<EPI_BIAS_LN>(variant);
       case EPI_QGELU_LN: return pick<EPI_QGELU_LN>(variant);
       case EPI_RESID_EMIT: return pick<EPI_RESID_EMIT>(variant);
+      case EPI_RESID_SPLIT: return pick<EPI_RESID_SPLIT>(variant);
       default: return nullptr;
     }
   }

@@ -186,7 +186,7 @@ int gemm_launch_skinny(int epi, const GemmParams& p, hipStream_t s, const char**
   static const char* names[EPI_COUNT] = {"gemm_skinny<bf16,32x64_splitk,bias>", "gemm_skinny<bf16,32x64_splitk,bias_qgelu>",
                                          "gemm_skinny<bf16,32x64_splitk,bias_resid>", nullptr, nullptr,
                                          "gemm_skinny<bf16,32x64_splitk,ln_bias>", "gemm_skinny<bf16,32x64_splitk,ln_qgelu>",
-                                         "gemm_skinny<bf16,32x64_splitk,resid_emit>"};
+                                         "gemm_skinny<bf16,32x64_splitk,resid_emit>", nullptr};
   if (kernel_name) *kernel_name = names[epi];
   switch (epi) {
     case EPI_BIAS: return launch_skinny<EPI_BIAS>(p, s);

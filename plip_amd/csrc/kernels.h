@@ -11,15 +11,18 @@ namespace plipmi {
 hipError_t launch_layernorm(const float* x, size_t x_row_stride, const float* g, const float* b, void* y, int y_dtype,
                             int rows, int D, float eps, hipStream_t s);
 
-// LayerNorm folded into the GEMMs (bf16 engine, gemm.h EPI_*_LN): the one LayerNorm pass a tower keeps -- fp32 in place
-// plus the bf16 copy xb [rows, D] and the statistics partials st [rows, D/64, 2] of its OUTPUT rows (D % 64 == 0)
-hipError_t launch_layernorm_emit(float* x, const float* g, const float* b, void* xb, float* st, int rows, int D, float eps,
-                                 hipStream_t s);
+// LayerNorm folded into the GEMMs (bf16 engine, gemm.h EPI_*_LN): the one LayerNorm pass a tower keeps -- fp32 rows in,
+// the normalised rows out as the split residual stream (common.h split_f32: hi = bf16 plane [rows, D], lo = int16
+// remainder plane, hi + lo == the fp32 value exactly) plus their statistics partials st [rows, D/64, 2] (D % 64 == 0)
+hipError_t launch_layernorm_emit(const float* x, const float* g, const float* b, void* hi, void* lo, float* st, int rows, int D,
+                                 float eps, hipStream_t s);
+// the two planes back to plain fp32 (n % 4 == 0 elements)
+hipError_t launch_join_planes(const void* hi, const void* lo, float* x, size_t n, hipStream_t s);
 // weight folding at plipmi_create: Wf[n,:] = bf16(pre * (W[n,:] * g - mean_k(W[n,:] * g))), c2[n] = pre * (W[n,:].b + bias[n])
 hipError_t launch_fold_ln(const float* W, const float* bias, const float* g, const float* b, void* Wf, float* c2, int rows,
                           int K, float pre, hipStream_t s);
 // token + position embedding with the same by-products (text tower's first block)
-hipError_t launch_text_embed_emit(const int64_t* ids, const float* tok, const float* pos, float* x, void* xb, float* st, int B,
+hipError_t launch_text_embed_emit(const int64_t* ids, const float* tok, const float* pos, void* hi, void* lo, float* st, int B,
                                   int S, int D, int vocab, hipStream_t s);
 
 // pixels fp32 [B,3,H,W] -> patch rows [B*np, Kpad] (dtype), column (c,u,v), zero padded to Kpad.
@@ -56,9 +59,10 @@ hipError_t launch_pool_layernorm(const float* x, int S, int D, const int64_t* id
                                  const float* ln_b, float eps, float* out, int B, hipStream_t s);
 
 // pooled row of every sample (CLS when ids == nullptr, else the caption's EOS row): attention output (bf16) and residual
-// row (fp32) copied to compact [B, D] buffers -- the inputs of the last block's pooled-row-only out_proj / fc1 / fc2
-hipError_t launch_pool_gather(const void* att, const float* x, int S, int D, const int64_t* ids, int eos_id, void* attp,
-                              float* xp, int B, hipStream_t s);
+// row (hi/lo planes -> fp32) copied to compact [B, D] buffers -- the inputs of the last block's pooled-row-only
+// out_proj / fc1 / fc2
+hipError_t launch_pool_gather(const void* att, const void* hi, const void* lo, int S, int D, const int64_t* ids, int eos_id,
+                              void* attp, float* xp, int B, hipStream_t s);
 
 hipError_t launch_l2_normalize(float* x, int N, int D, hipStream_t s);
 // C[M,N] = A[M,K] . W[N,K]^T, exact fp32 MFMA, split-K over the four waves of a 32x32-tile workgroup (N, K % 32 == 0)

@@ -207,20 +207,22 @@ hipError_t launch_quantize_rows_fp8(const float* src, void* dst, float* scale, i
 
 // ---------------------------------------------------------------------------------
 // LayerNorm folded into the neighbouring GEMMs (bf16 engine; gemm.h EPI_*_LN / EPI_RESID_EMIT).
-//   * layernorm_emit_kernel: the ONE LayerNorm pass a tower keeps (vision pre_layrnorm, modeling_clip.py:642): fp32
-//     in place, plus what the first block's folded LayerNorm needs of its output -- the bf16 copy of the rows (A
-//     operand of the q/k/v GEMM) and their statistics as per-64-column partials {sum, centred M2}.
+//   * layernorm_emit_kernel: the ONE LayerNorm pass a tower keeps (vision pre_layrnorm, modeling_clip.py:642): reads the
+//     fp32 embedding rows, writes the normalised rows as the engine's split residual stream (common.h split_f32: the hi
+//     plane is the bf16 A operand of the q/k/v GEMM, hi + lo the exact fp32 value) and the rows' statistics as
+//     per-64-column partials {sum, centred M2} for the first block's folded LayerNorm.
 //   * fold_ln_kernel (plipmi_create): W'[n,:] = bf16(pre * (W[n,:] * g - mean_k(W[n,:] * g))) -- gain folded in and the
 //     row centred, so that x . W'^T == (x - mean(x)) . (W * g)^T and LayerNorm's mean subtraction needs no epilogue term;
 //     c2[n] = pre * (sum_k W[n,k] b[k] + bias[n]); sums in fp64.
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void layernorm_emit_kernel(float* x, const float* __restrict__ g, const float* __restrict__ b,
-                                                             bf16_t* __restrict__ xb, float* __restrict__ st, int rows, int D,
-                                                             float eps) {
+__global__ __launch_bounds__(256) void layernorm_emit_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                             const float* __restrict__ b, unsigned short* __restrict__ hi,
+                                                             unsigned short* __restrict__ lo, float* __restrict__ st, int rows,
+                                                             int D, float eps) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;                       // wave-uniform
-  float* xr = x + (size_t)row * D;
+  const float* xr = x + (size_t)row * D;
   float4 v[kLnMaxVec];
   float s = 0.f;
 #pragma unroll
@@ -258,17 +260,32 @@ __global__ __launch_bounds__(256) void layernorm_emit_kernel(float* x, const flo
     const float d0 = y.x - mj, d1 = y.y - mj, d2 = y.z - mj, d3 = y.w - mj;
     const float m2 = row16_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
     if (live) {
-      store4(xr + idx, y.x, y.y, y.z, y.w);
-      store4(xb + (size_t)row * D + idx, y.x, y.y, y.z, y.w);
+      store4_split(hi + (size_t)row * D + idx, lo + (size_t)row * D + idx, y.x, y.y, y.z, y.w);
       if ((lane & 15) == 0) *reinterpret_cast<float2*>(st + ((size_t)row * ns + idx / kLnSlice) * 2) = make_float2(ssum, m2);
     }
   }
 }
-hipError_t launch_layernorm_emit(float* x, const float* g, const float* b, void* xb, float* st, int rows, int D, float eps,
-                                 hipStream_t s) {
+hipError_t launch_layernorm_emit(const float* x, const float* g, const float* b, void* hi, void* lo, float* st, int rows, int D,
+                                 float eps, hipStream_t s) {
   if (rows <= 0) return hipSuccess;
   if (D % kLnSlice || D > kLnMaxVec * 256) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(layernorm_emit_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, g, b, (bf16_t*)xb, st, rows, D, eps);
+  hipLaunchKernelGGL(layernorm_emit_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, g, b, (unsigned short*)hi,
+                     (unsigned short*)lo, st, rows, D, eps);
+  return hipGetLastError();
+}
+
+// hi/lo planes -> plain fp32 rows (plipmi_debug_hidden, and the head of an engine that runs its last block on every token)
+__global__ __launch_bounds__(256) void join_planes_kernel(const unsigned short* __restrict__ hi, const unsigned short* __restrict__ lo,
+                                                          float* __restrict__ x, size_t n4) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  *reinterpret_cast<float4*>(x + i * 4) = load4_split(hi + i * 4, lo + i * 4);
+}
+hipError_t launch_join_planes(const void* hi, const void* lo, float* x, size_t n, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  if (n % 4) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(join_planes_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, (const unsigned short*)hi,
+                     (const unsigned short*)lo, x, n / 4);
   return hipGetLastError();
 }
 
@@ -459,11 +476,11 @@ hipError_t launch_text_embed(const int64_t* ids, const float* tok, const float* 
   return hipGetLastError();
 }
 
-// the same lookup for the LayerNorm-folded engine: also emits the bf16 copy of the rows and their statistics partials
-// (one wave per row; 16 lanes cover one 64-column slice)
+// the same lookup for the LayerNorm-folded engine: writes the rows as the split residual stream (hi/lo planes) and emits
+// their statistics partials (one wave per row; 16 lanes cover one 64-column slice)
 __global__ __launch_bounds__(256) void text_embed_emit_kernel(const int64_t* __restrict__ ids, const float* __restrict__ tok,
-                                                              const float* __restrict__ pos, float* __restrict__ x,
-                                                              bf16_t* __restrict__ xb, float* __restrict__ st, int rows,
+                                                              const float* __restrict__ pos, unsigned short* __restrict__ hi,
+                                                              unsigned short* __restrict__ lo, float* __restrict__ st, int rows,
                                                               int S, int D, int vocab) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -486,18 +503,17 @@ __global__ __launch_bounds__(256) void text_embed_emit_kernel(const int64_t* __r
     const float d0 = y.x - mj, d1 = y.y - mj, d2 = y.z - mj, d3 = y.w - mj;
     const float m2 = row16_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
     if (live) {
-      store4(x + (size_t)row * D + idx, y.x, y.y, y.z, y.w);
-      store4(xb + (size_t)row * D + idx, y.x, y.y, y.z, y.w);
+      store4_split(hi + (size_t)row * D + idx, lo + (size_t)row * D + idx, y.x, y.y, y.z, y.w);
       if ((lane & 15) == 0) *reinterpret_cast<float2*>(st + ((size_t)row * ns + idx / kLnSlice) * 2) = make_float2(ssum, m2);
     }
   }
 }
-hipError_t launch_text_embed_emit(const int64_t* ids, const float* tok, const float* pos, float* x, void* xb, float* st, int B,
+hipError_t launch_text_embed_emit(const int64_t* ids, const float* tok, const float* pos, void* hi, void* lo, float* st, int B,
                                   int S, int D, int vocab, hipStream_t s) {
   if (B <= 0) return hipSuccess;
   if (D % kLnSlice) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(text_embed_emit_kernel, dim3((B * S + 3) / 4), dim3(256), 0, s, ids, tok, pos, x, (bf16_t*)xb, st, B * S, S,
-                     D, vocab);
+  hipLaunchKernelGGL(text_embed_emit_kernel, dim3((B * S + 3) / 4), dim3(256), 0, s, ids, tok, pos, (unsigned short*)hi,
+                     (unsigned short*)lo, st, B * S, S, D, vocab);
   return hipGetLastError();
 }
 
@@ -621,9 +637,10 @@ __device__ __forceinline__ int eos_position(const int64_t* row, int S, int eos_i
 }
 
 // The LAST block of a tower only matters for the row that is pooled afterwards (CLS, or the caption's EOS row): one
-// wavefront per sample picks that row and copies its attention output (bf16) and residual row (fp32) into compact [B, D]
-// buffers, on which out_proj / fc1 / fc2 of the last block then run (engine.hip run_last_block_pooled).
-__global__ __launch_bounds__(256) void pool_gather_kernel(const bf16_t* __restrict__ att, const float* __restrict__ x, int S, int D,
+// wavefront per sample picks that row and copies its attention output (bf16) and residual row (hi/lo planes -> fp32) into
+// compact [B, D] buffers, on which out_proj / fc1 / fc2 of the last block then run (engine.hip run_last_block_pooled).
+__global__ __launch_bounds__(256) void pool_gather_kernel(const bf16_t* __restrict__ att, const unsigned short* __restrict__ hi,
+                                                          const unsigned short* __restrict__ lo, int S, int D,
                                                           const int64_t* __restrict__ ids, int eos_id, bf16_t* __restrict__ attp,
                                                           float* __restrict__ xp, int B) {
   const int lane = threadIdx.x & 63;
@@ -633,16 +650,16 @@ __global__ __launch_bounds__(256) void pool_gather_kernel(const bf16_t* __restri
   const size_t src = ((size_t)smp * S + pos) * D, dst = (size_t)smp * D;
   for (int i = lane * 8; i < D; i += 512) {     // D % 8 == 0 (widths are multiples of 128)
     *reinterpret_cast<u32x4_t*>(attp + dst + i) = *reinterpret_cast<const u32x4_t*>(att + src + i);
-    *reinterpret_cast<float4*>(xp + dst + i) = *reinterpret_cast<const float4*>(x + src + i);
-    *reinterpret_cast<float4*>(xp + dst + i + 4) = *reinterpret_cast<const float4*>(x + src + i + 4);
+    *reinterpret_cast<float4*>(xp + dst + i) = load4_split(hi + src + i, lo + src + i);
+    *reinterpret_cast<float4*>(xp + dst + i + 4) = load4_split(hi + src + i + 4, lo + src + i + 4);
   }
 }
-hipError_t launch_pool_gather(const void* att, const float* x, int S, int D, const int64_t* ids, int eos_id, void* attp,
-                              float* xp, int B, hipStream_t s) {
+hipError_t launch_pool_gather(const void* att, const void* hi, const void* lo, int S, int D, const int64_t* ids, int eos_id,
+                              void* attp, float* xp, int B, hipStream_t s) {
   if (B <= 0) return hipSuccess;
   if (D % 8) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(pool_gather_kernel, dim3((B + 3) / 4), dim3(256), 0, s, (const bf16_t*)att, x, S, D, ids, eos_id,
-                     (bf16_t*)attp, xp, B);
+  hipLaunchKernelGGL(pool_gather_kernel, dim3((B + 3) / 4), dim3(256), 0, s, (const bf16_t*)att, (const unsigned short*)hi,
+                     (const unsigned short*)lo, S, D, ids, eos_id, (bf16_t*)attp, xp, B);
   return hipGetLastError();
 }
 

@@ -371,7 +371,9 @@ def attention(qkv: torch.Tensor, B: int, S: int, H: int, causal: bool = False, k
 def gemm_nt_ln(mode: int, a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, stats: Optional[torch.Tensor] = None,
                eps: float = 1e-5, variant: int = -1, out: Optional[torch.Tensor] = None):
     """Kernel-level entry (tests) for the LayerNorm-folded epilogues, see include/plipmi.h plipmi_gemm_nt_ln.
-    mode 0/1 -> bf16 [M,N]; mode 2 -> (C fp32 updated in place, xb bf16 [M,N], st fp32 [M,N/64,2])."""
+    mode 0/1 -> bf16 [M,N]; mode 2 -> (C fp32 updated in place, xb bf16 [M,N], st fp32 [M,N/64,2]); mode 3 -> the same
+    update on the split residual stream: ``out`` = (hi bf16 [M,N], lo int16 [M,N]), both updated in place; returns
+    (hi, lo, st)."""
     lib = _lib.load()
     assert a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and a.is_contiguous() and w.is_contiguous()
     M, K = a.shape
@@ -384,11 +386,35 @@ def gemm_nt_ln(mode: int, a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, 
             _lib.check(lib.plipmi_gemm_nt_ln(mode, variant, M, N, K, _ptr(a), _ptr(w), _ptr(bias), _ptr(stats),
                                              stats.shape[1], float(eps), _ptr(out), None, None, stream), "plipmi_gemm_nt_ln")
             return out
-        xb = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
         st = torch.empty((M, N // 64, 2), dtype=torch.float32, device=a.device)
+        if mode == 3:
+            hi, lo = out
+            assert hi.dtype == torch.bfloat16 and lo.dtype == torch.int16 and hi.is_contiguous() and lo.is_contiguous()
+            _lib.check(lib.plipmi_gemm_nt_ln(3, variant, M, N, K, _ptr(a), _ptr(w), _ptr(bias), None, 0, float(eps),
+                                             _ptr(lo), _ptr(hi), _ptr(st), stream), "plipmi_gemm_nt_ln")
+            return hi, lo, st
+        xb = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
         _lib.check(lib.plipmi_gemm_nt_ln(2, variant, M, N, K, _ptr(a), _ptr(w), _ptr(bias), None, 0, float(eps),
                                          _ptr(out), _ptr(xb), _ptr(st), stream), "plipmi_gemm_nt_ln")
         return out, xb, st
+
+
+def split_planes(x: torch.Tensor):
+    """fp32 -> the engine's two-plane residual form (csrc/common.h split_f32): hi = bf16 plane (round to nearest, ties
+    away from zero), lo = int16 remainder of the bit pattern; ``join_planes`` is the exact inverse."""
+    u = x.contiguous().view(torch.int32).to(torch.int64) & 0xFFFFFFFF
+    t = (u + 0x8000) & 0xFFFFFFFF
+    hi = (t >> 16).to(torch.int32)
+    lo = (u - (t & 0xFFFF0000))                                   # in [-32768, 32767]
+    hi16 = torch.where(hi >= 32768, hi - 65536, hi).to(torch.int16).view(torch.bfloat16)
+    return hi16, lo.to(torch.int16)
+
+
+def join_planes(hi: torch.Tensor, lo: torch.Tensor) -> torch.Tensor:
+    h = hi.view(torch.int16).to(torch.int64) & 0xFFFF
+    u = ((h << 16) + lo.to(torch.int64)) & 0xFFFFFFFF
+    u = torch.where(u >= 2 ** 31, u - 2 ** 32, u)
+    return u.to(torch.int32).view(torch.float32)
 
 
 def gemm_variant_built(dtype, variant: int) -> bool:

@@ -220,6 +220,38 @@ def test_layernorm_folded_producer_epilogue(variant):
         assert rel < 1e-4, rel
 
 
+@pytest.mark.parametrize("variant", [1, 36, 37, 41, 42, -1])
+def test_split_plane_residual_epilogue(variant):
+    """The engine's residual update: the fp32 stream lives as two 16-bit planes, hi = the value rounded to bf16 (the next
+    GEMM's A operand), lo = the signed remainder of its bit pattern, hi + lo == the fp32 value EXACTLY.  The kernel must
+    (a) read the planes back to the very fp32 value, (b) produce the same fp32 result as the plain-array epilogue (mode 2)
+    bit for bit, and (c) emit the same statistics."""
+    from plip_amd.engine import gemm_nt_ln, join_planes, split_planes
+    dev = torch.device("cuda:0")
+    g0 = torch.Generator().manual_seed(300 + variant)
+    for (M, N, K) in [(1, 256, 64), (50, 512, 512), (515, 768, 3072), (1300, 1024, 256)]:
+        a = torch.randn(M, K, generator=g0).to(dev).bfloat16()
+        w = (torch.randn(N, K, generator=g0) / K ** 0.5).to(dev).bfloat16()
+        bias = torch.randn(N, generator=g0).to(dev)
+        x0 = (torch.randn(M, N, generator=g0) * 3.0 + 11.0).to(dev)
+        x0[:, 7] -= 90.0
+        x0[0, :4] = torch.tensor([0.0, -0.0, 1e-30, -3.0e38], device=dev)[:min(4, N)]
+        hi0, lo0 = split_planes(x0)
+        assert torch.equal(join_planes(hi0, lo0).view(torch.int32), x0.view(torch.int32))       # the host mirror is exact
+        x_ref, xb_ref, st_ref = gemm_nt_ln(2, a, w, bias, variant=variant, out=x0.clone())
+        hi, lo, st = gemm_nt_ln(3, a, w, bias, variant=variant, out=(hi0.clone(), lo0.clone()))
+        torch.cuda.synchronize()
+        x = join_planes(hi, lo)
+        assert torch.equal(x.view(torch.int32), x_ref.view(torch.int32))                       # same fp32 stream, bit for bit
+        assert torch.equal(st, st_ref)
+        # hi is the bf16 nearest to x (ties away from zero; RNE differs only on exact ties)
+        diff = hi.view(torch.int16).to(torch.int32) - xb_ref.view(torch.int16).to(torch.int32)
+        ties = (x.view(torch.int32) & 0xFFFF) == 0x8000
+        assert (diff[~ties] == 0).all() and (diff.abs() <= 1).all()
+        ref = x0.double() + a.double() @ w.double().T + bias.double()
+        assert (x.double() - ref).abs().max().item() < 2e-4 * max(1.0, ref.abs().max().item())
+
+
 @pytest.mark.parametrize("epi", [0, 1, 2])
 def test_small_m_split_k_gemm(epi):
     """gemm_skinny.hip (variant -3): 32 x 64 tile per workgroup, K split over its four waves with a k permutation shared by

@@ -286,3 +286,18 @@ def test_load_checkpoint_refuses_code_carrying_pickles(tmp_path, monkeypatch):
         W.load_checkpoint(str(whole))
     got2, _ = W.load_checkpoint(str(whole), trust_pickle=True)
     np.testing.assert_array_equal(got2["visual_projection.weight"], sd["visual_projection.weight"])
+
+
+def test_split_plane_host_mirror_is_exact():
+    """The bf16 engine stores its fp32 residual stream as a bf16 plane + an int16 remainder plane (csrc/common.h
+    split_f32); the host mirror used by the GPU tests must invert exactly and its hi plane must be the nearest bf16."""
+    import torch
+    from plip_amd.engine import join_planes, split_planes
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(200000, generator=g) * torch.exp(torch.randn(200000, generator=g) * 6)
+    x[:6] = torch.tensor([0.0, -0.0, 1e-38, -3.0e38, 1.00390625, -1.00390625])      # the last two are exact bf16 ties
+    hi, lo = split_planes(x)
+    assert hi.dtype == torch.bfloat16 and lo.dtype == torch.int16
+    assert torch.equal(join_planes(hi, lo).view(torch.int32), x.view(torch.int32))
+    assert ((hi.float() - x).abs() <= (x.bfloat16().float() - x).abs()).all()
+    assert hi[4].item() == 1.0078125 and hi[5].item() == -1.0078125                  # ties go away from zero

@@ -205,6 +205,11 @@ def sec_lnbench():
                     out = torch.zeros(M, N, device=dev, dtype=torch.float32)
                     t0 = _time(lambda: gemm_nt(a, w, bias, epilogue=2, variant=v, out=out), iters=20)
                     t1 = _time(lambda: gemm_nt_ln(2, a, w, bias, variant=v, out=out), iters=20)
+                    hi = torch.zeros(M, N, device=dev, dtype=torch.bfloat16)
+                    lo = torch.zeros(M, N, device=dev, dtype=torch.int16)
+                    t2 = _time(lambda: gemm_nt_ln(3, a, w, bias, variant=v, out=(hi, lo)), iters=20)
+                    row.append(f"v{v}: {t0 * 1e3:6.1f} -> {t1 * 1e3:6.1f} -> split {t2 * 1e3:6.1f} us")
+                    continue
                 row.append(f"v{v}: {t0 * 1e3:6.1f} -> {t1 * 1e3:6.1f} us")
             except Exception as e:
                 row.append(f"v{v}: n/a")
