@@ -364,7 +364,7 @@ def main():
         "roofline_single_stream": roofline_1s,
         "roofline_by_role": {"note": "launches of the single-stream dominant kernel symbol split by what they compute, each priced "
                                      "against the bound its arithmetic intensity puts it under (ridge 312 FLOP/B at 2.5 PF / 8 TB/s); "
-                                     "bytes are algorithmic (operands once, fp32 residual read + write, bf16 copy)",
+                                     "bytes are algorithmic (operands once, fp32 residual stream read + written as two 16-bit planes)",
                              "roles": roles} if roles else None,
         "kernels": kernels,
     }
@@ -397,6 +397,31 @@ def main():
         except Exception as e:  # pragma: no cover
             os.environ.pop("PLIPMI_POOLED_LAST_BLOCK", None)
             res["dense_last_block"] = {"error": repr(e)}
+    if world == 1 and not args.no_fp32_tower and args.dtype == "bf16" and res["executed_gflop_per_pair"]["pooled_last_block"]:
+        # A/B, NOT the headline: the same step with the text tower on the captions' live rows only (plipmi_set_text_packing).
+        # The headline above executes every padded position of the 77-token context, as the reference does.
+        try:
+            model.engine.set_text_packing(True)
+            for _ in range(args.warmup):
+                sharded_pair_logits(model, px, ids, mask, overlap=bool(args.overlap), equal_shards=True)
+            torch.cuda.synchronize(dev)
+            t4 = time.perf_counter()
+            for _ in range(args.steps):
+                op = sharded_pair_logits(model, px, ids, mask, overlap=bool(args.overlap), equal_shards=True)
+            torch.cuda.synchronize(dev)
+            dtp = (time.perf_counter() - t4) / args.steps
+            live = float(mask.sum(dim=1).float().mean().item())          # BOS .. EOS inclusive
+            res["packed_captions"] = {
+                "note": "same step with plipmi_set_text_packing(1): rows behind each caption's EOS token are not computed (causal "
+                        "tower + EOS pooling: they cannot reach text_embeds); embeddings bit-identical to the padded step. Opt-in; "
+                        "the headline value is the padded computation",
+                "pairs_per_s": round(B / dtp, 1), "ms_per_step": round(dtp * 1e3, 3),
+                "mean_live_tokens_per_caption": round(live, 1), "context_length": cfg.context_length,
+                "max_abs_diff_of_logits_vs_padded": float((op[0] - logits).abs().max())}
+        except Exception as e:  # pragma: no cover
+            res["packed_captions"] = {"error": repr(e)}
+        finally:
+            model.engine.set_text_packing(False)
     if world == 1 and not args.no_fp32_tower and args.dtype == "bf16":
         # BASELINE.json configs[1]: ViT-B/32 image tower only, bs=256, fp32 (exact-fp32 MFMA engine), same pixels
         try:

@@ -154,6 +154,16 @@ int plipmi_encode_text(plipmi_handle h, const int64_t* ids, const int64_t* atten
  * zero_shot_classification runs both towers at batch 8 (plip.py:90-91), where the step is launch-bound. */
 int plipmi_set_graph_batch(plipmi_handle h, int max_batch);
 
+/* Caption packing (bf16 engine, off by default; environment PLIPMI_TEXT_PACKING=1).  CLIPTextTransformer is causal and
+ * pools the EOS row only (modeling_clip.py:543-581), so the positions behind a caption's EOS token -- the tokenizer's
+ * padding to 77 -- cannot influence text_embeds; the reference computes them anyway.  With packing on, plipmi_encode_text
+ * lays the captions' live rows (0 .. EOS) end to end and runs every kernel of the text tower on those rows only: lengths,
+ * row offsets and the live-row count are derived from `ids` ON THE DEVICE (no host synchronisation; the path stays
+ * graph-capturable), the GEMMs size their grids for the padded worst case and retire dead tiles at once, attention takes
+ * per-caption lengths.  text_embeds are BIT-IDENTICAL to the padded computation.  A caption of L tokens then costs L/77 of
+ * a padded one.  The default (off) executes every padded position, which is what the bench's headline line measures. */
+int plipmi_set_text_packing(plipmi_handle h, int on);
+
 /* in-place row-wise x / sqrt(sum x^2), no epsilon (modeling_clip.py:57-65) */
 int plipmi_l2_normalize(plipmi_handle h, float* x, int N, int D, void* stream);
 

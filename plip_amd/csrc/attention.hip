@@ -14,7 +14,7 @@
 namespace plipmi {
 
 hipError_t launch_attention_mfma(const void* qkv, void* out, int B, int S, int H, int causal, const int64_t* key_mask,
-                                 hipStream_t s);
+                                 hipStream_t s, const int* cu);
 
 constexpr int kDh = 64;      // head dim
 constexpr int kKeyTile = 64;  // keys staged in LDS per step
@@ -119,12 +119,13 @@ __global__ __launch_bounds__(kMaxThreads) void attention_valu_kernel(const T* __
 }
 
 hipError_t launch_attention(const void* qkv, void* out, int dtype, int B, int S, int H, int causal,
-                            const int64_t* key_mask, int impl, hipStream_t s) {
+                            const int64_t* key_mask, int impl, hipStream_t s, const int* cu) {
   if (B <= 0) return hipSuccess;
   if (impl == 1) {
     if (dtype != 1) return hipErrorInvalidValue;
-    return launch_attention_mfma(qkv, out, B, S, H, causal, key_mask, s);
+    return launch_attention_mfma(qkv, out, B, S, H, causal, key_mask, s, cu);
   }
+  if (cu) return hipErrorInvalidValue;   // packed rows are a bf16 MFMA-kernel form
   const int threads = ((S + 63) / 64) * 64;
   if (threads > 1024) return hipErrorInvalidValue;  // S <= 1024 (ViT-L/14@336 has 577 tokens)
   const dim3 grid(B * H), block(threads);

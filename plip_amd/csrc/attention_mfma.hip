@@ -50,7 +50,9 @@ template <int KT, int PAIRS>  // 32-key tiles: S <= 32*KT
 __global__ __launch_bounds__(64 * KT) void attention_mfma_kernel(const bf16_t* __restrict__ qkv,
                                                                  bf16_t* __restrict__ out, int S, int H, int causal,
                                                                  const int64_t* __restrict__ key_mask, int n_problems,
-                                                                 int pairs /* == PAIRS; a run-time value so the loop stays a loop */) {
+                                                                 int pairs /* == PAIRS; a run-time value so the loop stays a loop */,
+                                                                 const int* __restrict__ cu /* packed rows: sample b owns rows
+                                                                 cu[b] .. cu[b+1]-1 of qkv / out (nullptr: b*S .. b*S+S-1) */) {
   constexpr int SP = 32 * KT;   // padded sequence
   constexpr int NT = 64 * KT;
   constexpr int NP = SP * 8 / NT;   // 16-byte pieces of K (and of V) per thread: 4
@@ -70,7 +72,6 @@ __global__ __launch_bounds__(64 * KT) void attention_mfma_kernel(const bf16_t* _
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int q0 = wave * 32;
-  const bool active = q0 < S;
   const int lrow = lane & 31, hi_c = lane >> 5;
   const int qidx_c = q0 + lrow;
   const int lsw = (lrow >> 1) & 7;
@@ -78,11 +79,12 @@ __global__ __launch_bounds__(64 * KT) void attention_mfma_kernel(const bf16_t* _
   u32x4 kreg[NP], vreg[NP];
   auto fetch = [&](int bh) {   // this thread's pieces of problem bh's K and V rows -> registers
     const int b = bh / H, h = bh - b * H;
-    const bf16_t* base = qkv + (size_t)b * S * ld + h * 64;
+    const int row0 = cu ? cu[b] : b * S, Sb = cu ? cu[b + 1] - row0 : S;
+    const bf16_t* base = qkv + (size_t)row0 * ld + h * 64;
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
       const int e = tid + i * NT, row = e >> 3, c = e & 7;
-      const bf16_t* src = base + (size_t)(row < S ? row : S - 1) * ld + c * 8;
+      const bf16_t* src = base + (size_t)(row < Sb ? row : Sb - 1) * ld + c * 8;
       kreg[i] = *reinterpret_cast<const u32x4*>(src + D);
       vreg[i] = *reinterpret_cast<const u32x4*>(src + 2 * D);
     }
@@ -100,10 +102,16 @@ __global__ __launch_bounds__(64 * KT) void attention_mfma_kernel(const bf16_t* _
     int qidx = qidx_c, hi = hi_c;
     asm volatile("" : "+v"(qidx), "+v"(hi));
     const int b = bh / H, h = bh - b * H;
-    const bf16_t* base = qkv + (size_t)b * S * ld + h * 64;
+    // packed captions: this problem's rows start at cu[b] and there are cu[b+1] - cu[b] of them (queries AND keys); the
+    // tokenizer mask keeps its [B, S] layout.  Keys past the caption's last row are masked like sequence padding, so a
+    // query's result is the one the padded layout gives it, bit for bit (a masked key contributes an exact zero).
+    const int row0 = __builtin_amdgcn_readfirstlane(cu ? cu[b] : b * S);
+    const int Sb = __builtin_amdgcn_readfirstlane(cu ? cu[b + 1] - row0 : S);
+    const bool active = q0 < Sb;
+    const bf16_t* base = qkv + (size_t)row0 * ld + h * 64;
     // key validity bits (sequence padding and the tokenizer's attention_mask): key = tid
     {
-      const bool ok = tid < S && (key_mask == nullptr || key_mask[(size_t)b * S + tid] != 0);
+      const bool ok = tid < Sb && (key_mask == nullptr || key_mask[(size_t)b * S + tid] != 0);
       const unsigned long long bits = __ballot(ok);
       if (lane == 0) mk[wave] = bits;
       if (KT < 4 && tid < 4 - KT) mk[KT + tid] = 0ull;
@@ -118,7 +126,7 @@ __global__ __launch_bounds__(64 * KT) void attention_mfma_kernel(const bf16_t* _
     // these rows, so an LDS image of Q would only cost residency (8-16 KB per workgroup = a third of its LDS).
     u32x4 qf[4];
     {
-      const bf16_t* qrow = base + (size_t)(qidx < S ? qidx : S - 1) * ld;
+      const bf16_t* qrow = base + (size_t)(qidx < Sb ? qidx : Sb - 1) * ld;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const u32x4*>(qrow + (ks * 2 + hi) * 8);
     }
@@ -211,7 +219,7 @@ __global__ __launch_bounds__(64 * KT) void attention_mfma_kernel(const bf16_t* _
         const int r = q0 + it * 8 + (lane >> 3);
         const u32x4 raw = *reinterpret_cast<const u32x4*>(Ks + r * 128 + ((c ^ ((r >> 1) & 7)) << 4));
         const u32x4 v = (r & 1) ? u32x4{raw[2], raw[3], raw[0], raw[1]} : raw;
-        if (r < S) *reinterpret_cast<u32x4*>(out + ((size_t)b * S + r) * D + h * 64 + c * 8) = v;
+        if (r < Sb) *reinterpret_cast<u32x4*>(out + ((size_t)row0 + r) * D + h * 64 + c * 8) = v;
       }
     }
     if (pp + 1 < npairs) __syncthreads();   // the next problem overwrites Ks / Vs / mk
@@ -389,9 +397,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 }
 
 hipError_t launch_attention_mfma(const void* qkv, void* out, int B, int S, int H, int causal, const int64_t* key_mask,
-                                 hipStream_t s) {
+                                 hipStream_t s, const int* cu) {
   if (S <= 0) return hipErrorInvalidValue;
   if (S > 128) {
+    if (cu) return hipErrorInvalidValue;   // packed rows: short-sequence kernel only (captions are 77 tokens at most)
     hipLaunchKernelGGL(attention_flash_kernel, dim3(B * H, (S + 127) / 128), dim3(256), 0, s, (const bf16_t*)qkv,
                        (bf16_t*)out, S, H, causal, key_mask);
     return hipGetLastError();
@@ -401,7 +410,7 @@ hipError_t launch_attention_mfma(const void* qkv, void* out, int B, int S, int H
   const dim3 grid((B * H + kPairs - 1) / kPairs), block(64 * KT);
 #define PLIPMI_ATT(K) \
   hipLaunchKernelGGL((attention_mfma_kernel<K, kPairs>), grid, block, 0, s, (const bf16_t*)qkv, (bf16_t*)out, S, H, causal, \
-                     key_mask, B * H, kPairs)
+                     key_mask, B * H, kPairs, cu)
   switch (KT) {
     case 1: PLIPMI_ATT(1); break;
     case 2: PLIPMI_ATT(2); break;

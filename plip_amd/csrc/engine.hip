@@ -69,6 +69,10 @@ struct Tower {
   // statistics partials [M, D/64, 2]
   float* st = nullptr;
   void* lo = nullptr;
+  // packed captions (text tower, plipmi_set_text_packing): rows past a caption's EOS are not computed; everything about the
+  // packing lives on the device -- cu [B+1] row offsets, rowmap [B*S] packed row -> (sample << 8 | position), mdev = live rows
+  int *cu = nullptr, *rowmap = nullptr, *mdev = nullptr;
+  bool packed = false;   // set for the duration of one packed forward
   // last block, pooled rows only (one row per sample): residual row, attention output, bf16 copy, MLP hidden, partials
   float* xp = nullptr; void *attp = nullptr, *hp = nullptr, *mlpp = nullptr; float* stp = nullptr;
 };
@@ -104,6 +108,10 @@ struct plipmi_engine {
   // is pooled afterwards (CLS / EOS): the encode paths run them on that one row per sample (PLIPMI_POOLED_LAST_BLOCK=0
   // computes all rows, as plipmi_debug_hidden always does).  bf16 LayerNorm-folded engine only.
   bool pooled_last = false;
+  // Packed captions (plipmi_set_text_packing; PLIPMI_TEXT_PACKING=1): the text tower computes rows 0 .. EOS of each caption
+  // only -- causal attention and EOS pooling mean the rows behind EOS cannot reach the embedding.  Off by default: the
+  // default engine executes every padded position, like the reference does.
+  bool text_pack = false;
   int gemm_policy = 0;  // tile policy of this handle's GEMMs (plipmi_set_gemm_policy)
   // small-batch hipGraph replay (plipmi_set_graph_batch; PLIPMI_GRAPH_BATCH): batches of at most this many samples
   int graph_batch = 0;
@@ -213,6 +221,9 @@ void carve(plipmi_engine* e, Carver& c) {
     t->h = c.take<void>(M * D, es);
     if (e->fp8w) { t->h8 = c.take<void>(M * D, 1); t->hs = c.take<float>(M, 4); }
     if (e->ln_fold) { t->st = c.take<float>(M * (D / kLnSlice) * 2, 4); t->lo = c.take<void>(M * D, 2); }
+    if (e->ln_fold && t == &e->txt) {
+      t->cu = c.take<int>(B + 1, 4); t->rowmap = c.take<int>(M, 4); t->mdev = c.take<int>(1, 4);
+    }
     if (e->pooled_last) {
       t->xp = c.take<float>(B * D, 4); t->attp = c.take<void>(B * D, es); t->hp = c.take<void>(B * D, es);
       t->mlpp = c.take<void>(B * F, es); t->stp = c.take<float>(B * (D / kLnSlice) * 2, 4);
@@ -286,9 +297,9 @@ const char* name_with_role(const char* name, const char* role) {
 }
 
 int run_gemm(plipmi_engine* e, int epi, const void* A, const void* W, void* C, const float* bias, int M, int N, int K,
-             int ldc, int np, hipStream_t s, const char* role, const LnArgs* ln = nullptr) {
+             int ldc, int np, hipStream_t s, const char* role, const LnArgs* ln = nullptr, const int* m_dev = nullptr) {
   GemmParams p;
-  p.A = A; p.W = W; p.C = C; p.bias = bias;
+  p.A = A; p.W = W; p.C = C; p.bias = bias; p.m_dev = m_dev;
   p.M = M; p.N = N; p.K = K; p.lda = K; p.ldw = K; p.ldc = ldc; p.alpha = 1.f; p.np = np;
   if (ln) {
     p.ln_stats = ln->stats; p.ln_ns = ln->ns; p.ln_inv_d = ln->inv_d; p.ln_eps = ln->eps;
@@ -332,9 +343,11 @@ int run_layers(plipmi_engine* e, Tower& t, int B, int n_layers, int causal, cons
   const int M = B * t.S, D = t.D, F = t.F;
   const float eps = e->cfg.layer_norm_eps;
   const int impl = (&t == &e->vis) ? e->attn_impl_vis : e->attn_impl_txt;
+  const int* cu = t.packed ? t.cu : nullptr;          // packed captions: row offsets / live-row count on the device
+  const int* md = t.packed ? t.mdev : nullptr;
   auto attention = [&]() -> int {
     Scope sc(e, s, impl ? "attention_mfma" : "attention_valu", 4.0 * B * t.H * (double)t.S * t.S * 64, (double)M * 4 * D * e->esz);
-    HIP_TRY(launch_attention(t.qkv, t.att, e->dtype, B, t.S, t.H, causal, key_mask, impl, s));
+    HIP_TRY(launch_attention(t.qkv, t.att, e->dtype, B, t.S, t.H, causal, key_mask, impl, s, cu));
     return PLIPMI_OK;
   };
   if (e->ln_fold) {
@@ -347,13 +360,14 @@ int run_layers(plipmi_engine* e, Tower& t, int B, int n_layers, int causal, cons
     LnArgs emit; emit.xb_out = t.h; emit.st_out = t.st; emit.lo_io = t.lo;
     for (int l = 0; l < n_layers; ++l) {
       const LayerW& w = t.layers[l];
-      RUN(run_gemm(e, EPI_BIAS_LN, t.h, w.wqkv, t.qkv, w.bqkv, M, 3 * D, D, 3 * D, 0, s, "qkv", &use));
+      RUN(run_gemm(e, EPI_BIAS_LN, t.h, w.wqkv, t.qkv, w.bqkv, M, 3 * D, D, 3 * D, 0, s, "qkv", &use, md));
       RUN(attention());
-      RUN(run_gemm(e, EPI_RESID_SPLIT, t.att, w.wo, nullptr, w.bo, M, D, D, D, 0, s, "out_proj", &emit));
-      RUN(run_gemm(e, EPI_QGELU_LN, t.h, w.w1, t.mlp, w.b1, M, F, D, F, 0, s, "fc1", &use));
-      RUN(run_gemm(e, EPI_RESID_SPLIT, t.mlp, w.w2, nullptr, w.b2, M, D, F, D, 0, s, "fc2", &emit));
+      RUN(run_gemm(e, EPI_RESID_SPLIT, t.att, w.wo, nullptr, w.bo, M, D, D, D, 0, s, "out_proj", &emit, md));
+      RUN(run_gemm(e, EPI_QGELU_LN, t.h, w.w1, t.mlp, w.b1, M, F, D, F, 0, s, "fc1", &use, md));
+      RUN(run_gemm(e, EPI_RESID_SPLIT, t.mlp, w.w2, nullptr, w.b2, M, D, F, D, 0, s, "fc2", &emit, md));
     }
-    if (!more_follow) {   // a consumer of plain fp32 rows follows (the every-token head, plipmi_debug_hidden)
+    if (!more_follow) {
+      if (t.packed) return fail(PLIPMI_ERR_INVALID, "packed rows have no every-token form");   // a consumer of plain fp32 rows follows (the every-token head, plipmi_debug_hidden)
       Scope sc(e, s, "join_planes", 0, (double)M * D * 8);
       HIP_TRY(launch_join_planes(t.h, t.lo, t.x, (size_t)M * D, s));
     }
@@ -398,11 +412,12 @@ int run_last_block_pooled(plipmi_engine* e, Tower& t, int B, int causal, const i
   const LayerW& w = t.layers[t.L - 1];
   const int impl = (&t == &e->vis) ? e->attn_impl_vis : e->attn_impl_txt;
   LnArgs use; use.stats = t.st; use.ns = D / kLnSlice; use.inv_d = 1.0f / (float)D; use.eps = e->cfg.layer_norm_eps;
-  RUN(run_gemm(e, EPI_BIAS_LN, t.h, w.wqkv, t.qkv, w.bqkv, M, 3 * D, D, 3 * D, 0, s, "qkv", &use));
+  const int* cu = t.packed ? t.cu : nullptr;
+  RUN(run_gemm(e, EPI_BIAS_LN, t.h, w.wqkv, t.qkv, w.bqkv, M, 3 * D, D, 3 * D, 0, s, "qkv", &use, t.packed ? t.mdev : nullptr));
   { Scope sc(e, s, impl ? "attention_mfma" : "attention_valu", 4.0 * B * t.H * (double)t.S * t.S * 64, (double)M * 4 * D * e->esz);
-    HIP_TRY(launch_attention(t.qkv, t.att, e->dtype, B, t.S, t.H, causal, key_mask, impl, s)); }
+    HIP_TRY(launch_attention(t.qkv, t.att, e->dtype, B, t.S, t.H, causal, key_mask, impl, s, cu)); }
   { Scope sc(e, s, "pool_gather", 0, (double)B * D * (2 * e->esz + 8));
-    HIP_TRY(launch_pool_gather(t.att, t.h, t.lo, t.S, D, ids, eos_id, t.attp, t.xp, B, s)); }
+    HIP_TRY(launch_pool_gather(t.att, t.h, t.lo, t.S, D, ids, eos_id, t.attp, t.xp, B, s, cu)); }
   LnArgs emit; emit.xb_out = t.hp; emit.st_out = t.stp;
   RUN(run_gemm(e, EPI_RESID_EMIT, t.attp, w.wo, t.xp, w.bo, B, D, D, D, 0, s, "~out_proj_pooled", &emit));
   use.stats = t.stp;
@@ -434,8 +449,16 @@ int vision_embed(plipmi_engine* e, const float* pixels, const uint8_t* tiles_u8,
   return PLIPMI_OK;
 }
 
-int text_embed(plipmi_engine* e, const int64_t* ids, int B, hipStream_t s) {
+int text_embed(plipmi_engine* e, const int64_t* ids, int B, hipStream_t s, int eos_id = -1) {
   Tower& t = e->txt;
+  if (t.packed) {
+    { Scope sc(e, s, "text_pack", 0, (double)B * t.S * 12);
+      HIP_TRY(launch_text_pack(ids, B, t.S, eos_id, t.cu, t.rowmap, t.mdev, s)); }
+    Scope sc(e, s, "text_embed", 0, (double)B * t.S * t.D * 8.2);
+    HIP_TRY(launch_text_embed_emit_packed(ids, e->tok, e->tpos, t.h, t.lo, t.st, t.rowmap, t.mdev, B * t.S, t.S, t.D,
+                                          e->cfg.vocab_size, s));
+    return PLIPMI_OK;
+  }
   Scope sc(e, s, "text_embed", 0, (double)B * t.S * t.D * (e->ln_fold ? 8.2 : 8.0));
   if (e->ln_fold) HIP_TRY(launch_text_embed_emit(ids, e->tok, e->tpos, t.h, t.lo, t.st, B, t.S, t.D, e->cfg.vocab_size, s));
   else HIP_TRY(launch_text_embed(ids, e->tok, e->tpos, t.x, B, t.S, t.D, e->cfg.vocab_size, s));
@@ -482,7 +505,11 @@ int image_forward(plipmi_handle h, const float* pixels, const uint8_t* tiles, in
 }
 int text_forward(plipmi_handle h, const int64_t* ids, const int64_t* mask, int B, int eos_token_id, float* out,
                         int normalize, hipStream_t s) {
-  RUN(text_embed(h, ids, B, s));
+  // Packed captions (opt-in): the tower is causal and only the EOS row is pooled, so rows past EOS cannot reach the output;
+  // they are left out of every kernel.  Needs the pooled last block (no every-token consumer) and the bf16 MFMA attention.
+  struct Unpack { Tower& t; ~Unpack() { t.packed = false; } } unpack{h->txt};
+  h->txt.packed = h->text_pack && h->ln_fold && h->pooled_last && h->attn_impl_txt == 1 && h->txt.S <= 128;
+  RUN(text_embed(h, ids, B, s, eos_token_id));
   if (h->pooled_last) {
     RUN(run_layers(h, h->txt, B, h->txt.L - 1, 1, mask, s, /*more_follow=*/true));
     RUN(run_last_block_pooled(h, h->txt, B, 1, mask, ids, eos_token_id, s));
@@ -568,7 +595,9 @@ int plipmi_create(const plipmi_config* cfg, const plipmi_weights* w, void* strea
   { const char* lf = getenv("PLIPMI_LN_FOLD");
     e->ln_fold = e->dtype == PLIPMI_BF16 && !e->fp8w && !(lf && atoi(lf) == 0);
     const char* pl = getenv("PLIPMI_POOLED_LAST_BLOCK");
-    e->pooled_last = e->ln_fold && !(pl && atoi(pl) == 0); }
+    e->pooled_last = e->ln_fold && !(pl && atoi(pl) == 0);
+    const char* tp = getenv("PLIPMI_TEXT_PACKING");
+    e->text_pack = e->pooled_last && tp && atoi(tp) != 0; }
   { const char* gb = getenv("PLIPMI_GRAPH_BATCH");
     e->graph_batch_cap = std::min(g.max_batch, 32);
     e->graph_batch = gb ? std::max(0, std::min(atoi(gb), e->graph_batch_cap)) : e->graph_batch_cap; }
@@ -680,6 +709,18 @@ int plipmi_encode_text(plipmi_handle h, const int64_t* ids, const int64_t* atten
 int plipmi_set_graph_batch(plipmi_handle h, int max_batch) {
   if (!h) return fail(PLIPMI_ERR_INVALID, "null handle");
   h->graph_batch = std::max(0, std::min(max_batch, h->graph_batch_cap));
+  return PLIPMI_OK;
+}
+
+int plipmi_set_text_packing(plipmi_handle h, int on) {
+  if (!h) return fail(PLIPMI_ERR_INVALID, "null handle");
+  if (on && !h->pooled_last)
+    return fail(PLIPMI_ERR_INVALID, "caption packing needs the bf16 engine's pooled last block (compute_dtype bf16, LayerNorm folding on)");
+  if ((on != 0) != h->text_pack) {   // captured text forwards hold the other form's launches
+    for (auto& kv : h->graphs) if (kv.second.exec) hipGraphExecDestroy(kv.second.exec);
+    h->graphs.clear();
+  }
+  h->text_pack = on != 0;
   return PLIPMI_OK;
 }
 

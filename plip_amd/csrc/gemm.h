@@ -85,6 +85,9 @@ struct GemmParams {
   void* xb_out = nullptr;
   float* st_out = nullptr;
   void* lo_io = nullptr;
+  // Row count known only on the device (packed captions, kernels.h launch_text_pack): when set, the kernel processes
+  // min(*m_dev, M) rows -- M then only sizes the grid; workgroups whose tile starts past the live rows exit at once
+  const int* m_dev = nullptr;
   // Tile raster: the N tiles are cut in column groups `gw` tiles wide; logical tile ids run group by group,
   // M-major inside a group.  An XCD's contiguous id range is then a compact (rows x gw) patch whose W panels
   // (gw*BN rows of W) stay resident in its 4 MiB L2 while the A row panels stream through once.
@@ -299,6 +302,12 @@ void gemm_nt_kernel(const GemmParams p) {
   const int gw = p.gw > 0 ? p.gw : nbn, tpg = nbm * gw;  // column group width, tiles per group
   const int cgrp = lid / tpg, crem = lid - cgrp * tpg;
   const int m0 = (crem / gw) * BM, n0 = (cgrp * gw + crem % gw) * BN;
+  int Mrt = p.M;   // live rows
+  if (p.m_dev) {
+    const int md = __builtin_amdgcn_readfirstlane(*p.m_dev);
+    Mrt = md < p.M ? md : p.M;
+    if (m0 >= Mrt) return;   // workgroup-uniform
+  }
 
   // ---- staging addresses --------------------------------------------------
   // thread -> LDS chunk position q = pass*NT + tid: row = q>>3, slot = q&7, and the
@@ -310,7 +319,7 @@ void gemm_nt_kernel(const GemmParams p) {
 #pragma unroll
   for (int i = 0; i < PA; ++i) {
     int r = m0 + i * (NT / 8) + srow;
-    r = r < p.M ? r : p.M - 1;  // M edge: re-read the last row, stores are masked
+    r = r < Mrt ? r : Mrt - 1;  // M edge: re-read the last row, stores are masked
     a_src[i] = reinterpret_cast<const char*>(p.A) + ((size_t)r * p.lda + schunk * ELEMS16) * sizeof(T);
   }
 #pragma unroll
@@ -421,7 +430,7 @@ void gemm_nt_kernel(const GemmParams p) {
   if constexpr (L2PF > 0) {
     const int line = tid < BM + BN ? tid : BM + BN - 1;  // every lane touches (no exec-masked wave may skip the op)
     if (line < BM) {
-      const int r = m0 + line < p.M ? m0 + line : p.M - 1;
+      const int r = m0 + line < Mrt ? m0 + line : Mrt - 1;
       touch_ptr = reinterpret_cast<const char*>(p.A) + (size_t)r * p.lda * sizeof(T);
     } else {
       touch_ptr = reinterpret_cast<const char*>(p.W) + (size_t)(n0 + line - BM) * p.ldw * sizeof(T);
@@ -465,7 +474,7 @@ void gemm_nt_kernel(const GemmParams p) {
 #pragma unroll
       for (int it = 0; it < 8; ++it) {
         const int m = m0 + wm * TM + i * 32 + it * 4 + rd_row;
-        dst[jp][it] = EpilogueOp<T, EPI>::load(p, m < p.M ? m : p.M - 1, n0 + wn * TN + jp * 64 + rd_col);
+        dst[jp][it] = EpilogueOp<T, EPI>::load(p, m < Mrt ? m : Mrt - 1, n0 + wn * TN + jp * 64 + rd_col);
       }
   };
 
@@ -630,7 +639,7 @@ void gemm_nt_kernel(const GemmParams p) {
     // then reads one float per row instead of walking the partials (a chain of L2 round trips per row) before the stores.
     float* ln_rows = reinterpret_cast<float*>(smem + NSTAGE * STAGE);
     for (int r = tid; r < BM; r += NT) {
-      const int mr = m0 + r < p.M ? m0 + r : p.M - 1;
+      const int mr = m0 + r < Mrt ? m0 + r : Mrt - 1;
       float mu, rs;
       ln_combine(p.ln_stats + (size_t)mr * p.ln_ns * 2, p.ln_ns, p.ln_inv_d, p.ln_eps, mu, rs);
       ln_rows[r] = rs;
@@ -714,7 +723,7 @@ void gemm_nt_kernel(const GemmParams p) {
       if constexpr (sizeof(T) == 1) {
         if (scaled) {  // dequantise: one scale per output row (this lane's row of the block) x one per column
           const int mr = m0 + wm * TM + i * 32 + lrow;
-          const float sa = p.row_scale[mr < p.M ? mr : p.M - 1];
+          const float sa = p.row_scale[mr < Mrt ? mr : Mrt - 1];
 #pragma unroll
           for (int j = 0; j < NI; ++j)
 #pragma unroll
@@ -761,7 +770,7 @@ void gemm_nt_kernel(const GemmParams p) {
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
           int m = m0 + wm * TM + i * 32 + it * 8 + hr_row;
-          const bool in_range = m < p.M;
+          const bool in_range = m < Mrt;
           if (p.ablate & 32) m &= 255;  // timeline experiment: every tile stores to the same 256 rows (L2-resident)
           if (in_range)
             *reinterpret_cast<u32x4*>(reinterpret_cast<OutT*>(p.C) + (size_t)m * p.ldc + n0 + wn * TN + jp * 64 + hr_chunk * 8) = o[it];
@@ -804,7 +813,7 @@ void gemm_nt_kernel(const GemmParams p) {
 #pragma unroll
       for (int it = 0; it < 8; ++it) {
         int m = m0 + wm * TM + i * 32 + it * 4 + rd_row;
-        const bool in_range = m < p.M;
+        const bool in_range = m < Mrt;
         if (p.ablate & 32) m &= 255;  // timeline experiment: every tile stores to the same 256 rows (L2-resident)
         if constexpr (epi_emits_stats(EPI)) {
           // the updated residual row piece (4 columns per lane, 16 lanes = one 64-column slice of one row): fp32 in

@@ -144,6 +144,8 @@ int gemm_launch(int dtype, int epi, int variant, const GemmParams& p, hipStream_
     if (span >= (1ull << 32)) variant = 1;
   }
   if (p.M <= 0) return 0;
+  // a device-side row count is read by gemm_nt_kernel only (not by the archived persistent / 8-phase forms or the naive kernel)
+  if (p.m_dev && (variant < 0 || (variant >= 10 && variant <= 12) || variant == 20)) return (int)hipErrorInvalidValue;
   const int bk = dtype == 1 ? 64 : 32;
   if (variant >= 0) {
     if (variant >= kNumVariants) return (int)hipErrorInvalidValue;

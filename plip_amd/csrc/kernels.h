@@ -61,8 +61,9 @@ hipError_t launch_pool_layernorm(const float* x, int S, int D, const int64_t* id
 // pooled row of every sample (CLS when ids == nullptr, else the caption's EOS row): attention output (bf16) and residual
 // row (hi/lo planes -> fp32) copied to compact [B, D] buffers -- the inputs of the last block's pooled-row-only
 // out_proj / fc1 / fc2
+// cu != nullptr: packed rows, the pooled row of sample b is its last one, cu[b+1]-1
 hipError_t launch_pool_gather(const void* att, const void* hi, const void* lo, int S, int D, const int64_t* ids, int eos_id,
-                              void* attp, float* xp, int B, hipStream_t s);
+                              void* attp, float* xp, int B, hipStream_t s, const int* cu = nullptr);
 
 hipError_t launch_l2_normalize(float* x, int N, int D, hipStream_t s);
 // C[M,N] = A[M,K] . W[N,K]^T, exact fp32 MFMA, split-K over the four waves of a 32x32-tile workgroup (N, K % 32 == 0)
@@ -101,7 +102,18 @@ hipError_t launch_scale_copy(const float* src, float* dst, int n, float scale, h
 // Multi-head attention over the fused qkv buffer [B*S, 3*D] (q | k | v, head h at columns h*64..), the 1/sqrt(64)
 // scale already folded into q.  out [B*S, D].  causal: key j <= query i.  key_mask: int64 [B,S] or nullptr.
 //   impl 0 = exact fp32 VALU kernel (any dtype), 1 = bf16 MFMA kernel (dtype must be bf16)
+//   cu (impl 1, S <= 128): packed rows -- sample b owns rows cu[b] .. cu[b+1]-1 of qkv / out (its first cu[b+1]-cu[b]
+//   positions; the rest of its S positions do not exist); key_mask keeps its [B, S] layout
 hipError_t launch_attention(const void* qkv, void* out, int dtype, int B, int S, int H, int causal,
-                            const int64_t* key_mask, int impl, hipStream_t s);
+                            const int64_t* key_mask, int impl, hipStream_t s, const int* cu = nullptr);
+
+// Packed captions (text tower, opt-in): a causal tower's pooled output depends on rows 0 .. EOS only, so the rows past a
+// caption's EOS token need not exist.  One workgroup: len[b] = eos_position(ids[b]) + 1, cu = exclusive prefix sums
+// [B+1], rowmap[r] = (b << 8) | t for packed row r (S <= 256), *m_dev = cu[B] = live rows.
+hipError_t launch_text_pack(const int64_t* ids, int B, int S, int eos_id, int* cu, int* rowmap, int* m_dev, hipStream_t s);
+// token + position embedding of the packed rows (split planes + statistics partials, as launch_text_embed_emit)
+hipError_t launch_text_embed_emit_packed(const int64_t* ids, const float* tok, const float* pos, void* hi, void* lo, float* st,
+                                         const int* rowmap, const int* m_dev, int max_rows, int S, int D, int vocab,
+                                         hipStream_t s);
 
 }  // namespace plipmi

@@ -642,12 +642,14 @@ __device__ __forceinline__ int eos_position(const int64_t* row, int S, int eos_i
 __global__ __launch_bounds__(256) void pool_gather_kernel(const bf16_t* __restrict__ att, const unsigned short* __restrict__ hi,
                                                           const unsigned short* __restrict__ lo, int S, int D,
                                                           const int64_t* __restrict__ ids, int eos_id, bf16_t* __restrict__ attp,
-                                                          float* __restrict__ xp, int B) {
+                                                          float* __restrict__ xp, int B, const int* __restrict__ cu) {
   const int lane = threadIdx.x & 63;
   const int smp = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (smp >= B) return;
-  const int pos = ids ? eos_position(ids + (size_t)smp * S, S, eos_id, lane) : 0;
-  const size_t src = ((size_t)smp * S + pos) * D, dst = (size_t)smp * D;
+  size_t row;
+  if (cu) row = (size_t)cu[smp + 1] - 1;      // packed captions end at their EOS row
+  else row = (size_t)smp * S + (ids ? eos_position(ids + (size_t)smp * S, S, eos_id, lane) : 0);
+  const size_t src = row * D, dst = (size_t)smp * D;
   for (int i = lane * 8; i < D; i += 512) {     // D % 8 == 0 (widths are multiples of 128)
     *reinterpret_cast<u32x4_t*>(attp + dst + i) = *reinterpret_cast<const u32x4_t*>(att + src + i);
     *reinterpret_cast<float4*>(xp + dst + i) = load4_split(hi + src + i, lo + src + i);
@@ -655,11 +657,96 @@ __global__ __launch_bounds__(256) void pool_gather_kernel(const bf16_t* __restri
   }
 }
 hipError_t launch_pool_gather(const void* att, const void* hi, const void* lo, int S, int D, const int64_t* ids, int eos_id,
-                              void* attp, float* xp, int B, hipStream_t s) {
+                              void* attp, float* xp, int B, hipStream_t s, const int* cu) {
   if (B <= 0) return hipSuccess;
   if (D % 8) return hipErrorInvalidValue;
   hipLaunchKernelGGL(pool_gather_kernel, dim3((B + 3) / 4), dim3(256), 0, s, (const bf16_t*)att, (const unsigned short*)hi,
-                     (const unsigned short*)lo, S, D, ids, eos_id, (bf16_t*)attp, xp, B);
+                     (const unsigned short*)lo, S, D, ids, eos_id, (bf16_t*)attp, xp, B, cu);
+  return hipGetLastError();
+}
+
+// Packed captions: lengths (EOS position + 1), their exclusive prefix sums, the packed-row -> (sample, position) map and
+// the live-row count, all on the device (nothing of it is known to the host: no synchronisation, graph-capturable).
+// One workgroup of 16 waves; B and S are small (B <= max_batch, S <= 256).
+__global__ __launch_bounds__(1024) void text_pack_kernel(const int64_t* __restrict__ ids, int B, int S, int eos_id,
+                                                         int* __restrict__ cu, int* __restrict__ rowmap, int* __restrict__ m_dev) {
+  extern __shared__ int len_s[];              // [B + 1]: lengths, then (in place) exclusive prefix sums
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for (int b = wave; b < B; b += nw) {
+    const int pos = eos_position(ids + (size_t)b * S, S, eos_id, lane);
+    if (lane == 0) len_s[b] = pos + 1;
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {                      // wave 0: chunked scan, 64 samples per step
+    int carry = 0;
+    for (int b0 = 0; b0 < B; b0 += 64) {
+      const int v = b0 + lane < B ? len_s[b0 + lane] : 0;
+      int inc = v;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int u = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += u;
+      }
+      if (b0 + lane < B) len_s[b0 + lane] = carry + inc - v;
+      carry += __shfl(inc, 63, 64);
+    }
+    if (lane == 0) { len_s[B] = carry; *m_dev = carry; }
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b <= B; b += blockDim.x) cu[b] = len_s[b];
+  for (int b = wave; b < B; b += nw) {
+    const int r0 = len_s[b], n = len_s[b + 1] - r0;
+    for (int t = lane; t < n; t += 64) rowmap[r0 + t] = (b << 8) | t;
+  }
+}
+hipError_t launch_text_pack(const int64_t* ids, int B, int S, int eos_id, int* cu, int* rowmap, int* m_dev, hipStream_t s) {
+  if (B <= 0) return hipSuccess;
+  if (S > 256 || B > (1 << 22)) return hipErrorInvalidValue;
+  const size_t lds = (size_t)(B + 1) * sizeof(int);
+  if (lds > 64 * 1024) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(text_pack_kernel, dim3(1), dim3(1024), lds, s, ids, B, S, eos_id, cu, rowmap, m_dev);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void text_embed_emit_packed_kernel(const int64_t* __restrict__ ids, const float* __restrict__ tok,
+                                                                     const float* __restrict__ pos, unsigned short* __restrict__ hi,
+                                                                     unsigned short* __restrict__ lo, float* __restrict__ st,
+                                                                     const int* __restrict__ rowmap, const int* __restrict__ m_dev,
+                                                                     int S, int D, int vocab) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= *m_dev) return;                  // wave-uniform
+  const int bt = rowmap[row], b = bt >> 8, tpos = bt & 255;
+  long long id = ids[(size_t)b * S + tpos];
+  id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+  const float* t = tok + (size_t)id * D;
+  const float* p = pos + (size_t)tpos * D;
+  const int ns = D / kLnSlice;
+  for (int c0 = 0; c0 < D; c0 += 256) {
+    const int idx = c0 + lane * 4;
+    const bool live = idx < D;
+    float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live) {
+      const float4 a = *reinterpret_cast<const float4*>(t + idx), c = *reinterpret_cast<const float4*>(p + idx);
+      y = make_float4(a.x + c.x, a.y + c.y, a.z + c.z, a.w + c.w);
+    }
+    const float ssum = row16_sum((y.x + y.y) + (y.z + y.w));
+    const float mj = ssum * (1.0f / kLnSlice);
+    const float d0 = y.x - mj, d1 = y.y - mj, d2 = y.z - mj, d3 = y.w - mj;
+    const float m2 = row16_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
+    if (live) {
+      store4_split(hi + (size_t)row * D + idx, lo + (size_t)row * D + idx, y.x, y.y, y.z, y.w);
+      if ((lane & 15) == 0) *reinterpret_cast<float2*>(st + ((size_t)row * ns + idx / kLnSlice) * 2) = make_float2(ssum, m2);
+    }
+  }
+}
+hipError_t launch_text_embed_emit_packed(const int64_t* ids, const float* tok, const float* pos, void* hi, void* lo, float* st,
+                                         const int* rowmap, const int* m_dev, int max_rows, int S, int D, int vocab,
+                                         hipStream_t s) {
+  if (max_rows <= 0) return hipSuccess;
+  if (D % kLnSlice || S > 256) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(text_embed_emit_packed_kernel, dim3((max_rows + 3) / 4), dim3(256), 0, s, ids, tok, pos,
+                     (unsigned short*)hi, (unsigned short*)lo, st, rowmap, m_dev, S, D, vocab);
   return hipGetLastError();
 }
 

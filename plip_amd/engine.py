@@ -179,6 +179,11 @@ class Engine:
         """Batches of at most ``max_batch`` samples replay a captured hipGraph (0 = always launch eagerly)."""
         _lib.check(self.lib.plipmi_set_graph_batch(self._h, int(max_batch)), "plipmi_set_graph_batch")
 
+    def set_text_packing(self, on: bool):
+        """Captions packed to their live rows (0 .. EOS): bit-identical text_embeds, cost proportional to the caption
+        lengths instead of the padded 77 (include/plipmi.h plipmi_set_text_packing).  Off by default."""
+        _lib.check(self.lib.plipmi_set_text_packing(self._h, int(bool(on))), "plipmi_set_text_packing")
+
     def _set_policy(self, policy: int):
         _lib.check(self.lib.plipmi_set_gemm_policy(self._h, int(policy)), "plipmi_set_gemm_policy")
 

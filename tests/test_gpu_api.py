@@ -327,3 +327,67 @@ def test_small_batch_graph_replay_is_bit_identical(dtype, engines):
     big = torch.from_numpy(px)
     assert torch.equal(eng.encode_image(big), eng.encode_image(big))
     eng.set_graph_batch(32)
+
+
+@pytest.mark.parametrize("case,max_batch", [("tiny_b6", 32), ("vitb32_b4", 32), ("vitb32_b4", 256)])
+def test_packed_captions_are_bit_identical(case, max_batch, engines):
+    """plipmi_set_text_packing: the text tower runs on rows 0 .. EOS of every caption only (causal attention + EOS pooling:
+    the padding behind EOS cannot reach text_embeds).  Lengths, row offsets and the live-row count never leave the device.
+    The embeddings must equal the padded computation BIT FOR BIT -- for both EOS rules (modeling_clip.py:561-581), both
+    padding conventions (HF: EOS, OpenAI clip.tokenize: 0), with and without the tokenizer's mask, for captions of one
+    token and of the full context, and when a captured graph is replayed on captions of other lengths."""
+    from plip_amd import weights as W
+    model, cfg, sd, px, ids0, mask0 = engines(case, "bf16", max_batch)
+    eng = model.engine
+    S = cfg.context_length
+    B = 256 if max_batch == 256 else 8
+    sets = []
+    for seed, pad in ((11, "eos"), (12, "zero"), (13, "eos")):
+        ids, mask = W.synthetic_ids(cfg, B, seed=seed, pad=pad)
+        sets.append((ids, mask))
+    # hand-made edge rows: EOS right after BOS, EOS in the last position, no EOS at all (explicit rule pools row 0)
+    ids, mask = W.synthetic_ids(cfg, B, seed=14)
+    ids[0, :] = cfg.eos_token_id; ids[0, 0] = cfg.bos_token_id; mask[0, :] = 0; mask[0, :2] = 1
+    ids[1, 1:S - 1] = 5; ids[1, S - 1] = cfg.eos_token_id; mask[1, :] = 1
+    if B > 2:
+        ids[2, 1:] = 7; mask[2, :] = 1
+    sets.append((ids, mask))
+    try:
+        for gb in (0, 32):
+            eng.set_graph_batch(gb)
+            for rule in (None, -1):                               # config's eos_token_id / the legacy argmax rule
+                want = []
+                eng.set_text_packing(False)
+                for ids, mask in sets:
+                    t, m = torch.from_numpy(ids), torch.from_numpy(mask)
+                    want.append((eng.encode_text(t, m, True, eos_token_id=rule).clone(),
+                                 eng.encode_text(t, None, False, eos_token_id=rule).clone()))
+                eng.set_text_packing(True)
+                for (ids, mask), (w_mask, w_plain) in zip(sets, want):
+                    t, m = torch.from_numpy(ids), torch.from_numpy(mask)
+                    g_mask = eng.encode_text(t, m, True, eos_token_id=rule)
+                    g_plain = eng.encode_text(t, None, False, eos_token_id=rule)
+                    torch.cuda.synchronize()
+                    assert torch.isfinite(g_mask).all() and torch.isfinite(g_plain).all()
+                    assert torch.equal(g_mask, w_mask), (case, gb, rule)
+                    assert torch.equal(g_plain, w_plain), (case, gb, rule)
+        # both towers of a step on two streams, as bench.py times them
+        ids, mask = sets[0]
+        eng.set_text_packing(False)
+        i0, t0 = eng.encode_pair(torch.from_numpy(px[:B] if len(px) >= B else np.resize(px, (B,) + px.shape[1:])),
+                                 torch.from_numpy(ids), torch.from_numpy(mask), True, overlap=True)
+        eng.set_text_packing(True)
+        i1, t1 = eng.encode_pair(torch.from_numpy(px[:B] if len(px) >= B else np.resize(px, (B,) + px.shape[1:])),
+                                 torch.from_numpy(ids), torch.from_numpy(mask), True, overlap=True)
+        torch.cuda.synchronize()
+        assert torch.equal(i0, i1) and torch.equal(t0, t1)
+    finally:
+        eng.set_text_packing(False)
+        eng.set_graph_batch(32)
+
+
+def test_text_packing_needs_the_pooled_bf16_engine(engines):
+    model, *_ = engines("tiny_b6", "f32")
+    with pytest.raises(RuntimeError):
+        model.engine.set_text_packing(True)
+    model.engine.set_text_packing(False)                         # switching it off is always allowed

@@ -276,6 +276,52 @@ def sec_prio():
     model.engine.close()
 
 
+def sec_fourstream():
+    """Experiment: the bs=256 step as FOUR independent chains (each tower's batch cut in two halves, on four HIP streams, two
+    handles sharing nothing) against the shipped two-stream arrangement -- does finer interleaving of kernels from
+    independent chains hide more of the GEMMs' prologue / epilogue phases?"""
+    cfg = get_config("ViT-B/32")
+    sd = W.synthetic_state_dict(cfg, 0)
+    B = 256
+    px = torch.from_numpy(W.synthetic_pixels(cfg, B, 1)).to(dev)
+    ids_np, mask_np = W.synthetic_ids(cfg, B, 2)
+    ids, mask = torch.from_numpy(ids_np).to(dev), torch.from_numpy(mask_np).to(dev)
+    mA = PlipModel(cfg, sd, dtype="bf16", max_batch=B)
+    mB = PlipModel(cfg, sd, dtype="bf16", max_batch=B)
+    s1, s2 = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    h = B // 2
+
+    def two():
+        return mA.engine.encode_pair(px, ids, mask, True, overlap=True)
+
+    def four():
+        main = torch.cuda.current_stream(dev)
+        s1.wait_stream(main); s2.wait_stream(main)
+        with torch.cuda.stream(s1):
+            a = mA.engine.encode_pair(px[:h], ids[:h], mask[:h], True, overlap=True)
+        with torch.cuda.stream(s2):
+            b = mB.engine.encode_pair(px[h:], ids[h:], mask[h:], True, overlap=True)
+        main.wait_stream(s1); main.wait_stream(s2)
+        return a, b
+
+    ia, ta = two()
+    (i1, t1), (i2, t2) = four()
+    torch.cuda.synchronize()
+    print("four-chain vs two-stream embeddings max diff", (torch.cat([i1, i2]) - ia).abs().max().item(), (torch.cat([t1, t2]) - ta).abs().max().item())
+    res = {"two": [], "four": []}
+    for rep in range(5):
+        for name, fn in (("two", two), ("four", four)):
+            ms = _time(fn, iters=10, warm=2)
+            if rep:
+                res[name].append(ms)
+    for name in res:
+        print(f"{name:5s} streams/chains: both towers {np.median(res[name]):6.3f} ms (min {min(res[name]):6.3f})")
+    for pol in (0, 3):
+        mA.engine.pair_policy = pol; mB.engine.pair_policy = pol
+        print(f"  four chains, tile policy {pol}: {_time(four, iters=10, warm=2):6.3f} ms")
+    mA.engine.close(); mB.engine.close()
+
+
 def sec_libgemm():
     """Calibration only (never used by the product): what the vendor GEMM library (hipBLASLt/rocBLAS behind
     torch.nn.functional.linear) reaches on the production shapes -- an external yardstick for gemm_nt."""
@@ -609,6 +655,6 @@ def sec_e2e():
 
 if __name__ == "__main__":
     t0 = time.time()
-    {"gemm": sec_gemm, "attn": sec_attn, "tiny": sec_tiny, "vitb32": sec_vitb32, "gemmbench": sec_gemmbench, "lnbench": sec_lnbench, "latency": sec_latency, "prio": sec_prio, "libgemm": sec_libgemm, "fp8": sec_fp8, "fp8w": sec_fp8w, "towerswap": sec_towerswap, "e2e": sec_e2e, "gemmone": sec_gemmone, "policy": sec_policy, "ldpad": sec_ldpad, "gemmtrace": sec_gemmtrace,
+    {"gemm": sec_gemm, "attn": sec_attn, "tiny": sec_tiny, "vitb32": sec_vitb32, "gemmbench": sec_gemmbench, "lnbench": sec_lnbench, "latency": sec_latency, "prio": sec_prio, "fourstream": sec_fourstream, "libgemm": sec_libgemm, "fp8": sec_fp8, "fp8w": sec_fp8w, "towerswap": sec_towerswap, "e2e": sec_e2e, "gemmone": sec_gemmone, "policy": sec_policy, "ldpad": sec_ldpad, "gemmtrace": sec_gemmtrace,
      "overlap": sec_overlap}[sys.argv[1]]()
     print(f"[{sys.argv[1]} done in {time.time() - t0:.1f} s]")
