@@ -66,6 +66,14 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 
+// the same over the 8 lanes of a half row (lanes 8h .. 8h+7)
+__device__ __forceinline__ float row8_sum(float v) {
+  v += dpp_mov<0xB1>(v);
+  v += dpp_mov<0x4E>(v);
+  v += dpp_mov<0x141>(v);
+  return v;
+}
+
 // LayerNorm statistics travel as per-row PARTIALS over 64-column slices: {sum, M2 = sum (x - sum/64)^2}.  Folding
 // NS slices with Chan's update gives the row mean and the (biased) variance without ever forming E[x^2] - mean^2.
 // The LayerNorm-folded bf16 engine keeps its fp32 residual stream as two 16-bit planes: hi = the value rounded to bf16

@@ -469,6 +469,21 @@ void gemm_nt_kernel(const GemmParams p) {
   float4 add[kAddBufs][NI / 2][8];
   bool add_ready = false;
   auto load_block = [&](int i, float4 (&dst)[NI / 2][8]) {
+    if constexpr (EPI == EPI_RESID_SPLIT) {
+      // the residual planes in 16-byte pieces: a lane owns 8 consecutive columns of a row (8 lanes = one 64-column slice),
+      // 8 rows per pass; dst[jp][2*it] = hi piece (8 bf16), dst[jp][2*it+1] = lo piece (8 int16), raw
+#pragma unroll
+      for (int jp = 0; jp < NI / 2; ++jp)
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          int m = m0 + wm * TM + i * 32 + it * 8 + (lane >> 3);
+          m = m < Mrt ? m : Mrt - 1;
+          const size_t off = (size_t)m * p.ldc + n0 + wn * TN + jp * 64 + (lane & 7) * 8;
+          dst[jp][2 * it] = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned short*>(p.xb_out) + off);
+          dst[jp][2 * it + 1] = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned short*>(p.lo_io) + off);
+        }
+      return;
+    }
 #pragma unroll
     for (int jp = 0; jp < NI / 2; ++jp)
 #pragma unroll
@@ -805,6 +820,60 @@ void gemm_nt_kernel(const GemmParams p) {
           *reinterpret_cast<f32x4*>(slab + lrow * SLAB_PITCH + (jj * 32 + 8 * q + 4 * lgrp) * 4) = v;
         }
       __builtin_amdgcn_wave_barrier();  // LDS ops of one wave execute in order; keep the compiler from reordering
+      if constexpr (EPI == EPI_RESID_SPLIT) {
+        // 8 columns per lane, 8 rows per pass: every global access of the two planes is a full 16-byte piece
+        const int r8 = lane >> 3, c8 = (lane & 7) * 8;
+        const int nn = n0 + wn * TN + jp * 64 + c8;
+        const float4 b0 = *reinterpret_cast<const float4*>(p.bias + nn), b1 = *reinterpret_cast<const float4*>(p.bias + nn + 4);
+        f32x4 va[4], vb[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          va[it] = *reinterpret_cast<const f32x4*>(slab + (it * 8 + r8) * SLAB_PITCH + c8 * 4);
+          vb[it] = *reinterpret_cast<const f32x4*>(slab + (it * 8 + r8) * SLAB_PITCH + c8 * 4 + 16);
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int m = m0 + wm * TM + i * 32 + it * 8 + r8;
+          const bool in_range = m < Mrt;
+          const u32x4 h = __builtin_bit_cast(u32x4, add[kAddBufs == 2 ? (i & 1) : 0][jp][2 * it]);
+          const u32x4 l = __builtin_bit_cast(u32x4, add[kAddBufs == 2 ? (i & 1) : 0][jp][2 * it + 1]);
+          float o[8];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            o[2 * e] = join_f32(h[e] & 0xffffu, l[e] & 0xffffu);
+            o[2 * e + 1] = join_f32(h[e] >> 16, l[e] >> 16);
+          }
+          // (residual + bias) + product: the order of the plain-array epilogues, so the stream is bit-identical to theirs
+          o[0] = (o[0] + b0.x) + va[it][0]; o[1] = (o[1] + b0.y) + va[it][1]; o[2] = (o[2] + b0.z) + va[it][2];
+          o[3] = (o[3] + b0.w) + va[it][3]; o[4] = (o[4] + b1.x) + vb[it][0]; o[5] = (o[5] + b1.y) + vb[it][1];
+          o[6] = (o[6] + b1.z) + vb[it][2]; o[7] = (o[7] + b1.w) + vb[it][3];
+          const float ssum = row8_sum(((o[0] + o[1]) + (o[2] + o[3])) + ((o[4] + o[5]) + (o[6] + o[7])));
+          const float mj = ssum * (1.0f / kLnSlice);
+          float q2 = 0.f;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { const float d = o[e] - mj; q2 = fmaf(d, d, q2); }
+          const float m2 = row8_sum(q2);
+          if (in_range) {
+            u32x4 ho, lo4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              unsigned ha, la, hb, lb;
+              split_f32(o[2 * e], ha, la);
+              split_f32(o[2 * e + 1], hb, lb);
+              ho[e] = ha | (hb << 16);
+              lo4[e] = la | (lb << 16);
+            }
+            const size_t off = (size_t)m * p.ldc + nn;
+            *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(p.xb_out) + off) = ho;
+            *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(p.lo_io) + off) = lo4;
+            if ((lane & 7) == 0)
+              *reinterpret_cast<float2*>(p.st_out + ((size_t)m * (p.N / kLnSlice) + (n0 + wn * TN + jp * 64) / kLnSlice) * 2) =
+                  make_float2(ssum, m2);
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+        continue;
+      }
       const int n = n0 + wn * TN + jp * 64 + rd_col;
       f32x4 v[8];
 #pragma unroll
