@@ -25,13 +25,6 @@ namespace {
 
 constexpr int SK_BM = 32, SK_BN = 64, SK_PITCH = 68;   // floats per LDS row of a partial tile (272 B: conflict-free b128)
 
-__device__ __forceinline__ float row8_sum(float v) {    // sum over the 8 lanes 8r .. 8r+7, result in all of them
-  v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
-  v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
-  v += dpp_mov<0x141>(v);  // row_half_mirror: lane i <-> 7 - i inside each 8-lane half of a DPP row
-  return v;
-}
-
 template <int EPI, int NW, int NB>
 __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(const GemmParams p) {
   __shared__ __attribute__((aligned(16))) float part[NW][SK_BM][SK_PITCH];

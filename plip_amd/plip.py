@@ -67,11 +67,13 @@ def _uniform_u8_images(chunk, n_px):
 class PLIP:
     def __init__(self, model_name: str = None, auth_token=None, *, model: Optional[PlipModel] = None,
                  tokenizer: Optional[Callable] = None, tokenizer_dir: Optional[str] = None, dtype: str = "bf16",
-                 max_batch: int = 256, device: str = "cuda:0"):
+                 max_batch: int = 256, device: str = "cuda:0", pack_captions: bool = False):
         """``model_name``: local HF directory (what ``CLIPModel/CLIPProcessor.from_pretrained`` take, plip.py:26-27)
         or an OpenAI-clip ``.pt`` state dict.  The tokenizer comes from ``tokenizer`` (a callable), else from
         ``tokenizer_dir`` / the model directory when it holds ``vocab.json`` + ``merges.txt``; with neither,
-        ``encode_text`` still takes token ids."""
+        ``encode_text`` still takes token ids.  ``pack_captions`` (extension, bf16 engine): the text tower computes only
+        the positions up to each caption's EOS token -- bit-identical embeddings, cost proportional to the caption lengths
+        instead of the padded 77 (include/plipmi.h ``plipmi_set_text_packing``)."""
         if not torch.cuda.is_available():
             raise RuntimeError("plip_amd.PLIP needs an MI355X (ROCm) GPU; there is no CPU path")
         self.device = device
@@ -88,6 +90,8 @@ class PLIP:
         if model is None:
             model = PlipModel.from_pretrained(model_name, device=device, dtype=dtype, max_batch=max_batch)
         self.model = model.to(self.device)
+        if pack_captions:
+            self.model.engine.set_text_packing(True)
         self.tokenizer = tokenizer
         self.model_hash = hash            # the reference returns the builtin too (plip.py:29)
         self.image_vectors = None
