@@ -13,7 +13,7 @@ import re
 import sys
 
 EPI = {"0": "bias", "1": "bias_qgelu", "2": "bias_resid", "3": "scale", "4": "patch", "5": "ln_bias", "6": "ln_qgelu",
-       "7": "resid_emit"}
+       "7": "resid_emit", "8": "resid_split"}
 
 
 def pretty(sym, variants):
