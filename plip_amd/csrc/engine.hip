@@ -898,7 +898,6 @@ int plipmi_gemm_nt_ln(int mode, int variant, int M, int N, int K, const void* A,
   p.xb_out = xb_out; p.st_out = st_out;
   if (mode == 3) { p.lo_io = C; p.C = nullptr; }
   const int epi = mode == 0 ? EPI_BIAS_LN : mode == 1 ? EPI_QGELU_LN : mode == 2 ? EPI_RESID_EMIT : EPI_RESID_SPLIT;
-  { static int ab = -1; if (ab < 0) { const char* ev = getenv("PLIPMI_GEMM_ABLATE"); ab = ev ? atoi(ev) : 0; } p.ablate = ab; }   // test hook only
   const int rc = variant == -3 ? gemm_launch_skinny(epi, p, reinterpret_cast<hipStream_t>(stream), nullptr)
                                : gemm_launch(PLIPMI_BF16, epi, variant, p, reinterpret_cast<hipStream_t>(stream), nullptr);
   if (rc != 0) return fail(PLIPMI_ERR_HIP, "gemm launch failed (LN mode %d, variant %d, M=%d N=%d K=%d): %s", mode, variant, M, N, K,

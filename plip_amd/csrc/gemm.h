@@ -208,10 +208,7 @@ struct EpilogueOp {
     if constexpr (epi_is_colwise(EPI)) {
       return *reinterpret_cast<const float4*>(p.bias + n0);
     } else if constexpr (EPI == EPI_RESID_SPLIT) {
-      const float4 b = *reinterpret_cast<const float4*>(p.bias + n0);
-      const float4 r = load4_split(reinterpret_cast<const unsigned short*>(p.xb_out) + (size_t)m * p.ldc + n0,
-                                   reinterpret_cast<const unsigned short*>(p.lo_io) + (size_t)m * p.ldc + n0);
-      return make_float4(r.x + b.x, r.y + b.y, r.z + b.z, r.w + b.w);
+      return make_float4(0.f, 0.f, 0.f, 0.f);   // the split-plane epilogue loads its planes itself (16-byte pieces)
     } else if constexpr (epi_is_resid(EPI)) {
       const float4 b = *reinterpret_cast<const float4*>(p.bias + n0);
       const float4 r = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.C) + (size_t)m * p.ldc + n0);
@@ -482,15 +479,15 @@ void gemm_nt_kernel(const GemmParams p) {
           dst[jp][2 * it] = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned short*>(p.xb_out) + off);
           dst[jp][2 * it + 1] = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned short*>(p.lo_io) + off);
         }
-      return;
+    } else {
+#pragma unroll
+      for (int jp = 0; jp < NI / 2; ++jp)
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+          const int m = m0 + wm * TM + i * 32 + it * 4 + rd_row;
+          dst[jp][it] = EpilogueOp<T, EPI>::load(p, m < Mrt ? m : Mrt - 1, n0 + wn * TN + jp * 64 + rd_col);
+        }
     }
-#pragma unroll
-    for (int jp = 0; jp < NI / 2; ++jp)
-#pragma unroll
-      for (int it = 0; it < 8; ++it) {
-        const int m = m0 + wm * TM + i * 32 + it * 4 + rd_row;
-        dst[jp][it] = EpilogueOp<T, EPI>::load(p, m < Mrt ? m : Mrt - 1, n0 + wn * TN + jp * 64 + rd_col);
-      }
   };
 
   auto compute = [&](int buf, int fill_buf) {
@@ -884,28 +881,20 @@ void gemm_nt_kernel(const GemmParams p) {
         int m = m0 + wm * TM + i * 32 + it * 4 + rd_row;
         const bool in_range = m < Mrt;
         if (p.ablate & 32) m &= 255;  // timeline experiment: every tile stores to the same 256 rows (L2-resident)
-        if constexpr (epi_emits_stats(EPI)) {
+        if constexpr (EPI == EPI_RESID_EMIT) {
           // the updated residual row piece (4 columns per lane, 16 lanes = one 64-column slice of one row): fp32 in
-          // place + its bf16 copy for the next GEMM's A operand (EMIT), or the two 16-bit planes of the fp32 value (SPLIT);
-          // and the slice's LayerNorm partials {sum, centred M2}
+          // place, its bf16 copy for the next GEMM's A operand, and the slice's LayerNorm partials {sum, centred M2}
+          // (EPI_RESID_SPLIT has its own block above)
           const float4 a4 = add[kAddBufs == 2 ? (i & 1) : 0][jp][it];
           const float o0 = a4.x + v[it][0], o1 = a4.y + v[it][1], o2 = a4.z + v[it][2], o3 = a4.w + v[it][3];
-          float ssum = 0.f, m2 = 0.f;
-          if (!(p.ablate & 128)) {   // (test hook: bit 7 skips the statistics, bit 6 the bf16 copy)
-            ssum = row16_sum((o0 + o1) + (o2 + o3));
-            const float mj = ssum * (1.0f / kLnSlice);
-            const float d0 = o0 - mj, d1 = o1 - mj, d2 = o2 - mj, d3 = o3 - mj;
-            m2 = row16_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
-          }
+          const float ssum = row16_sum((o0 + o1) + (o2 + o3));
+          const float mj = ssum * (1.0f / kLnSlice);
+          const float d0 = o0 - mj, d1 = o1 - mj, d2 = o2 - mj, d3 = o3 - mj;
+          const float m2 = row16_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
           if (in_range) {
-            if constexpr (EPI == EPI_RESID_SPLIT) {
-              store4_split(reinterpret_cast<unsigned short*>(p.xb_out) + (size_t)m * p.ldc + n,
-                           reinterpret_cast<unsigned short*>(p.lo_io) + (size_t)m * p.ldc + n, o0, o1, o2, o3);
-            } else {
-              store4(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n, o0, o1, o2, o3);
-              if (!(p.ablate & 64)) store4(reinterpret_cast<bf16_t*>(p.xb_out) + (size_t)m * p.ldc + n, o0, o1, o2, o3);
-            }
-            if ((lane & 15) == 0 && !(p.ablate & 128))
+            store4(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n, o0, o1, o2, o3);
+            store4(reinterpret_cast<bf16_t*>(p.xb_out) + (size_t)m * p.ldc + n, o0, o1, o2, o3);
+            if ((lane & 15) == 0)
               *reinterpret_cast<float2*>(p.st_out + ((size_t)m * (p.N / kLnSlice) + (n0 + wn * TN + jp * 64) / kLnSlice) * 2) =
                   make_float2(ssum, m2);
           }

@@ -391,3 +391,17 @@ def test_text_packing_needs_the_pooled_bf16_engine(engines):
     with pytest.raises(RuntimeError):
         model.engine.set_text_packing(True)
     model.engine.set_text_packing(False)                         # switching it off is always allowed
+
+
+def test_plip_class_pack_captions_is_bit_identical(engines):
+    """PLIP(..., pack_captions=True) (extension of plip.py:17-29): same text embeddings as the padded engine, bit for bit,
+    through the reference's own encode_text flow (tokenise -> batches -> get_text_features)."""
+    from plip_amd.plip import PLIP
+    model, cfg, sd, px, ids, mask = engines("tiny_b6", "bf16")
+    texts = ["an h&e image of tumor", "lymphocytes", "a", "normal colon mucosa with crypts and goblet cells " * 3]
+    try:
+        want = PLIP(model=model, tokenizer=fake_tokenizer(cfg)).encode_text(texts, batch_size=3)
+        got = PLIP(model=model, tokenizer=fake_tokenizer(cfg), pack_captions=True).encode_text(texts, batch_size=3)
+    finally:
+        model.engine.set_text_packing(False)
+    assert np.array_equal(np.asarray(want), np.asarray(got))

@@ -51,8 +51,6 @@ for s in $SECTIONS; do
              done; done
              python tools/pmc_table.py gpurun_out/pmcstep_1 gpurun_out/pmcstep_2 gpurun_out/pmc_bench_FETCH_SIZE_ov0 gpurun_out/pmc_bench_WRITE_SIZE_ov0 > gpurun_out/pmc_step_counters.txt 2>> gpurun_out/pmcstep.log
              python tools/pmc_summary.py gpurun_out/pmc_bench_FETCH_SIZE_ov0 gpurun_out/pmc_bench_WRITE_SIZE_ov0 gpurun_out/pmc_bench_FETCH_SIZE_ov1 gpurun_out/pmc_bench_WRITE_SIZE_ov1 > gpurun_out/pmc_traffic.json 2>> gpurun_out/pmcstep.log ;;
-    emitablate) for ab in 0 64 128 192; do echo "=== PLIPMI_GEMM_ABLATE=$ab (64: no bf16 copy, 128: no statistics)" >> gpurun_out/diag_emitablate.log
-               PLIPMI_GEMM_ABLATE=$ab timeout 120 python tools/gpu_diag.py lnbench 2>&1 | grep -E "out|fc2" >> gpurun_out/diag_emitablate.log; done ;;
     config3) timeout 900 python tools/config3_shard.py > gpurun_out/config3_shard.json 2> gpurun_out/config3_shard.err ;;
     smoke)   timeout 600 python __graft_entry__.py --smoke > gpurun_out/smoke.log 2>&1 ;;
     *)       timeout 600 python tools/gpu_diag.py $s > gpurun_out/diag_$s.log 2>&1 ;;
