@@ -234,7 +234,8 @@ int plipmi_set_gemm_policy(plipmi_handle h, int policy);
 int plipmi_gemm_nt_ld(int dtype, int epilogue, int variant, int M, int N, int K, const void* A, int lda, const void* W,
                       int ldw, const float* bias, float alpha, void* C, void* stream);
 /* same call with an in-kernel timeline: trace = device buffer of 8 x uint64 per workgroup
- * {start, prologue done, main loop done, epilogue done (s_memtime ticks), tile id, HW_ID|XCC_ID<<32, k tiles, 0} */
+ * {start, prologue done, main loop done, epilogue done (s_memtime ticks: shader cycles, one counter per XCD), tile id,
+ *  HW_ID|XCC_ID<<32, k tiles, start (low 32 bits) | lifetime << 32 in s_memrealtime ticks (100 MHz, device-wide)} */
 int plipmi_gemm_nt_traced(int dtype, int epilogue, int variant, int M, int N, int K, const void* A, const void* W,
                           const float* bias, float alpha, void* C, uint64_t* trace, void* stream);
 

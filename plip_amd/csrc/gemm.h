@@ -595,8 +595,10 @@ void gemm_nt_kernel(const GemmParams p) {
   // ---- main loop: tile kt+1 streams in while tile kt is multiplied; one barrier per tile.
   const int KT = p.K / BK;
   unsigned long long* trace = p.trace ? p.trace + (size_t)bid * 8 : nullptr;
+  unsigned long long trace_real0 = 0;
   if (trace && tid == 0) {
     trace[0] = __builtin_amdgcn_s_memtime();
+    trace_real0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz, one counter for the whole device (s_memtime is per XCD)
     trace[4] = lid;
     trace[5] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4 /* HW_ID [31:0] */) |
                ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20 /* XCC_ID [3:0] */) << 32);
@@ -792,7 +794,10 @@ void gemm_nt_kernel(const GemmParams p) {
     }
     if (trace) {
       __builtin_amdgcn_s_waitcnt(0);
-      if (tid == 0) trace[3] = __builtin_amdgcn_s_memtime();
+      if (tid == 0) {
+        trace[3] = __builtin_amdgcn_s_memtime();
+        trace[7] = (trace_real0 & 0xffffffffull) | ((__builtin_amdgcn_s_memrealtime() - trace_real0) << 32);
+      }
     }
     return;
   }
@@ -907,7 +912,10 @@ void gemm_nt_kernel(const GemmParams p) {
   }
   if (trace) {
     __builtin_amdgcn_s_waitcnt(0);  // stores issued and acknowledged before the stamp
-    if (tid == 0) trace[3] = __builtin_amdgcn_s_memtime();
+    if (tid == 0) {
+      trace[3] = __builtin_amdgcn_s_memtime();
+      trace[7] = (trace_real0 & 0xffffffffull) | ((__builtin_amdgcn_s_memrealtime() - trace_real0) << 32);
+    }
   }
 }
 

@@ -510,31 +510,29 @@ def sec_gemmtrace():
     t = tr.cpu().numpy().reshape(nblk, 8).astype(np.int64)
     ms = e0.elapsed_time(e1)
     xcc = (t[:, 5] >> 32) & 0xF
-    # s_memtime is a per-XCD counter (not synchronised across XCDs): normalise per XCC
-    start = np.zeros(nblk, dtype=np.int64)
-    end = np.zeros(nblk, dtype=np.int64)
-    spans = []
-    for x in range(8):
-        m = xcc == x
-        if not m.any():
-            continue
-        t0 = t[m, 0].min()
-        start[m] = t[m, 0] - t0
-        end[m] = t[m, 3] - t0
-        spans.append(end[m].max())
-    pro, loop, epi_t = t[:, 1] - t[:, 0], t[:, 2] - t[:, 1], t[:, 3] - t[:, 2]
-    tick_us = float(np.median(spans)) / (ms * 1e3)          # ticks per microsecond, from the per-XCC span
+    # cycle stamps (s_memtime: shader cycles, one counter per XCD -> only differences inside a workgroup mean anything) and
+    # wall stamps (s_memrealtime: 100 MHz, one counter for the device -> start offsets and lifetimes in real time)
+    pro, loop, epi_t, life = t[:, 1] - t[:, 0], t[:, 2] - t[:, 1], t[:, 3] - t[:, 2], t[:, 3] - t[:, 0]
+    real0 = (t[:, 7] & 0xFFFFFFFF).astype(np.int64)
+    real_life_us = ((t[:, 7] >> 32) & 0xFFFFFFFF).astype(np.float64) / 100.0
+    start_us = ((real0 - real0.min()) & 0xFFFFFFFF).astype(np.float64) / 100.0
+    end_us = start_us + real_life_us
+    clk = life / np.maximum(real_life_us, 1e-9) / 1e3            # GHz, per workgroup
     print(f"variant {names[v]} {M}x{N}x{K} epi{epi}: {nblk} workgroups, kernel {ms * 1e3:.1f} us by events "
-          f"({2.0 * M * N * K / ms / 1e9:.0f} TFLOP/s); per-XCC spans {spans} ticks => ~{tick_us:.1f} ticks/us")
-    q = lambda x: (f"min {x.min() / tick_us:7.2f}  p50 {np.median(x) / tick_us:7.2f}  p90 {np.percentile(x, 90) / tick_us:7.2f}"
-                   f"  max {x.max() / tick_us:7.2f} us")
+          f"({2.0 * M * N * K / ms / 1e9:.0f} TFLOP/s); first start -> last end {end_us.max():.1f} us; "
+          f"shader clock while the workgroups ran: median {np.median(clk):.2f} GHz (min {clk.min():.2f}, max {clk.max():.2f})")
+    qc = lambda x: (f"min {x.min():8.0f}  p50 {np.median(x):8.0f}  p90 {np.percentile(x, 90):8.0f}  max {x.max():8.0f} cycles"
+                    f"  = p50 {np.median(x) / np.median(clk) / 1e3:6.2f} us at that clock")
+    qu = lambda x: f"min {x.min():7.2f}  p50 {np.median(x):7.2f}  p90 {np.percentile(x, 90):7.2f}  max {x.max():7.2f} us"
     kt = max(1, int(t[0, 6]) - 1)
-    print("  start offset :", q(start))
-    print("  prologue     :", q(pro))
-    print("  main loop    :", q(loop), f"  ({np.median(loop) / tick_us / kt * 1e3:.0f} ns = {np.median(loop) / kt:.0f} ticks per k-tile, {kt} tiles)")
-    print("  epilogue     :", q(epi_t))
-    print("  lifetime     :", q(t[:, 3] - t[:, 0]))
+    print("  start offset :", qu(start_us))
+    print("  prologue     :", qc(pro))
+    print("  main loop    :", qc(loop), f"  ({np.median(loop) / kt:.0f} cycles per k-tile, {kt} tiles)")
+    print("  epilogue     :", qc(epi_t))
+    print("  lifetime     :", qc(life), "  wall:", qu(real_life_us))
+    print("  end          :", qu(end_us))
     print("  workgroups per XCC:", np.bincount(xcc, minlength=8).tolist())
+    return
     m0 = xcc == 0
     first_end = end[m0].min()
     print(f"  XCC0: {m0.sum()} workgroups, {(start[m0] < first_end).sum()} started before its first one ended")
