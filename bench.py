@@ -29,7 +29,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}   # dense MFMA peaks, MI355X_MICROARCH.md "Chip-level parameters"
+PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}   # dense MFMA peaks, MI355X_MICROARCH.md "Chip-level parameters"
 
 
 def parse():
@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256, help="pairs per GPU per step")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--arch", default="ViT-B/32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="lower bound of CPU work for the baseline sample")
@@ -155,8 +155,7 @@ def executed_gflop_per_pair(cfg, args):
     afterwards (CLS / EOS) -- the other rows of that block cannot reach get_image_features / get_text_features -- so it
     executes slightly fewer FLOPs than that; kernel rooflines always use executed FLOPs."""
     full = cfg.pair_flops()
-    pooled = args.dtype == "bf16" and os.environ.get("PLIPMI_POOLED_LAST_BLOCK", "1") != "0" and \
-        os.environ.get("PLIPMI_LN_FOLD", "1") != "0"
+    pooled = args.dtype in ("bf16", "f16")
     saved = 0.0
     if pooled:
         for tokens, D, F in ((cfg.v_tokens, cfg.v_width, cfg.v_mlp), (cfg.context_length, cfg.t_width, cfg.t_mlp)):
@@ -373,12 +372,10 @@ def main():
         res["csrc_sha16"] = source_digest()
     except Exception:  # pragma: no cover
         pass
-    if world == 1 and not args.no_fp32_tower and args.dtype == "bf16" and res["executed_gflop_per_pair"]["pooled_last_block"]:
+    if world == 1 and not args.no_fp32_tower and args.dtype != "f32" and res["executed_gflop_per_pair"]["pooled_last_block"]:
         # A/B: the same step with the last block computed on EVERY token (as HF does), i.e. the dense 14.777 GFLOP per pair
         try:
-            os.environ["PLIPMI_POOLED_LAST_BLOCK"] = "0"
-            md = PlipModel(cfg, sd, device=dev, dtype=args.dtype, max_batch=B)
-            del os.environ["PLIPMI_POOLED_LAST_BLOCK"]
+            md = PlipModel(cfg, sd, device=dev, dtype=args.dtype, max_batch=B, pooled_last_block=False)
             for _ in range(args.warmup):
                 sharded_pair_logits(md, px, ids, mask, overlap=bool(args.overlap), equal_shards=True)
             torch.cuda.synchronize(dev)
@@ -388,16 +385,15 @@ def main():
             torch.cuda.synchronize(dev)
             dtd = (time.perf_counter() - t3) / args.steps
             res["dense_last_block"] = {
-                "note": "same step, PLIPMI_POOLED_LAST_BLOCK=0: the last block's out_proj / fc1 / fc2 on all tokens instead of the "
+                "note": "same step, an engine built with PLIPMI_FLAG_DENSE_LAST_BLOCK: the last block's out_proj / fc1 / fc2 on all tokens instead of the "
                         "pooled row only (identical embeddings up to fp32 summation order)",
                 "pairs_per_s": round(B / dtd, 1), "ms_per_step": round(dtd * 1e3, 3),
                 "max_abs_diff_of_logits_vs_pooled_path": float((od[0] - logits).abs().max())}
             md.engine.close()
             del md
         except Exception as e:  # pragma: no cover
-            os.environ.pop("PLIPMI_POOLED_LAST_BLOCK", None)
             res["dense_last_block"] = {"error": repr(e)}
-    if world == 1 and not args.no_fp32_tower and args.dtype == "bf16" and res["executed_gflop_per_pair"]["pooled_last_block"]:
+    if world == 1 and not args.no_fp32_tower and args.dtype != "f32" and res["executed_gflop_per_pair"]["pooled_last_block"]:
         # A/B, NOT the headline: the same step with the text tower on the captions' live rows only (plipmi_set_text_packing).
         # The headline above executes every padded position of the 77-token context, as the reference does.
         try:
@@ -422,7 +418,7 @@ def main():
             res["packed_captions"] = {"error": repr(e)}
         finally:
             model.engine.set_text_packing(False)
-    if world == 1 and not args.no_fp32_tower and args.dtype == "bf16":
+    if world == 1 and not args.no_fp32_tower and args.dtype != "f32":
         # BASELINE.json configs[1]: ViT-B/32 image tower only, bs=256, fp32 (exact-fp32 MFMA engine), same pixels
         try:
             m32 = PlipModel(cfg, sd, device=dev, dtype="f32", max_batch=B)

@@ -42,16 +42,28 @@
 extern "C" {
 #endif
 
-#define PLIPMI_VERSION 100 /* 0.1.0 */
+#define PLIPMI_VERSION 300 /* 0.3.0: plipmi_config grew `flags` and `graph_batch`; PLIPMI_F16; fp8-weights mode removed */
 
 /* arithmetic the towers' GEMMs and attention run in (accumulation, LayerNorm,
- * softmax statistics, residual stream, projections and logits are always fp32) */
-enum { PLIPMI_F32 = 0, PLIPMI_BF16 = 1,
-       /* EXPERIMENTAL (BASELINE configs[4] "fp8 MFMA weights"): the bf16 engine whose QKV and fc1 projections run on
-        * fp8 e4m3fn weights (one scale per output channel, fixed at plipmi_create) and fp8 LayerNorm rows (one dynamic
-        * scale per row) through v_mfma_scale_f32_32x32x64_f8f6f4; fp32 accumulation, everything else as PLIPMI_BF16.
-        * Not within the 1e-3 cosine bar (see tests/test_gpu_parity.py for the stated tolerance). */
-       PLIPMI_FP8W = 2 };
+ * softmax statistics, residual stream, projections and logits are always fp32):
+ *   PLIPMI_F32   exact fp32 MFMA (v_mfma_f32_32x32x2_f32)
+ *   PLIPMI_BF16  bf16 MFMA operands (8 significand bits)  -- BASELINE.json configs[2] as named
+ *   PLIPMI_F16   IEEE half MFMA operands (11 significand bits, +-65504; outputs saturate), same matrix-core rate as
+ *                bf16.  The reference's own GPU path runs its CLIP in this type (OpenAI clip.load on "cuda" ->
+ *                convert_weights: reproducibility/embedders/factory.py:21, scripts/extract_embedding.py:94-97).
+ * (The experimental fp8-weights mode of earlier versions, value 2, is gone: 2.7e-3 against the 1e-3 cosine bar.) */
+enum { PLIPMI_F32 = 0, PLIPMI_BF16 = 1, PLIPMI_F16 = 2 };
+
+/* plipmi_config.flags -- every switch of a handle's behaviour is an argument of plipmi_create (or a per-handle setter
+ * below); the library reads no environment variables for them */
+enum {
+  PLIPMI_FLAG_SEPARATE_LAYERNORM = 1,  /* 16-bit engines: run the 2 x L block LayerNorms as their own kernels instead
+                                        * of folding them into the q/k/v and fc1 GEMMs (A/B measurements) */
+  PLIPMI_FLAG_DENSE_LAST_BLOCK = 2,    /* compute the last block's out_proj / fc1 / fc2 on every token, as the reference
+                                        * does, instead of on the pooled row of each sample only */
+  PLIPMI_FLAG_PACK_CAPTIONS = 4,       /* start with caption packing on (plipmi_set_text_packing) */
+  PLIPMI_FLAG_VALU_ATTENTION = 8       /* exact-fp32 VALU attention kernel instead of the MFMA kernels (A/B measurements) */
+};
 
 /* towers, for plipmi_debug_hidden */
 enum { PLIPMI_VISION = 0, PLIPMI_TEXT = 1 };
@@ -83,8 +95,11 @@ typedef struct plipmi_config {
   int32_t t_mlp;           /* 2048 */
   int32_t projection_dim;  /* 512 */
   float   layer_norm_eps;  /* 1e-5 */
-  int32_t compute_dtype;   /* PLIPMI_F32 | PLIPMI_BF16 | PLIPMI_FP8W */
+  int32_t compute_dtype;   /* PLIPMI_F32 | PLIPMI_BF16 | PLIPMI_F16 */
   int32_t max_batch;       /* images (and captions) per encode call the workspace is sized for */
+  int32_t flags;           /* PLIPMI_FLAG_* bits, 0 = the product defaults */
+  int32_t graph_batch;     /* small-batch hipGraph replay: 0 = default (batches of <= min(32, max_batch) samples),
+                            * > 0 = that many, < 0 = never (plipmi_set_graph_batch changes it later) */
 } plipmi_config;
 
 /* One pre-LN transformer block, HF CLIPEncoderLayer naming; all DEVICE pointers
@@ -146,15 +161,22 @@ int plipmi_encode_image_u8(plipmi_handle h, const uint8_t* tiles, int B, float* 
 int plipmi_encode_text(plipmi_handle h, const int64_t* ids, const int64_t* attention_mask, int B,
                        int eos_token_id, float* out, int normalize, void* stream);
 
-/* Small-batch launch amortisation.  An encode call of at most `max_batch` samples (default min(32, cfg.max_batch);
- * environment PLIPMI_GRAPH_BATCH; 0 = never) replays a captured hipGraph of its ~170 kernel launches instead of issuing
+/* Token ids outside [0, vocab_size).  The reference's embedding lookup raises on them (plip.py:68 -> nn.Embedding; on a
+ * GPU as a device-side assert that surfaces at the next synchronisation).  plipmi_encode_text only enqueues work, so the
+ * ids -- device memory -- are checked BY the embedding kernel: it clamps the lookup (no wild read) and raises a flag in
+ * host-visible memory.  The flag is reported, once, by the next plipmi_encode_* call on the handle and by this function
+ * (call it after synchronising the stream; PLIPMI_ERR_INVALID = the embeddings of an earlier encode_text are invalid). */
+int plipmi_check_async(plipmi_handle h);
+
+/* Small-batch launch amortisation.  An encode call of at most `max_batch` samples (default min(32, cfg.max_batch), see
+ * plipmi_config.graph_batch; 0 = never) replays a captured hipGraph of its ~170 kernel launches instead of issuing
  * them one by one: the first call of a shape (tower, batch, normalise, pooling rule, mask present) runs eagerly, the
  * second captures on the caller's stream, later ones replay.  Inputs / outputs of a replay travel through handle-owned
  * staging buffers (two device-to-device copies per call), results are bit-identical to the eager path.  The reference's
  * zero_shot_classification runs both towers at batch 8 (plip.py:90-91), where the step is launch-bound. */
 int plipmi_set_graph_batch(plipmi_handle h, int max_batch);
 
-/* Caption packing (bf16 engine, off by default; environment PLIPMI_TEXT_PACKING=1).  CLIPTextTransformer is causal and
+/* Caption packing (16-bit engines, off by default; PLIPMI_FLAG_PACK_CAPTIONS starts with it on).  CLIPTextTransformer is causal and
  * pools the EOS row only (modeling_clip.py:543-581), so the positions behind a caption's EOS token -- the tokenizer's
  * padding to 77 -- cannot influence text_embeds; the reference computes them anyway.  With packing on, plipmi_encode_text
  * lays the captions' live rows (0 .. EOS) end to end and runs every kernel of the text tower on those rows only: lengths,
@@ -209,22 +231,23 @@ int plipmi_debug_hidden(plipmi_handle h, int tower, int layer, const void* input
 
 /* Kernel-level entry for unit tests and micro-benchmarks of the GEMM that carries
  * >98 % of the path's FLOPs:  C = epilogue(A[M,K] * W[N,K]^T).
- *   dtype    PLIPMI_F32 | PLIPMI_BF16 (A, W and non-fp32 outputs are that type; bf16 as raw uint16)
+ *   dtype    PLIPMI_F32 | PLIPMI_BF16 | PLIPMI_F16 (A, W and non-fp32 outputs are that type; 16-bit types as raw uint16)
  *   epilogue 0: C(dtype) = acc + bias        1: C(dtype) = quickgelu(acc + bias)
  *            2: C(f32) += acc + bias         3: C(f32)   = alpha * acc
  *   variant  -1 = the engine's own choice, >= 0 = a specific tile configuration
  *            (plipmi_gemm_variant_name lists them; NULL past the end);
  *            variant -2 = the naive one-thread-per-output checker kernel;
- *            variant -3 = the small-M split-K kernel (bf16; epilogues 0..2; N % 64 == 0, K % 256 == 0). */
+ *            variant -3 = the small-M split-K kernel (16-bit types; epilogues 0..2; N % 64 == 0, K % 256 == 0). */
 int plipmi_gemm_nt(int dtype, int epilogue, int variant, int M, int N, int K, const void* A, const void* W,
                    const float* bias, float alpha, void* C, void* stream);
 const char* plipmi_gemm_variant_name(int variant);
-/* 1 if this build of the library carries `variant` for `dtype` (the default build holds the product tiles only;
- * -DPLIPMI_ALL_VARIANTS adds the schedule experiments of round 1), else 0 */
+/* 1 if this build of the library carries `variant` for `dtype`, else 0 */
 int plipmi_gemm_variant_built(int dtype, int variant);
 /* TEST / A-B HOOK, process-wide, not used by the product path: force every GEMM onto one tile variant (>= 0), or back
  * to the engine's own choice (-1); the environment variable PLIPMI_GEMM_VARIANT sets the same thing at start-up */
 void plipmi_set_gemm_variant(int variant);
+/* TEST / A-B HOOK, process-wide: epilogue stores of every GEMM write through the XCD's L2 (1) or not (0) */
+void plipmi_set_gemm_store_wt(int on);
 /* Tile policy of ONE handle's own choice (per-handle state, like everything else behind a handle):
  * 0 = wave-quantisation cost model (its kernels own the GPU one at a time; the default),
  * 1..3 = the caller runs the handle's two towers on two streams (idle CUs are filled by the other tower, so the tile
@@ -239,23 +262,25 @@ int plipmi_gemm_nt_ld(int dtype, int epilogue, int variant, int M, int N, int K,
 int plipmi_gemm_nt_traced(int dtype, int epilogue, int variant, int M, int N, int K, const void* A, const void* W,
                           const float* bias, float alpha, void* C, uint64_t* trace, void* stream);
 
-/* Kernel-level entry for the LayerNorm-folded epilogues of the bf16 engine (gemm.h EPI_BIAS_LN / EPI_QGELU_LN /
- * EPI_RESID_EMIT; A, W bf16 as raw uint16):
- *   mode 0: C(bf16) = rstd[m] * A.W^T + bias[n]       rstd from `stats` [M, ns, 2] fp32 = per-64-column partials
- *   mode 1: C(bf16) = quickgelu(that)                 {sum, centred M2} of the LayerNorm input rows (D = 64 * ns), eps as
+/* Kernel-level entry for the LayerNorm-folded epilogues of the 16-bit engines (gemm.h EPI_BIAS_LN / EPI_QGELU_LN /
+ * EPI_RESID_EMIT / EPI_RESID_SPLIT; dtype PLIPMI_BF16 | PLIPMI_F16, A, W as raw uint16; "h16" below = that type):
+ *   mode 0: C(h16) = rstd[m] * A.W^T + bias[n]       rstd from `stats` [M, ns, 2] fp32 = per-64-column partials
+ *   mode 1: C(h16) = quickgelu(that)                 {sum, centred M2} of the LayerNorm input rows (D = 64 * ns), eps as
  *                                                     given; W is expected to carry LayerNorm's gain with CENTRED rows
  *                                                     (sum_k W[n,k] = 0), which is what subtracts the row mean
- *   mode 2: C(f32) += A.W^T + bias;  xb_out(bf16)[M,N] = C;  st_out [M, N/64, 2] = partials of the updated rows
- *   mode 3: the same update on a residual kept as two 16-bit planes, xb_out = hi (uint16: the value rounded to bf16,
- *           ties away from zero) and C = lo (int16), bits(x) == (hi << 16) + lo: both read and written in place;
+ *   mode 2: C(f32) += A.W^T + bias;  xb_out(h16)[M,N] = C;  st_out [M, N/64, 2] = partials of the updated rows
+ *   mode 3: the same update on a residual kept as two 16-bit planes, xb_out = hi (uint16: the value rounded to h16) and
+ *           C = lo (int16 remainder; bf16: bits(x) == (hi << 16) + lo, f16: x == hi + lo * 2^(E(hi) - 24)), an EXACT
+ *           fp32 value either way (plip_amd/csrc/common.h split_f32): both read and written in place;
  *           st_out as in mode 2.  This is the form the engine runs (an fp32 stream at 8 bytes per element of epilogue
  *           traffic, whose hi plane is the next GEMM's A operand) */
-int plipmi_gemm_nt_ln(int mode, int variant, int M, int N, int K, const void* A, const void* W, const float* bias,
+int plipmi_gemm_nt_ln(int dtype, int mode, int variant, int M, int N, int K, const void* A, const void* W, const float* bias,
                       const float* stats, int ns, float eps, void* C, void* xb_out, float* st_out, void* stream);
 
 /* Kernel-level entry for the attention kernels: out[B*S, H*64] = softmax(q k^T + masks) v over the fused
  * activation qkv [B*S, 3*H*64] (q | k | v, 1/sqrt(64) already folded into q).
- *   impl 0 = exact-fp32 VALU kernel (dtype f32 or bf16), impl 1 = bf16 MFMA kernel (S <= 128). */
+ *   impl 0 = exact-fp32 VALU kernel (any dtype), impl 1 = MFMA kernels (bf16 / f16; single pass for S <= 128, chunked
+ *   online softmax beyond). */
 int plipmi_attention(int dtype, int impl, const void* qkv, void* out, int B, int S, int H, int causal,
                      const int64_t* key_mask, void* stream);
 

@@ -8,7 +8,9 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libplipmi.so")
 
-F32, BF16, FP8W = 0, 1, 2
+F32, BF16, F16 = 0, 1, 2
+# plipmi_config.flags
+FLAG_SEPARATE_LAYERNORM, FLAG_DENSE_LAST_BLOCK, FLAG_PACK_CAPTIONS, FLAG_VALU_ATTENTION = 1, 2, 4, 8
 VISION, TEXT = 0, 1
 
 
@@ -16,7 +18,8 @@ class Config(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "image_size", "patch_size", "v_width", "v_layers", "v_heads", "v_mlp", "vocab_size",
         "context_length", "t_width", "t_layers", "t_heads", "t_mlp", "projection_dim")] + [
-        ("layer_norm_eps", C.c_float), ("compute_dtype", C.c_int32), ("max_batch", C.c_int32)]
+        ("layer_norm_eps", C.c_float), ("compute_dtype", C.c_int32), ("max_batch", C.c_int32), ("flags", C.c_int32),
+        ("graph_batch", C.c_int32)]
 
 
 _LAYER_FIELDS = ("ln1_w", "ln1_b", "q_w", "q_b", "k_w", "k_b", "v_w", "v_b", "o_w", "o_b",
@@ -53,6 +56,7 @@ SYMBOLS = {
     "plipmi_encode_image": (_i, [_vp, _vp, _i, _vp, _i, _vp]),
     "plipmi_encode_image_u8": (_i, [_vp, _vp, _i, _vp, _i, _vp]),
     "plipmi_encode_text": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _vp]),
+    "plipmi_check_async": (_i, [_vp]),
     "plipmi_set_graph_batch": (_i, [_vp, _i]),
     "plipmi_l2_normalize": (_i, [_vp, _vp, _i, _i, _vp]),
     "plipmi_logits": (_i, [_vp, _vp, _i, _vp, _i, _i, _f, _vp, _vp, _vp, _vp]),
@@ -63,10 +67,11 @@ SYMBOLS = {
     "plipmi_gemm_nt": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _f, _vp, _vp]),
     "plipmi_gemm_variant_name": (C.c_char_p, [_i]),
     "plipmi_set_gemm_variant": (None, [_i]),
+    "plipmi_set_gemm_store_wt": (None, [_i]),
     "plipmi_set_gemm_policy": (_i, [_vp, _i]),
     "plipmi_gemm_variant_built": (_i, [_i, _i]),
     "plipmi_set_text_packing": (_i, [_vp, _i]),
-    "plipmi_gemm_nt_ln": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp]),
+    "plipmi_gemm_nt_ln": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp]),
     "plipmi_gemm_nt_ld": (_i, [_i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _f, _vp, _vp]),
     "plipmi_gemm_nt_traced": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
     "plipmi_attention": (_i, [_i, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),

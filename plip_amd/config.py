@@ -119,7 +119,7 @@ PRESETS = {
 }
 # the tiny model with a 4-pixel patch: 257 vision tokens (the ViT-L/14 count) -> the long-sequence attention path
 PRESETS["tiny-p4"] = PRESETS["tiny"].replace(patch_size=4)
-# the smallest shape the fp8 GEMM tiles accept (3*width and the MLP width multiples of 256): fp8-weights mode tests
+# widths of 256: every GEMM of the tower takes the 256-column tiles
 PRESETS["tiny-w256"] = PRESETS["tiny"].replace(v_width=256, v_heads=4, v_mlp=512, t_width=256, t_heads=4, t_mlp=512)
 
 

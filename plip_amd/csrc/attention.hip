@@ -13,7 +13,7 @@
 
 namespace plipmi {
 
-hipError_t launch_attention_mfma(const void* qkv, void* out, int B, int S, int H, int causal, const int64_t* key_mask,
+hipError_t launch_attention_mfma(const void* qkv, void* out, int dtype, int B, int S, int H, int causal, const int64_t* key_mask,
                                  hipStream_t s, const int* cu);
 
 constexpr int kDh = 64;      // head dim
@@ -122,10 +122,10 @@ hipError_t launch_attention(const void* qkv, void* out, int dtype, int B, int S,
                             const int64_t* key_mask, int impl, hipStream_t s, const int* cu) {
   if (B <= 0) return hipSuccess;
   if (impl == 1) {
-    if (dtype != 1) return hipErrorInvalidValue;
-    return launch_attention_mfma(qkv, out, B, S, H, causal, key_mask, s, cu);
+    if (dtype != 1 && dtype != 2) return hipErrorInvalidValue;
+    return launch_attention_mfma(qkv, out, dtype, B, S, H, causal, key_mask, s, cu);
   }
-  if (cu) return hipErrorInvalidValue;   // packed rows are a bf16 MFMA-kernel form
+  if (cu) return hipErrorInvalidValue;   // packed rows are an MFMA-kernel form
   const int threads = ((S + 63) / 64) * 64;
   if (threads > 1024) return hipErrorInvalidValue;  // S <= 1024 (ViT-L/14@336 has 577 tokens)
   const dim3 grid(B * H), block(threads);
@@ -133,8 +133,8 @@ hipError_t launch_attention(const void* qkv, void* out, int dtype, int B, int S,
   // build (S > 256, e.g. ViT-L/14@336) trades some spills for the larger block.
 #define PLIPMI_ATTN(T, MAXT) \
   hipLaunchKernelGGL((attention_valu_kernel<T, MAXT>), grid, block, 0, s, (const T*)qkv, (T*)out, S, H, causal, key_mask)
-  if (threads <= 256) { if (dtype == 1) PLIPMI_ATTN(bf16_t, 256); else PLIPMI_ATTN(float, 256); }
-  else                { if (dtype == 1) PLIPMI_ATTN(bf16_t, 1024); else PLIPMI_ATTN(float, 1024); }
+  if (threads <= 256) { if (dtype == 1) PLIPMI_ATTN(bf16_t, 256); else if (dtype == 2) PLIPMI_ATTN(f16_t, 256); else PLIPMI_ATTN(float, 256); }
+  else                { if (dtype == 1) PLIPMI_ATTN(bf16_t, 1024); else if (dtype == 2) PLIPMI_ATTN(f16_t, 1024); else PLIPMI_ATTN(float, 1024); }
 #undef PLIPMI_ATTN
   return hipGetLastError();
 }

@@ -1,6 +1,6 @@
-// attention_mfma.hip -- bf16 MFMA attention.  Short CLIP sequences (S <= 128: 50 vision tokens, 77 text tokens)
+// attention_mfma.hip -- MFMA attention for the two 16-bit engines (bf16 / f16).  Short CLIP sequences (S <= 128: 50 vision tokens, 77 text tokens)
 // take the single-pass kernel: one workgroup per (image|caption, head), one wavefront per block of 32 queries,
-// v_mfma_f32_32x32x16_bf16 for both products.  Longer ones (ViT-B/16, ViT-L/14[@336]) take the chunked
+// v_mfma_f32_32x32x16_bf16 / _f16 for both products.  Longer ones (ViT-B/16, ViT-L/14[@336]) take the chunked
 // online-softmax kernel further down, built from the same pieces.
 //
 //   scores^T = K Q^T   (operands swapped): a lane owns ONE query column (lane&31) and
@@ -14,7 +14,7 @@
 //                      V^T comes from a row-major LDS copy of V through the hardware transpose read
 //                      ds_read_b64_tr_b16 (two [keys][32] images with 64-byte rows -> conflict-free).
 //   Softmax statistics, the running sum and the 1/l normalisation are fp32
-//   (modeling_clip.py:271); P is rounded to bf16 only as the MFMA operand.
+//   (modeling_clip.py:271); P is rounded to the operand type only as the MFMA operand.
 #include "kernels.h"
 
 namespace plipmi {
@@ -31,13 +31,14 @@ typedef __attribute__((ext_vector_type(4))) short i16x4;
 __device__ __forceinline__ int vtr_lane_offset(int lrow, int hi) {
   return (((lrow & 15) >> 2) + 4 * hi) * 64 + ((lrow & 3) * 4 + (lrow >> 4) * 16) * 2;
 }
-__device__ __forceinline__ bf16x8 vtr_fragment(const char* vs, int byte_off) {
+template <typename H>
+__device__ __forceinline__ typename half_traits<H>::x8 vtr_fragment(const char* vs, int byte_off) {
   typedef __attribute__((address_space(3))) i16x4* lds_ptr;
   const i16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(vs + byte_off));
   const i16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(vs + byte_off + 8 * 64));  // keys +8
   typedef __attribute__((ext_vector_type(8))) short i16x8;
   const i16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-  return __builtin_bit_cast(bf16x8, v);
+  return __builtin_bit_cast(typename half_traits<H>::x8, v);
 }
 
 // PAIRS (sample, head) problems per workgroup, one after the other, the K / V rows of problem p+1 requested (into
@@ -46,13 +47,15 @@ __device__ __forceinline__ bf16x8 vtr_fragment(const char* vs, int byte_off) {
 // VGPRs vs 64 / 80: three waves per SIMD instead of six to eight) and the launch got slower, 18.4 -> 19.6 us (S = 50) and
 // 21.0 -> 29.2 us (S = 77): the many small independent workgroups already overlap each other's load -> compute -> store
 // chains better than a prefetching loop does.  The launcher instantiates PAIRS = 1; the template keeps the experiment.
-template <int KT, int PAIRS>  // 32-key tiles: S <= 32*KT
-__global__ __launch_bounds__(64 * KT) void attention_mfma_kernel(const bf16_t* __restrict__ qkv,
-                                                                 bf16_t* __restrict__ out, int S, int H, int causal,
+template <typename HT, int KT, int PAIRS>  // 32-key tiles: S <= 32*KT
+__global__ __launch_bounds__(64 * KT) void attention_mfma_kernel(const HT* __restrict__ qkv,
+                                                                 HT* __restrict__ out, int S, int H, int causal,
                                                                  const int64_t* __restrict__ key_mask, int n_problems,
                                                                  int pairs /* == PAIRS; a run-time value so the loop stays a loop */,
                                                                  const int* __restrict__ cu /* packed rows: sample b owns rows
                                                                  cu[b] .. cu[b+1]-1 of qkv / out (nullptr: b*S .. b*S+S-1) */) {
+  using X8 = typename half_traits<HT>::x8;
+  using X4 = typename half_traits<HT>::x4;
   constexpr int SP = 32 * KT;   // padded sequence
   constexpr int NT = 64 * KT;
   constexpr int NP = SP * 8 / NT;   // 16-byte pieces of K (and of V) per thread: 4
@@ -80,11 +83,11 @@ __global__ __launch_bounds__(64 * KT) void attention_mfma_kernel(const bf16_t* _
   auto fetch = [&](int bh) {   // this thread's pieces of problem bh's K and V rows -> registers
     const int b = bh / H, h = bh - b * H;
     const int row0 = cu ? cu[b] : b * S, Sb = cu ? cu[b + 1] - row0 : S;
-    const bf16_t* base = qkv + (size_t)row0 * ld + h * 64;
+    const HT* base = qkv + (size_t)row0 * ld + h * 64;
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
       const int e = tid + i * NT, row = e >> 3, c = e & 7;
-      const bf16_t* src = base + (size_t)(row < Sb ? row : Sb - 1) * ld + c * 8;
+      const HT* src = base + (size_t)(row < Sb ? row : Sb - 1) * ld + c * 8;
       kreg[i] = *reinterpret_cast<const u32x4*>(src + D);
       vreg[i] = *reinterpret_cast<const u32x4*>(src + 2 * D);
     }
@@ -108,7 +111,7 @@ __global__ __launch_bounds__(64 * KT) void attention_mfma_kernel(const bf16_t* _
     const int row0 = __builtin_amdgcn_readfirstlane(cu ? cu[b] : b * S);
     const int Sb = __builtin_amdgcn_readfirstlane(cu ? cu[b + 1] - row0 : S);
     const bool active = q0 < Sb;
-    const bf16_t* base = qkv + (size_t)row0 * ld + h * 64;
+    const HT* base = qkv + (size_t)row0 * ld + h * 64;
     // key validity bits (sequence padding and the tokenizer's attention_mask): key = tid
     {
       const bool ok = tid < Sb && (key_mask == nullptr || key_mask[(size_t)b * S + tid] != 0);
@@ -126,7 +129,7 @@ __global__ __launch_bounds__(64 * KT) void attention_mfma_kernel(const bf16_t* _
     // these rows, so an LDS image of Q would only cost residency (8-16 KB per workgroup = a third of its LDS).
     u32x4 qf[4];
     {
-      const bf16_t* qrow = base + (size_t)(qidx < Sb ? qidx : Sb - 1) * ld;
+      const HT* qrow = base + (size_t)(qidx < Sb ? qidx : Sb - 1) * ld;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const u32x4*>(qrow + (ks * 2 + hi) * 8);
     }
@@ -146,8 +149,7 @@ __global__ __launch_bounds__(64 * KT) void attention_mfma_kernel(const bf16_t* _
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
           const u32x4 kf = *reinterpret_cast<const u32x4*>(Ks + (32 * t + lrow) * 128 + (((ks * 2 + hi) ^ lsw) << 4));
-          sc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf), __builtin_bit_cast(bf16x8, qf[ks]),
-                                                          sc[t], 0, 0, 0);
+          sc[t] = half_traits<HT>::mfma32(__builtin_bit_cast(X8, kf), __builtin_bit_cast(X8, qf[ks]), sc[t]);
         }
       }
 #pragma unroll
@@ -185,13 +187,13 @@ __global__ __launch_bounds__(64 * KT) void attention_mfma_kernel(const bf16_t* _
         if (causal && 32 * t > q0 + 31) continue;
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
-          bf16x8 pf;
+          X8 pf;
 #pragma unroll
-          for (int jj = 0; jj < 8; ++jj) pf[jj] = (bf16_t)sc[t][8 * s2 + jj];
+          for (int jj = 0; jj < 8; ++jj) pf[jj] = (HT)sc[t][8 * s2 + jj];
 #pragma unroll
           for (int dt = 0; dt < 2; ++dt) {
-            const bf16x8 vf = vtr_fragment(vlane, dt * VIMG + (32 * t + 16 * s2) * 64);
-            acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, acc[dt], 0, 0, 0);
+            const X8 vf = vtr_fragment<HT>(vlane, dt * VIMG + (32 * t + 16 * s2) * 64);
+            acc[dt] = half_traits<HT>::mfma32(vf, pf, acc[dt]);
           }
         }
       }
@@ -201,16 +203,15 @@ __global__ __launch_bounds__(64 * KT) void attention_mfma_kernel(const bf16_t* _
       // ds_write_b64 group (16 consecutive rows, same column chunk) touch 16 distinct 8-byte bank pairs.
       const float inv = 1.0f / rsum;
       char* orow_lds = Ks + (q0 + lrow) * 128;
-      typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4) {
           const int d = dt * 32 + 8 * q4 + 4 * hi;                 // 4 consecutive head-dim columns
           const int c = d >> 3;                                    // 16-byte chunk, half (d&4) inside it
-          const bf16x4 v = {(bf16_t)(acc[dt][4 * q4 + 0] * inv), (bf16_t)(acc[dt][4 * q4 + 1] * inv),
-                            (bf16_t)(acc[dt][4 * q4 + 2] * inv), (bf16_t)(acc[dt][4 * q4 + 3] * inv)};
-          *reinterpret_cast<bf16x4*>(orow_lds + ((c ^ lsw) << 4) + ((((d >> 2) ^ lrow) & 1) << 3)) = v;
+          const X4 v = {from_f32<HT>(acc[dt][4 * q4 + 0] * inv), from_f32<HT>(acc[dt][4 * q4 + 1] * inv),
+                        from_f32<HT>(acc[dt][4 * q4 + 2] * inv), from_f32<HT>(acc[dt][4 * q4 + 3] * inv)};
+          *reinterpret_cast<X4*>(orow_lds + ((c ^ lsw) << 4) + ((((d >> 2) ^ lrow) & 1) << 3)) = v;
         }
       __builtin_amdgcn_wave_barrier();
       const int c = lane & 7;
@@ -234,9 +235,12 @@ __global__ __launch_bounds__(64 * KT) void attention_mfma_kernel(const bf16_t* _
 // running max / running sum / rescale of the online softmax are per-lane scalars: no cross-lane traffic beyond the
 // one lane^32 exchange per chunk.  K and V^T chunks are staged through LDS exactly like the short-sequence kernel.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void attention_flash_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+template <typename HT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void attention_flash_kernel(const HT* __restrict__ qkv, HT* __restrict__ out,
                                                               int S, int H, int causal,
                                                               const int64_t* __restrict__ key_mask) {
+  using X8 = typename half_traits<HT>::x8;
+  using X4 = typename half_traits<HT>::x4;
   constexpr int SP = 128;
   __shared__ __attribute__((aligned(16))) char Qs[SP * 128];
   __shared__ __attribute__((aligned(16))) char Ks[SP * 128];
@@ -248,7 +252,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   const int D = H * 64, ld = 3 * D;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bf16_t* base = qkv + (size_t)b * S * ld + h * 64;
+  const HT* base = qkv + (size_t)b * S * ld + h * 64;
 
   const int qrows = min(SP, (S - qbase + 31) & ~31);  // 32-row tiles that hold at least one real query
   for (int e = tid; e < qrows * 8; e += 256) {  // the query block, whole 128-byte lines, GEMM swizzle
@@ -288,7 +292,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     for (int e = tid; e < krows * 8; e += 256) {
       const int row = e >> 3, c = e & 7;
       const int rg = kbase + row < S ? kbase + row : S - 1;
-      const bf16_t* src = base + (size_t)rg * ld + c * 8 + D;
+      const HT* src = base + (size_t)rg * ld + c * 8 + D;
       const u32x4 k16 = *reinterpret_cast<const u32x4*>(src);
       const u32x4 v16 = *reinterpret_cast<const u32x4*>(src + D);
       *reinterpret_cast<u32x4*>(Ks + row * 128 + ((c ^ ((row >> 1) & 7)) << 4)) = k16;
@@ -322,8 +326,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
           for (int ks = 0; ks < 4; ++ks) {
             const u32x4 kf = *reinterpret_cast<const u32x4*>(Ks + (32 * t + lrow) * 128 + (((ks * 2 + hi) ^ lsw) << 4));
-            sc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf),
-                                                             __builtin_bit_cast(bf16x8, qf[ks]), sc[tt], 0, 0, 0);
+            sc[tt] = half_traits<HT>::mfma32(__builtin_bit_cast(X8, kf), __builtin_bit_cast(X8, qf[ks]), sc[tt]);
           }
         }
         const int kfirst = kbase + 32 * t + 4 * hi;  // key of slot 0
@@ -351,17 +354,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         if (kbase + 32 * t >= S || (causal && kbase + 32 * t > qbase + q0 + 31)) continue;
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
-          bf16x8 pf;
+          X8 pf;
 #pragma unroll
           for (int jj = 0; jj < 8; ++jj) {
             const float pv = __expf(sc[tt][8 * s2 + jj] - m_use);
             csum += pv;
-            pf[jj] = (bf16_t)pv;
+            pf[jj] = (HT)pv;
           }
 #pragma unroll
           for (int dt = 0; dt < 2; ++dt) {
-            const bf16x8 vf = vtr_fragment(vlane, dt * (SP * 64) + (32 * t + 16 * s2) * 64);
-            acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, acc[dt], 0, 0, 0);
+            const X8 vf = vtr_fragment<HT>(vlane, dt * (SP * 64) + (32 * t + 16 * s2) * 64);
+            acc[dt] = half_traits<HT>::mfma32(vf, pf, acc[dt]);
           }
         }
       }
@@ -373,16 +376,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const float rsum = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / rsum;
     char* orow_lds = Qs + (q0 + lrow) * 128;  // this wave's own Q rows: consumed into qf long ago
-    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
       for (int q4 = 0; q4 < 4; ++q4) {
         const int d = dt * 32 + 8 * q4 + 4 * hi;
         const int c = d >> 3;
-        const bf16x4 v = {(bf16_t)(acc[dt][4 * q4 + 0] * inv), (bf16_t)(acc[dt][4 * q4 + 1] * inv),
-                          (bf16_t)(acc[dt][4 * q4 + 2] * inv), (bf16_t)(acc[dt][4 * q4 + 3] * inv)};
-        *reinterpret_cast<bf16x4*>(orow_lds + ((c ^ lsw) << 4) + (d & 4) * 2) = v;
+        const X4 v = {from_f32<HT>(acc[dt][4 * q4 + 0] * inv), from_f32<HT>(acc[dt][4 * q4 + 1] * inv),
+                      from_f32<HT>(acc[dt][4 * q4 + 2] * inv), from_f32<HT>(acc[dt][4 * q4 + 3] * inv)};
+        *reinterpret_cast<X4*>(orow_lds + ((c ^ lsw) << 4) + (d & 4) * 2) = v;
       }
     __builtin_amdgcn_wave_barrier();
     const int c = lane & 7;
@@ -396,20 +398,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   }
 }
 
-hipError_t launch_attention_mfma(const void* qkv, void* out, int B, int S, int H, int causal, const int64_t* key_mask,
-                                 hipStream_t s, const int* cu) {
-  if (S <= 0) return hipErrorInvalidValue;
+template <typename HT>
+static hipError_t launch_attention_mfma_t(const void* qkv, void* out, int B, int S, int H, int causal, const int64_t* key_mask,
+                                          hipStream_t s, const int* cu) {
   if (S > 128) {
     if (cu) return hipErrorInvalidValue;   // packed rows: short-sequence kernel only (captions are 77 tokens at most)
-    hipLaunchKernelGGL(attention_flash_kernel, dim3(B * H, (S + 127) / 128), dim3(256), 0, s, (const bf16_t*)qkv,
-                       (bf16_t*)out, S, H, causal, key_mask);
+    hipLaunchKernelGGL(attention_flash_kernel<HT>, dim3(B * H, (S + 127) / 128), dim3(256), 0, s, (const HT*)qkv,
+                       (HT*)out, S, H, causal, key_mask);
     return hipGetLastError();
   }
   const int KT = (S + 31) / 32;
   constexpr int kPairs = 1;                   // (sample, head) problems per workgroup, see the kernel's header
   const dim3 grid((B * H + kPairs - 1) / kPairs), block(64 * KT);
 #define PLIPMI_ATT(K) \
-  hipLaunchKernelGGL((attention_mfma_kernel<K, kPairs>), grid, block, 0, s, (const bf16_t*)qkv, (bf16_t*)out, S, H, causal, \
+  hipLaunchKernelGGL((attention_mfma_kernel<HT, K, kPairs>), grid, block, 0, s, (const HT*)qkv, (HT*)out, S, H, causal, \
                      key_mask, B * H, kPairs, cu)
   switch (KT) {
     case 1: PLIPMI_ATT(1); break;
@@ -419,6 +421,13 @@ hipError_t launch_attention_mfma(const void* qkv, void* out, int B, int S, int H
   }
 #undef PLIPMI_ATT
   return hipGetLastError();
+}
+
+hipError_t launch_attention_mfma(const void* qkv, void* out, int dtype, int B, int S, int H, int causal, const int64_t* key_mask,
+                                 hipStream_t s, const int* cu) {
+  if (S <= 0 || (dtype != 1 && dtype != 2)) return hipErrorInvalidValue;
+  return dtype == 1 ? launch_attention_mfma_t<bf16_t>(qkv, out, B, S, H, causal, key_mask, s, cu)
+                    : launch_attention_mfma_t<f16_t>(qkv, out, B, S, H, causal, key_mask, s, cu);
 }
 
 }  // namespace plipmi

@@ -7,35 +7,65 @@ namespace plipmi {
 
 typedef __bf16 bf16_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+// IEEE half: the OTHER 16-bit operand type of the matrix cores (v_mfma_f32_32x32x16_f16, same rate as bf16).  11
+// significand bits against bf16's 8: the PLIPMI_F16 engine's operand roundings are 8x smaller, which is what the cosine
+// bar needs on the text tower; range +-65504 -- the reference's own CUDA path runs its CLIP in
+// this type (clip.model.convert_weights; reproducibility/embedders/factory.py:21 -> clip.load on "cuda").
+typedef _Float16 f16_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
-// OCP e4m3fn operand of the experimental fp8 GEMM (storage tag only: the arithmetic is the scaled f8f6f4 MFMA)
-struct fp8_t { unsigned char v; };
-typedef __attribute__((ext_vector_type(8))) int i32x8;
 
 constexpr int kWave = 64;  // CDNA wavefront
 
 // ---- scalar conversions -------------------------------------------------
 __device__ __forceinline__ float to_f32(float x) { return x; }
 __device__ __forceinline__ float to_f32(bf16_t x) { return (float)x; }
+__device__ __forceinline__ float to_f32(f16_t x) { return (float)x; }
+// fp32 -> half: values beyond the type's range SATURATE (+-65504) instead of becoming inf, so one outlier activation costs
+// accuracy on its own row, not NaNs through every softmax it reaches
+__device__ __forceinline__ float sat_f16(float x) { return __builtin_amdgcn_fmed3f(x, -65504.0f, 65504.0f); }
 template <typename T> __device__ __forceinline__ T from_f32(float x);
 template <> __device__ __forceinline__ float from_f32<float>(float x) { return x; }
 template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float x) { return (bf16_t)x; }  // RNE (v_cvt_pk_bf16_f32)
+template <> __device__ __forceinline__ f16_t from_f32<f16_t>(float x) { return (f16_t)sat_f16(x); }   // RNE (v_cvt_f16_f32)
+
+// the two 16-bit operand types: vector forms and the MFMA that multiplies them
+template <typename T> struct half_traits;
+template <> struct half_traits<bf16_t> {
+  using x8 = bf16x8; using x4 = bf16x4;
+  static constexpr const char* name = "bf16";
+  __device__ __forceinline__ static f32x16 mfma32(x8 a, x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct half_traits<f16_t> {
+  using x8 = f16x8; using x4 = f16x4;
+  static constexpr const char* name = "f16";
+  __device__ __forceinline__ static f32x16 mfma32(x8 a, x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
+template <typename T> constexpr bool is_half_v = sizeof(T) == 2;
 
 // 4 consecutive outputs: fp32 -> 16-byte store, bf16 -> 8-byte store
 __device__ __forceinline__ void store4(float* p, float a, float b, float c, float d) {
   *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
 }
 __device__ __forceinline__ void store4(bf16_t* p, float a, float b, float c, float d) {
-  typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
   bf16x4 v = {(bf16_t)a, (bf16_t)b, (bf16_t)c, (bf16_t)d};
   *reinterpret_cast<bf16x4*>(p) = v;
 }
+__device__ __forceinline__ void store4(f16_t* p, float a, float b, float c, float d) {
+  f16x4 v = {from_f32<f16_t>(a), from_f32<f16_t>(b), from_f32<f16_t>(c), from_f32<f16_t>(d)};
+  *reinterpret_cast<f16x4*>(p) = v;
+}
 __device__ __forceinline__ float4 load4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ float4 load4(const bf16_t* p) {
-  typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
   bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+  return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+}
+__device__ __forceinline__ float4 load4(const f16_t* p) {
+  f16x4 v = *reinterpret_cast<const f16x4*>(p);
   return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
 }
 
@@ -76,28 +106,56 @@ __device__ __forceinline__ float row8_sum(float v) {
 
 // LayerNorm statistics travel as per-row PARTIALS over 64-column slices: {sum, M2 = sum (x - sum/64)^2}.  Folding
 // NS slices with Chan's update gives the row mean and the (biased) variance without ever forming E[x^2] - mean^2.
-// The LayerNorm-folded bf16 engine keeps its fp32 residual stream as two 16-bit planes: hi = the value rounded to bf16
-// (nearest, ties away from zero) -- which IS the next GEMM's A operand -- and lo = the signed 16-bit remainder of the bit
-// pattern, so that bits(x) == (hi << 16) + lo exactly.  No precision is given up against a plain fp32 array; a residual
-// GEMM's epilogue moves 4 + 4 bytes per element instead of 4 + 4 + 2 (fp32 in place plus a separate bf16 copy).
-__device__ __forceinline__ void split_f32(float x, unsigned& hi16, unsigned& lo16) {
+//
+// The LayerNorm-folded engines keep their fp32 residual stream as TWO 16-bit planes: hi = the value rounded to the engine's
+// 16-bit operand type -- which IS the next GEMM's A operand -- and lo = a signed 16-bit remainder chosen so that the pair
+// reproduces the fp32 value EXACTLY.  No precision is given up against a plain fp32 array; a residual GEMM's epilogue moves
+// 4 + 4 bytes per element instead of 4 + 4 + 2 (fp32 in place plus a separate 16-bit copy).
+//   bf16: hi = nearest bf16 (ties away from zero) = the upper half of the bit pattern after rounding, lo = the signed
+//         remainder of the bit pattern:  bits(x) == (hi << 16) + lo.
+//   f16:  hi = nearest f16 (ties to even, saturating at +-65504), lo = (x - hi) in units of 2^(E - 24) with E the exponent
+//         of hi (at least -14): x - hi is a multiple of ulp32(x) >= that unit and at most half an f16 ulp = 2^13 units, so
+//         it is an integer of at most 14 bits.  Exact for 2^-15 <= |x| <= 65504; below, the absolute error is < 2^-38;
+//         beyond, the stream saturates (the reference's own f16 CUDA path would hold inf there).
+template <typename H> __device__ __forceinline__ void split_f32(float x, unsigned& hi16, unsigned& lo16);
+template <typename H> __device__ __forceinline__ float join_f32(unsigned hi16, unsigned lo16);   // both in the low 16 bits of their words
+template <> __device__ __forceinline__ void split_f32<bf16_t>(float x, unsigned& hi16, unsigned& lo16) {
   const unsigned u = __builtin_bit_cast(unsigned, x), t = u + 0x8000u;
   hi16 = t >> 16;
   lo16 = (u - (t & 0xffff0000u)) & 0xffffu;
 }
-__device__ __forceinline__ float join_f32(unsigned hi16, unsigned lo16) {   // both in the low 16 bits of their words
+template <> __device__ __forceinline__ float join_f32<bf16_t>(unsigned hi16, unsigned lo16) {
   return __builtin_bit_cast(float, (hi16 << 16) + (unsigned)(((int)(lo16 << 16)) >> 16));
 }
+__device__ __forceinline__ unsigned f16_plane_exp(float hf) {   // biased fp32 exponent of the f16 value, floor 127 - 14
+  const unsigned eb = (__builtin_bit_cast(unsigned, hf) >> 23) & 0xffu;
+  return eb < 113u ? 113u : eb;
+}
+template <> __device__ __forceinline__ void split_f32<f16_t>(float x, unsigned& hi16, unsigned& lo16) {
+  const f16_t h = (f16_t)sat_f16(x);
+  const float hf = (float)h;
+  const float scale = __builtin_bit_cast(float, (278u - f16_plane_exp(hf)) << 23);   // 2^(24 - E)
+  const float r = __builtin_amdgcn_fmed3f((x - hf) * scale, -32768.0f, 32767.0f);
+  hi16 = (unsigned)__builtin_bit_cast(unsigned short, h);
+  lo16 = (unsigned)(int)r & 0xffffu;
+}
+template <> __device__ __forceinline__ float join_f32<f16_t>(unsigned hi16, unsigned lo16) {
+  const float hf = (float)__builtin_bit_cast(f16_t, (unsigned short)hi16);
+  const float unit = __builtin_bit_cast(float, (f16_plane_exp(hf) - 24u) << 23);     // 2^(E - 24)
+  return fmaf((float)(((int)(lo16 << 16)) >> 16), unit, hf);
+}
+template <typename H>
 __device__ __forceinline__ void store4_split(unsigned short* hi, unsigned short* lo, float a, float b, float c, float d) {
   unsigned h0, h1, h2, h3, l0, l1, l2, l3;
-  split_f32(a, h0, l0); split_f32(b, h1, l1); split_f32(c, h2, l2); split_f32(d, h3, l3);
+  split_f32<H>(a, h0, l0); split_f32<H>(b, h1, l1); split_f32<H>(c, h2, l2); split_f32<H>(d, h3, l3);
   *reinterpret_cast<uint2*>(hi) = make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));
   *reinterpret_cast<uint2*>(lo) = make_uint2(l0 | (l1 << 16), l2 | (l3 << 16));
 }
+template <typename H>
 __device__ __forceinline__ float4 load4_split(const unsigned short* hi, const unsigned short* lo) {
   const uint2 h = *reinterpret_cast<const uint2*>(hi), l = *reinterpret_cast<const uint2*>(lo);
-  return make_float4(join_f32(h.x & 0xffffu, l.x & 0xffffu), join_f32(h.x >> 16, l.x >> 16),
-                     join_f32(h.y & 0xffffu, l.y & 0xffffu), join_f32(h.y >> 16, l.y >> 16));
+  return make_float4(join_f32<H>(h.x & 0xffffu, l.x & 0xffffu), join_f32<H>(h.x >> 16, l.x >> 16),
+                     join_f32<H>(h.y & 0xffffu, l.y & 0xffffu), join_f32<H>(h.y >> 16, l.y >> 16));
 }
 
 constexpr int kLnSlice = 64;

@@ -49,8 +49,6 @@ namespace {
 
 struct LayerW {
   void *wqkv, *wo, *w1, *w2;
-  void *wqkv8 = nullptr, *w18 = nullptr;  // fp8-weights mode: e4m3fn copies of the QKV / fc1 weights ...
-  float *sqkv = nullptr, *s1 = nullptr;   // ... and their per-output-channel scales
   float *bqkv, *bo, *b1, *b2, *ln1w, *ln1b, *ln2w, *ln2b;
   // LayerNorm-folded engine: wqkv / w1 hold the centred W * g (LayerNorm gain and mean subtraction folded in),
   // bqkv / b1 hold c2 = W b_ln + bias
@@ -61,10 +59,8 @@ struct Tower {
   // workspace
   float* x = nullptr;
   void *h = nullptr, *qkv = nullptr, *att = nullptr, *mlp = nullptr;
-  void* h8 = nullptr;   // fp8-weights mode: LayerNorm output as fp8 rows ...
-  float* hs = nullptr;  // ... with one dynamic scale per row
-  // LayerNorm-folded engine: the residual stream lives as two 16-bit planes (common.h split_f32): h = its bf16 plane (the
-  // A operand of the q/k/v and fc1 GEMMs), lo = the int16 remainder (h + lo == the fp32 value exactly); x only holds the
+  // LayerNorm-folded engine: the residual stream lives as two 16-bit planes (common.h split_f32): h = its operand-type plane
+  // (the A operand of the q/k/v and fc1 GEMMs), lo = the int16 remainder (the pair == the fp32 value exactly); x only holds the
   // embedding rows before the first LayerNorm and a joined copy where something needs plain fp32.  st = the rows'
   // statistics partials [M, D/64, 2]
   float* st = nullptr;
@@ -100,20 +96,19 @@ struct plipmi_engine {
   plipmi_config cfg;
   int dtype = 0;
   size_t esz = 4;
-  bool fp8w = false;  // compute_dtype PLIPMI_FP8W: the bf16 engine with fp8 QKV / fc1 projections
-  // bf16 engine: the 2 x L LayerNorms of the blocks are folded into the GEMMs around them (no LayerNorm pass, no
-  // normalised activations in memory); PLIPMI_LN_FOLD=0 restores the separate LayerNorm kernels for A/B runs
+  // 16-bit engines: the 2 x L LayerNorms of the blocks are folded into the GEMMs around them (no LayerNorm pass, no
+  // normalised activations in memory); PLIPMI_FLAG_SEPARATE_LAYERNORM restores the separate LayerNorm kernels for A/B runs
   bool ln_fold = false;
   // The last block's out_proj / fc1 / fc2 (and both of its residual adds) only ever reach the output through the row that
-  // is pooled afterwards (CLS / EOS): the encode paths run them on that one row per sample (PLIPMI_POOLED_LAST_BLOCK=0
-  // computes all rows, as plipmi_debug_hidden always does).  bf16 LayerNorm-folded engine only.
+  // is pooled afterwards (CLS / EOS): the encode paths run them on that one row per sample (PLIPMI_FLAG_DENSE_LAST_BLOCK
+  // computes all rows, as plipmi_debug_hidden always does).  LayerNorm-folded engines only.
   bool pooled_last = false;
-  // Packed captions (plipmi_set_text_packing; PLIPMI_TEXT_PACKING=1): the text tower computes rows 0 .. EOS of each caption
+  // Packed captions (plipmi_set_text_packing; PLIPMI_FLAG_PACK_CAPTIONS): the text tower computes rows 0 .. EOS of each caption
   // only -- causal attention and EOS pooling mean the rows behind EOS cannot reach the embedding.  Off by default: the
   // default engine executes every padded position, like the reference does.
   bool text_pack = false;
   int gemm_policy = 0;  // tile policy of this handle's GEMMs (plipmi_set_gemm_policy)
-  // small-batch hipGraph replay (plipmi_set_graph_batch; PLIPMI_GRAPH_BATCH): batches of at most this many samples
+  // small-batch hipGraph replay (plipmi_config.graph_batch, plipmi_set_graph_batch): batches of at most this many samples
   int graph_batch = 0;
   std::map<std::tuple<int, int, int, int, int>, GraphEntry> graphs;
   void* g_vin = nullptr;      // staged image input (fp32 pixels or uint8 tiles) [graph_batch_cap, 3, H, W] x 4 B
@@ -135,6 +130,10 @@ struct plipmi_engine {
   char* slab = nullptr;
   size_t slab_bytes = 0;
   int attn_impl = 0, attn_impl_vis = 0, attn_impl_txt = 0;
+  // raised by the embedding kernels when a token id lies outside the vocabulary (host-visible memory; reported by the next
+  // call on the handle and by plipmi_check_async -- the reference's lookup raises, plip.py:68)
+  int* bad_id = nullptr;
+  bool half() const { return dtype != PLIPMI_F32; }
   char devname[128] = "";
   // plipmi_similarity_topk scratch (allocated on first use, grown on demand)
   char* sim_ws = nullptr;
@@ -206,20 +205,13 @@ void carve(plipmi_engine* e, Carver& c) {
     t->layers.resize(t->L);
     for (LayerW& w : t->layers) {
       w.wo = c.take<void>(D * D, es); w.w2 = c.take<void>(D * F, es);
-      if (e->fp8w) {
-        w.wqkv = nullptr; w.w1 = nullptr;
-        w.wqkv8 = c.take<void>(3 * D * D, 1); w.w18 = c.take<void>(F * D, 1);
-        w.sqkv = c.take<float>(3 * D, 4);     w.s1 = c.take<float>(F, 4);
-      } else {
-        w.wqkv = c.take<void>(3 * D * D, es); w.w1 = c.take<void>(F * D, es);
-      }
+      w.wqkv = c.take<void>(3 * D * D, es); w.w1 = c.take<void>(F * D, es);
       w.bqkv = c.take<float>(3 * D, 4); w.bo = c.take<float>(D, 4); w.b1 = c.take<float>(F, 4); w.b2 = c.take<float>(D, 4);
       w.ln1w = c.take<float>(D, 4); w.ln1b = c.take<float>(D, 4); w.ln2w = c.take<float>(D, 4); w.ln2b = c.take<float>(D, 4);
     }
     const size_t M = B * t->S;
     t->x = c.take<float>(M * D, 4);
     t->h = c.take<void>(M * D, es);
-    if (e->fp8w) { t->h8 = c.take<void>(M * D, 1); t->hs = c.take<float>(M, 4); }
     if (e->ln_fold) { t->st = c.take<float>(M * (D / kLnSlice) * 2, 4); t->lo = c.take<void>(M * D, 2); }
     if (e->ln_fold && t == &e->txt) {
       t->cu = c.take<int>(B + 1, 4); t->rowmap = c.take<int>(M, 4); t->mdev = c.take<int>(1, 4);
@@ -249,19 +241,13 @@ int pack_tower(plipmi_engine* e, Tower& t, const plipmi_layer_weights* src, hipS
   for (int l = 0; l < t.L; ++l) {
     const plipmi_layer_weights& w = src[l];
     LayerW& d = t.layers[l];
-    if (e->fp8w) {
-      char* wq8 = reinterpret_cast<char*>(d.wqkv8);
-      HIP_TRY(launch_quantize_rows_fp8(w.q_w, wq8, d.sqkv, D, D, qscale, s));
-      HIP_TRY(launch_quantize_rows_fp8(w.k_w, wq8 + (size_t)D * D, d.sqkv + D, D, D, 1.f, s));
-      HIP_TRY(launch_quantize_rows_fp8(w.v_w, wq8 + (size_t)2 * D * D, d.sqkv + 2 * D, D, D, 1.f, s));
-      HIP_TRY(launch_quantize_rows_fp8(w.fc1_w, d.w18, d.s1, F, D, 1.f, s));
-    } else if (e->ln_fold) {
-      // W' = bf16(W * g, rows centred) (q rows also x 1/8), c2 = W b_ln + bias -> the bias slot
+    if (e->ln_fold) {
+      // W' = (W * g, rows centred) in the operand type (q rows also x 1/8), c2 = W b_ln + bias -> the bias slot
       char* wq = reinterpret_cast<char*>(d.wqkv);
-      HIP_TRY(launch_fold_ln(w.q_w, w.q_b, w.ln1_w, w.ln1_b, wq, d.bqkv, D, D, qscale, s));
-      HIP_TRY(launch_fold_ln(w.k_w, w.k_b, w.ln1_w, w.ln1_b, wq + (size_t)D * D * e->esz, d.bqkv + D, D, D, 1.f, s));
-      HIP_TRY(launch_fold_ln(w.v_w, w.v_b, w.ln1_w, w.ln1_b, wq + (size_t)2 * D * D * e->esz, d.bqkv + 2 * D, D, D, 1.f, s));
-      HIP_TRY(launch_fold_ln(w.fc1_w, w.fc1_b, w.ln2_w, w.ln2_b, d.w1, d.b1, F, D, 1.f, s));
+      HIP_TRY(launch_fold_ln(w.q_w, w.q_b, w.ln1_w, w.ln1_b, wq, d.bqkv, D, D, qscale, dt, s));
+      HIP_TRY(launch_fold_ln(w.k_w, w.k_b, w.ln1_w, w.ln1_b, wq + (size_t)D * D * e->esz, d.bqkv + D, D, D, 1.f, dt, s));
+      HIP_TRY(launch_fold_ln(w.v_w, w.v_b, w.ln1_w, w.ln1_b, wq + (size_t)2 * D * D * e->esz, d.bqkv + 2 * D, D, D, 1.f, dt, s));
+      HIP_TRY(launch_fold_ln(w.fc1_w, w.fc1_b, w.ln2_w, w.ln2_b, d.w1, d.b1, F, D, 1.f, dt, s));
     } else {
       char* wq = reinterpret_cast<char*>(d.wqkv);
       HIP_TRY(launch_convert(w.q_w, wq, dt, D, D, D, qscale, s));
@@ -313,25 +299,12 @@ int run_gemm(plipmi_engine* e, int epi, const void* A, const void* W, void* C, c
   const double out_bytes = epi_is_colwise(epi) ? (double)M * N * e->esz
                            : (double)M * N * (epi_is_resid(epi) ? 8.0 : 4.0) + (epi == EPI_RESID_EMIT ? (double)M * N * 2.0 : 0.0);
   Scope sc(e, s, name, 2.0 * M * N * (double)K, ((double)M * K + (double)N * K) * e->esz + out_bytes);
-  const int rc = (skinny && e->dtype == PLIPMI_BF16 && gemm_skinny_supports(epi, M, N, K))
-                     ? gemm_launch_skinny(epi, p, s, &name)
+  const int rc = (skinny && e->half() && gemm_skinny_supports(epi, M, N, K))
+                     ? gemm_launch_skinny(e->dtype, epi, p, s, &name)
                      : gemm_launch(e->dtype, epi, -1, p, s, &name, e->gemm_policy);
   if (e->prof) sc.rename(name_with_role(name, role));
   if (rc != 0) return fail(PLIPMI_ERR_HIP, "gemm launch (%s, M=%d N=%d K=%d) failed: %s", name, M, N, K,
                            hipGetErrorString((hipError_t)rc));
-  return PLIPMI_OK;
-}
-
-// fp8-weights mode: C(bf16) = epilogue(A8[M,K] . W8[N,K]^T * row_scale[m] * col_scale[n] + bias)
-int run_gemm_fp8(plipmi_engine* e, int epi, const void* A8, const float* row_scale, const void* W8, const float* col_scale,
-                 void* C, const float* bias, int M, int N, int K, hipStream_t s) {
-  GemmParams p;
-  p.A = A8; p.W = W8; p.C = C; p.bias = bias; p.row_scale = row_scale; p.col_scale = col_scale;
-  p.M = M; p.N = N; p.K = K; p.lda = K; p.ldw = K; p.ldc = N; p.alpha = 1.f; p.np = 1;
-  Scope sc(e, s, epi == EPI_BIAS ? "gemm_nt<fp8,256x256_w4x2_bufdma_spreadfill,bias>" : "gemm_nt<fp8,256x256_w4x2_bufdma_spreadfill,bias_qgelu>",
-           2.0 * M * N * (double)K, (double)M * K + (double)N * K + (double)M * N * 2);
-  const int rc = gemm_launch_fp8(epi, 3, p, s);
-  if (rc != 0) return fail(PLIPMI_ERR_HIP, "fp8 gemm launch (M=%d N=%d K=%d) failed: %s", M, N, K, hipGetErrorString((hipError_t)rc));
   return PLIPMI_OK;
 }
 
@@ -369,32 +342,20 @@ int run_layers(plipmi_engine* e, Tower& t, int B, int n_layers, int causal, cons
     if (!more_follow) {
       if (t.packed) return fail(PLIPMI_ERR_INVALID, "packed rows have no every-token form");   // a consumer of plain fp32 rows follows (the every-token head, plipmi_debug_hidden)
       Scope sc(e, s, "join_planes", 0, (double)M * D * 8);
-      HIP_TRY(launch_join_planes(t.h, t.lo, t.x, (size_t)M * D, s));
+      HIP_TRY(launch_join_planes(t.h, t.lo, t.x, (size_t)M * D, e->dtype, s));
     }
     return PLIPMI_OK;
   }
   for (int l = 0; l < n_layers; ++l) {
     const LayerW& w = t.layers[l];
-    if (e->fp8w) {
-      { Scope sc(e, s, "layernorm_fp8", 0, (double)M * D * 5);
-        HIP_TRY(launch_layernorm_fp8(t.x, D, w.ln1w, w.ln1b, t.h8, t.hs, M, D, eps, s)); }
-      RUN(run_gemm_fp8(e, EPI_BIAS, t.h8, t.hs, w.wqkv8, w.sqkv, t.qkv, w.bqkv, M, 3 * D, D, s));
-    } else {
-      { Scope sc(e, s, "layernorm", 0, (double)M * D * (4 + e->esz));
-        HIP_TRY(launch_layernorm(t.x, D, w.ln1w, w.ln1b, t.h, e->dtype, M, D, eps, s)); }
-      RUN(run_gemm(e, EPI_BIAS, t.h, w.wqkv, t.qkv, w.bqkv, M, 3 * D, D, 3 * D, 0, s, "qkv"));
-    }
+    { Scope sc(e, s, "layernorm", 0, (double)M * D * (4 + e->esz));
+      HIP_TRY(launch_layernorm(t.x, D, w.ln1w, w.ln1b, t.h, e->dtype, M, D, eps, s)); }
+    RUN(run_gemm(e, EPI_BIAS, t.h, w.wqkv, t.qkv, w.bqkv, M, 3 * D, D, 3 * D, 0, s, "qkv"));
     RUN(attention());
     RUN(run_gemm(e, EPI_BIAS_RESID, t.att, w.wo, t.x, w.bo, M, D, D, D, 0, s, "out_proj"));
-    if (e->fp8w) {
-      { Scope sc(e, s, "layernorm_fp8", 0, (double)M * D * 5);
-        HIP_TRY(launch_layernorm_fp8(t.x, D, w.ln2w, w.ln2b, t.h8, t.hs, M, D, eps, s)); }
-      RUN(run_gemm_fp8(e, EPI_BIAS_QGELU, t.h8, t.hs, w.w18, w.s1, t.mlp, w.b1, M, F, D, s));
-    } else {
-      { Scope sc(e, s, "layernorm", 0, (double)M * D * (4 + e->esz));
-        HIP_TRY(launch_layernorm(t.x, D, w.ln2w, w.ln2b, t.h, e->dtype, M, D, eps, s)); }
-      RUN(run_gemm(e, EPI_BIAS_QGELU, t.h, w.w1, t.mlp, w.b1, M, F, D, F, 0, s, "fc1"));
-    }
+    { Scope sc(e, s, "layernorm", 0, (double)M * D * (4 + e->esz));
+      HIP_TRY(launch_layernorm(t.x, D, w.ln2w, w.ln2b, t.h, e->dtype, M, D, eps, s)); }
+    RUN(run_gemm(e, EPI_BIAS_QGELU, t.h, w.w1, t.mlp, w.b1, M, F, D, F, 0, s, "fc1"));
     RUN(run_gemm(e, EPI_BIAS_RESID, t.mlp, w.w2, t.x, w.b2, M, D, F, D, 0, s, "fc2"));
   }
   return PLIPMI_OK;
@@ -417,7 +378,7 @@ int run_last_block_pooled(plipmi_engine* e, Tower& t, int B, int causal, const i
   { Scope sc(e, s, impl ? "attention_mfma" : "attention_valu", 4.0 * B * t.H * (double)t.S * t.S * 64, (double)M * 4 * D * e->esz);
     HIP_TRY(launch_attention(t.qkv, t.att, e->dtype, B, t.S, t.H, causal, key_mask, impl, s, cu)); }
   { Scope sc(e, s, "pool_gather", 0, (double)B * D * (2 * e->esz + 8));
-    HIP_TRY(launch_pool_gather(t.att, t.h, t.lo, t.S, D, ids, eos_id, t.attp, t.xp, B, s, cu)); }
+    HIP_TRY(launch_pool_gather(t.att, t.h, t.lo, t.S, D, ids, eos_id, t.attp, t.xp, B, e->dtype, s, cu)); }
   LnArgs emit; emit.xb_out = t.hp; emit.st_out = t.stp;
   RUN(run_gemm(e, EPI_RESID_EMIT, t.attp, w.wo, t.xp, w.bo, B, D, D, D, 0, s, "~out_proj_pooled", &emit));
   use.stats = t.stp;
@@ -441,7 +402,7 @@ int vision_embed(plipmi_engine* e, const float* pixels, const uint8_t* tiles_u8,
   RUN(run_gemm(e, EPI_PATCH, e->patches, e->patch_w, t.x, e->vpos, B * e->np, t.D, e->kpad, t.D, e->np, s, "patch_embed"));
   if (e->ln_fold) {   // the tower's one LayerNorm pass: fp32 embedding rows in, the split residual stream + row statistics out
     Scope sc(e, s, "layernorm", 0, (double)B * t.S * t.D * 8.2);
-    HIP_TRY(launch_layernorm_emit(t.x, e->pre_w, e->pre_b, t.h, t.lo, t.st, B * t.S, t.D, g.layer_norm_eps, s));
+    HIP_TRY(launch_layernorm_emit(t.x, e->pre_w, e->pre_b, t.h, t.lo, t.st, B * t.S, t.D, g.layer_norm_eps, e->dtype, s));
     return PLIPMI_OK;
   }
   { Scope sc(e, s, "layernorm", 0, (double)B * t.S * t.D * 8);
@@ -456,12 +417,12 @@ int text_embed(plipmi_engine* e, const int64_t* ids, int B, hipStream_t s, int e
       HIP_TRY(launch_text_pack(ids, B, t.S, eos_id, t.cu, t.rowmap, t.mdev, s)); }
     Scope sc(e, s, "text_embed", 0, (double)B * t.S * t.D * 8.2);
     HIP_TRY(launch_text_embed_emit_packed(ids, e->tok, e->tpos, t.h, t.lo, t.st, t.rowmap, t.mdev, B * t.S, t.S, t.D,
-                                          e->cfg.vocab_size, s));
+                                          e->cfg.vocab_size, e->bad_id, e->dtype, s));
     return PLIPMI_OK;
   }
   Scope sc(e, s, "text_embed", 0, (double)B * t.S * t.D * (e->ln_fold ? 8.2 : 8.0));
-  if (e->ln_fold) HIP_TRY(launch_text_embed_emit(ids, e->tok, e->tpos, t.h, t.lo, t.st, B, t.S, t.D, e->cfg.vocab_size, s));
-  else HIP_TRY(launch_text_embed(ids, e->tok, e->tpos, t.x, B, t.S, t.D, e->cfg.vocab_size, s));
+  if (e->ln_fold) HIP_TRY(launch_text_embed_emit(ids, e->tok, e->tpos, t.h, t.lo, t.st, B, t.S, t.D, e->cfg.vocab_size, e->bad_id, e->dtype, s));
+  else HIP_TRY(launch_text_embed(ids, e->tok, e->tpos, t.x, B, t.S, t.D, e->cfg.vocab_size, e->bad_id, s));
   return PLIPMI_OK;
 }
 
@@ -484,8 +445,19 @@ int run_head(plipmi_engine* e, Tower& t, const float* x, int S, const int64_t* i
   return PLIPMI_OK;
 }
 
+// a token id outside the vocabulary seen by an EARLIER encode_text (the flag is written by the device, so it is known only
+// once that work has run): report once, then clear
+int check_async(plipmi_engine* e) {
+  if (e->bad_id && *reinterpret_cast<volatile int*>(e->bad_id) != 0) {
+    *reinterpret_cast<volatile int*>(e->bad_id) = 0;
+    return fail(PLIPMI_ERR_INVALID, "an earlier plipmi_encode_text on this handle was given a token id outside [0, %d) "
+                "(the reference's embedding lookup raises there, plip.py:68); its embeddings are invalid", e->cfg.vocab_size);
+  }
+  return PLIPMI_OK;
+}
 int check_batch(plipmi_engine* e, int B) {
   if (!e) return fail(PLIPMI_ERR_INVALID, "null handle");
+  RUN(check_async(e));
   if (B < 0 || B > e->cfg.max_batch)
     return fail(PLIPMI_ERR_INVALID, "batch %d outside [0, max_batch=%d]", B, e->cfg.max_batch);
   return PLIPMI_OK;
@@ -560,8 +532,10 @@ int plipmi_create(const plipmi_config* cfg, const plipmi_weights* w, void* strea
   if (!cfg || !w || !out) return fail(PLIPMI_ERR_INVALID, "null argument");
   *out = nullptr;
   const plipmi_config& g = *cfg;
-  if (g.compute_dtype != PLIPMI_F32 && g.compute_dtype != PLIPMI_BF16 && g.compute_dtype != PLIPMI_FP8W)
-    return fail(PLIPMI_ERR_INVALID, "compute_dtype must be PLIPMI_F32, PLIPMI_BF16 or PLIPMI_FP8W");
+  if (g.compute_dtype != PLIPMI_F32 && g.compute_dtype != PLIPMI_BF16 && g.compute_dtype != PLIPMI_F16)
+    return fail(PLIPMI_ERR_INVALID, "compute_dtype must be PLIPMI_F32, PLIPMI_BF16 or PLIPMI_F16");
+  if (g.flags & ~(PLIPMI_FLAG_SEPARATE_LAYERNORM | PLIPMI_FLAG_DENSE_LAST_BLOCK | PLIPMI_FLAG_PACK_CAPTIONS | PLIPMI_FLAG_VALU_ATTENTION))
+    return fail(PLIPMI_ERR_INVALID, "unknown bits in plipmi_config.flags (0x%x)", (unsigned)g.flags);
   if (g.v_heads <= 0 || g.t_heads <= 0 || g.v_width != g.v_heads * 64 || g.t_width != g.t_heads * 64)
     return fail(PLIPMI_ERR_INVALID, "head_dim must be 64 (v_width=%d/%d heads, t_width=%d/%d heads)", g.v_width,
                 g.v_heads, g.t_width, g.t_heads);
@@ -582,35 +556,24 @@ int plipmi_create(const plipmi_config* cfg, const plipmi_weights* w, void* strea
   if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
     return fail(PLIPMI_ERR_NODEVICE, "device %d is %s; libplipmi is built for gfx950 only", dev, prop.gcnArchName);
 
-  if (g.compute_dtype == PLIPMI_FP8W) {
-    // the fp8 GEMM tiles are 256 columns wide and 128 K deep
-    if (g.v_width % 128 || g.t_width % 128 || (3 * g.v_width) % 256 || (3 * g.t_width) % 256 || g.v_mlp % 256 || g.t_mlp % 256)
-      return fail(PLIPMI_ERR_INVALID, "fp8-weights mode needs widths that are multiples of 128 with 3*width and the MLP width multiples of 256");
-  }
   plipmi_engine* e = new plipmi_engine();
   e->cfg = g;
-  e->fp8w = g.compute_dtype == PLIPMI_FP8W;
-  e->dtype = e->fp8w ? PLIPMI_BF16 : g.compute_dtype;
-  e->esz = e->dtype == PLIPMI_BF16 ? 2 : 4;
-  { const char* lf = getenv("PLIPMI_LN_FOLD");
-    e->ln_fold = e->dtype == PLIPMI_BF16 && !e->fp8w && !(lf && atoi(lf) == 0);
-    const char* pl = getenv("PLIPMI_POOLED_LAST_BLOCK");
-    e->pooled_last = e->ln_fold && !(pl && atoi(pl) == 0);
-    const char* tp = getenv("PLIPMI_TEXT_PACKING");
-    e->text_pack = e->pooled_last && tp && atoi(tp) != 0; }
-  { const char* gb = getenv("PLIPMI_GRAPH_BATCH");
-    e->graph_batch_cap = std::min(g.max_batch, 32);
-    e->graph_batch = gb ? std::max(0, std::min(atoi(gb), e->graph_batch_cap)) : e->graph_batch_cap; }
+  e->dtype = g.compute_dtype;
+  e->esz = e->half() ? 2 : 4;
+  e->ln_fold = e->half() && !(g.flags & PLIPMI_FLAG_SEPARATE_LAYERNORM);
+  e->pooled_last = e->ln_fold && !(g.flags & PLIPMI_FLAG_DENSE_LAST_BLOCK);
+  e->text_pack = e->pooled_last && (g.flags & PLIPMI_FLAG_PACK_CAPTIONS);
+  e->graph_batch_cap = std::min(g.max_batch, 32);
+  e->graph_batch = g.graph_batch < 0 ? 0 : g.graph_batch == 0 ? e->graph_batch_cap : std::min(g.graph_batch, e->graph_batch_cap);
   e->np = tokens - 1;
   e->kpad = (int)align_up((size_t)3 * g.patch_size * g.patch_size, 64);
   snprintf(e->devname, sizeof(e->devname), "%s:%s", prop.gcnArchName, prop.name);
   e->vis.D = g.v_width; e->vis.F = g.v_mlp; e->vis.L = g.v_layers; e->vis.H = g.v_heads; e->vis.S = tokens;
   e->txt.D = g.t_width; e->txt.F = g.t_mlp; e->txt.L = g.t_layers; e->txt.H = g.t_heads; e->txt.S = g.context_length;
-  // attention kernel: exact-fp32 VALU kernel for the fp32 engine and for sequences > 128 tokens,
-  // bf16 MFMA kernel otherwise (PLIPMI_ATTENTION=0/1 forces one for A/B runs)
-  const char* ai = getenv("PLIPMI_ATTENTION");
-  e->attn_impl = ai ? atoi(ai) : PLIPMI_DEFAULT_ATTENTION;
-  if (e->dtype != PLIPMI_BF16) e->attn_impl = 0;
+  // attention kernel: exact-fp32 VALU kernel for the fp32 engine, MFMA kernels for the 16-bit engines
+  // (PLIPMI_FLAG_VALU_ATTENTION forces the VALU kernel for A/B runs)
+  e->attn_impl = (g.flags & PLIPMI_FLAG_VALU_ATTENTION) ? 0 : PLIPMI_DEFAULT_ATTENTION;
+  if (!e->half()) e->attn_impl = 0;
   e->attn_impl_txt = e->attn_impl ? 1 : 0;  // S <= 128: single-pass MFMA kernel, longer: chunked online softmax
   e->attn_impl_vis = e->attn_impl ? 1 : 0;
 
@@ -626,6 +589,8 @@ int plipmi_create(const plipmi_config* cfg, const plipmi_weights* w, void* strea
   Carver placing;
   placing.base = e->slab;
   carve(e, placing);
+  if (hipHostMalloc(reinterpret_cast<void**>(&e->bad_id), sizeof(int), hipHostMallocMapped) != hipSuccess) e->bad_id = nullptr;
+  else *e->bad_id = 0;
 
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   int rc = PLIPMI_OK;
@@ -653,6 +618,7 @@ int plipmi_create(const plipmi_config* cfg, const plipmi_weights* w, void* strea
   rc = body();
   if (rc != PLIPMI_OK) {
     hipFree(e->slab);
+    if (e->bad_id) hipHostFree(e->bad_id);
     delete e;
     return rc;
   }
@@ -668,6 +634,7 @@ void plipmi_destroy(plipmi_handle h) {
   if (h->cap_stream) hipStreamDestroy(h->cap_stream);
   if (h->slab) hipFree(h->slab);
   if (h->sim_ws) hipFree(h->sim_ws);
+  if (h->bad_id) hipHostFree(h->bad_id);
   delete h;
 }
 
@@ -715,7 +682,7 @@ int plipmi_set_graph_batch(plipmi_handle h, int max_batch) {
 int plipmi_set_text_packing(plipmi_handle h, int on) {
   if (!h) return fail(PLIPMI_ERR_INVALID, "null handle");
   if (on && !h->pooled_last)
-    return fail(PLIPMI_ERR_INVALID, "caption packing needs the bf16 engine's pooled last block (compute_dtype bf16, LayerNorm folding on)");
+    return fail(PLIPMI_ERR_INVALID, "caption packing needs a 16-bit engine's pooled last block (compute_dtype bf16 / f16, LayerNorm folding on, last block not dense)");
   if ((on != 0) != h->text_pack) {   // captured text forwards hold the other form's launches
     for (auto& kv : h->graphs) if (kv.second.exec) hipGraphExecDestroy(kv.second.exec);
     h->graphs.clear();
@@ -858,19 +825,7 @@ int plipmi_gemm_nt(int dtype, int epilogue, int variant, int M, int N, int K, co
 
 int plipmi_gemm_nt_traced(int dtype, int epilogue, int variant, int M, int N, int K, const void* A, const void* W,
                           const float* bias, float alpha, void* C, uint64_t* trace, void* stream) {
-  if (dtype == 2) {  // experimental: fp8 (e4m3fn) A and W, bf16 C, bias / bias+QuickGELU (gemm_fp8.hip)
-    if ((epilogue != EPI_BIAS && epilogue != EPI_BIAS_QGELU) || !bias || M < 0 || N <= 0 || K <= 0 || !A || !W || !C)
-      return fail(PLIPMI_ERR_INVALID, "fp8 gemm: bias / bias_qgelu epilogues only");
-    GemmParams p;
-    p.A = A; p.W = W; p.C = C; p.bias = bias; p.M = M; p.N = N; p.K = K; p.lda = K; p.ldw = K; p.ldc = N;
-    p.alpha = alpha; p.np = 1;
-    p.trace = reinterpret_cast<unsigned long long*>(trace);
-    const int rc = gemm_launch_fp8(epilogue, variant, p, reinterpret_cast<hipStream_t>(stream));
-    if (rc != 0) return fail(PLIPMI_ERR_HIP, "fp8 gemm launch failed (variant %d, M=%d N=%d K=%d): %s", variant, M, N, K,
-                             hipGetErrorString((hipError_t)rc));
-    return PLIPMI_OK;
-  }
-  if (dtype != PLIPMI_F32 && dtype != PLIPMI_BF16) return fail(PLIPMI_ERR_INVALID, "bad dtype");
+  if (dtype != PLIPMI_F32 && dtype != PLIPMI_BF16 && dtype != PLIPMI_F16) return fail(PLIPMI_ERR_INVALID, "bad dtype");
   if (epilogue < 0 || epilogue > EPI_SCALE) return fail(PLIPMI_ERR_INVALID, "epilogue must be 0..3");
   if (M < 0 || N <= 0 || K <= 0 || !A || !W || !C) return fail(PLIPMI_ERR_INVALID, "bad shape / null pointer");
   if (epilogue != EPI_SCALE && !bias) return fail(PLIPMI_ERR_INVALID, "bias required for this epilogue");
@@ -878,16 +833,17 @@ int plipmi_gemm_nt_traced(int dtype, int epilogue, int variant, int M, int N, in
   p.A = A; p.W = W; p.C = C; p.bias = bias; p.M = M; p.N = N; p.K = K; p.lda = K; p.ldw = K; p.ldc = N;
   p.alpha = alpha; p.np = 1;
   p.trace = reinterpret_cast<unsigned long long*>(trace);
-  const int rc = (variant == -3 && dtype == PLIPMI_BF16)     // -3: the small-M split-K kernel (gemm_skinny.hip)
-                     ? gemm_launch_skinny(epilogue, p, reinterpret_cast<hipStream_t>(stream), nullptr)
+  const int rc = (variant == -3 && dtype != PLIPMI_F32)     // -3: the small-M split-K kernel (gemm_skinny.hip)
+                     ? gemm_launch_skinny(dtype, epilogue, p, reinterpret_cast<hipStream_t>(stream), nullptr)
                      : gemm_launch(dtype, epilogue, variant, p, reinterpret_cast<hipStream_t>(stream), nullptr);
   if (rc != 0) return fail(PLIPMI_ERR_HIP, "gemm launch failed (variant %d, M=%d N=%d K=%d): %s", variant, M, N, K,
                            hipGetErrorString((hipError_t)rc));
   return PLIPMI_OK;
 }
 
-int plipmi_gemm_nt_ln(int mode, int variant, int M, int N, int K, const void* A, const void* W, const float* bias,
+int plipmi_gemm_nt_ln(int dtype, int mode, int variant, int M, int N, int K, const void* A, const void* W, const float* bias,
                       const float* stats, int ns, float eps, void* C, void* xb_out, float* st_out, void* stream) {
+  if (dtype != PLIPMI_BF16 && dtype != PLIPMI_F16) return fail(PLIPMI_ERR_INVALID, "LayerNorm-folded epilogues are 16-bit-engine forms");
   if (mode < 0 || mode > 3 || M < 0 || N <= 0 || K <= 0 || !A || !W || !C || !bias) return fail(PLIPMI_ERR_INVALID, "bad argument");
   if (mode < 2 && (!stats || ns <= 0)) return fail(PLIPMI_ERR_INVALID, "mode 0/1 need the row statistics");
   if (mode >= 2 && (!xb_out || !st_out || N % kLnSlice)) return fail(PLIPMI_ERR_INVALID, "mode 2/3 need xb_out, st_out and N % 64 == 0");
@@ -898,8 +854,8 @@ int plipmi_gemm_nt_ln(int mode, int variant, int M, int N, int K, const void* A,
   p.xb_out = xb_out; p.st_out = st_out;
   if (mode == 3) { p.lo_io = C; p.C = nullptr; }
   const int epi = mode == 0 ? EPI_BIAS_LN : mode == 1 ? EPI_QGELU_LN : mode == 2 ? EPI_RESID_EMIT : EPI_RESID_SPLIT;
-  const int rc = variant == -3 ? gemm_launch_skinny(epi, p, reinterpret_cast<hipStream_t>(stream), nullptr)
-                               : gemm_launch(PLIPMI_BF16, epi, variant, p, reinterpret_cast<hipStream_t>(stream), nullptr);
+  const int rc = variant == -3 ? gemm_launch_skinny(dtype, epi, p, reinterpret_cast<hipStream_t>(stream), nullptr)
+                               : gemm_launch(dtype, epi, variant, p, reinterpret_cast<hipStream_t>(stream), nullptr);
   if (rc != 0) return fail(PLIPMI_ERR_HIP, "gemm launch failed (LN mode %d, variant %d, M=%d N=%d K=%d): %s", mode, variant, M, N, K,
                            hipGetErrorString((hipError_t)rc));
   return PLIPMI_OK;
@@ -907,7 +863,7 @@ int plipmi_gemm_nt_ln(int mode, int variant, int M, int N, int K, const void* A,
 
 int plipmi_attention(int dtype, int impl, const void* qkv, void* out, int B, int S, int H, int causal,
                      const int64_t* key_mask, void* stream) {
-  if ((dtype != PLIPMI_F32 && dtype != PLIPMI_BF16) || !qkv || !out || B < 0 || S <= 0 || H <= 0)
+  if ((dtype != PLIPMI_F32 && dtype != PLIPMI_BF16 && dtype != PLIPMI_F16) || !qkv || !out || B < 0 || S <= 0 || H <= 0)
     return fail(PLIPMI_ERR_INVALID, "bad argument");
   hipError_t e = launch_attention(qkv, out, dtype, B, S, H, causal, key_mask, impl, reinterpret_cast<hipStream_t>(stream));
   if (e != hipSuccess) return fail(PLIPMI_ERR_HIP, "attention launch (impl %d, S=%d) failed: %s", impl, S, hipGetErrorString(e));
@@ -916,9 +872,9 @@ int plipmi_attention(int dtype, int impl, const void* qkv, void* out, int B, int
 
 int plipmi_gemm_nt_ld(int dtype, int epilogue, int variant, int M, int N, int K, const void* A, int lda, const void* W,
                       int ldw, const float* bias, float alpha, void* C, void* stream) {
-  if (dtype != PLIPMI_F32 && dtype != PLIPMI_BF16) return fail(PLIPMI_ERR_INVALID, "bad dtype");
+  if (dtype != PLIPMI_F32 && dtype != PLIPMI_BF16 && dtype != PLIPMI_F16) return fail(PLIPMI_ERR_INVALID, "bad dtype");
   if (epilogue < 0 || epilogue > EPI_SCALE) return fail(PLIPMI_ERR_INVALID, "epilogue must be 0..3");
-  const int per16 = dtype == PLIPMI_BF16 ? 8 : 4;
+  const int per16 = dtype == PLIPMI_F32 ? 4 : 8;
   if (M < 0 || N <= 0 || K <= 0 || !A || !W || !C || lda < K || ldw < K || lda % per16 || ldw % per16)
     return fail(PLIPMI_ERR_INVALID, "bad shape / leading dimension (must be >= K and a multiple of 16 bytes)");
   if (epilogue != EPI_SCALE && !bias) return fail(PLIPMI_ERR_INVALID, "bias required for this epilogue");
@@ -932,14 +888,23 @@ int plipmi_gemm_nt_ld(int dtype, int epilogue, int variant, int M, int N, int K,
 }
 
 void plipmi_set_gemm_variant(int variant) { gemm_set_default_override(variant); }
+void plipmi_set_gemm_store_wt(int on) { gemm_set_store_wt(on); }
 int plipmi_set_gemm_policy(plipmi_handle h, int policy) {
   if (!h) return fail(PLIPMI_ERR_INVALID, "null handle");
-  if (policy < 0 || policy > 3) return fail(PLIPMI_ERR_INVALID, "policy must be 0..3");
+  if (policy < 0 || policy > 5) return fail(PLIPMI_ERR_INVALID, "policy must be 0..5");
+  if (policy != h->gemm_policy) {   // captured forwards hold the other policy's tiles
+    for (auto& kv : h->graphs) if (kv.second.exec) hipGraphExecDestroy(kv.second.exec);
+    h->graphs.clear();
+  }
   h->gemm_policy = policy;
   return PLIPMI_OK;
 }
+int plipmi_check_async(plipmi_handle h) {
+  if (!h) return fail(PLIPMI_ERR_INVALID, "null handle");
+  return check_async(h);
+}
 int plipmi_gemm_variant_built(int dtype, int variant) {
-  if (dtype != PLIPMI_F32 && dtype != PLIPMI_BF16) return 0;
+  if (dtype != PLIPMI_F32 && dtype != PLIPMI_BF16 && dtype != PLIPMI_F16) return 0;
   return gemm_variant_is_built(dtype, variant) ? 1 : 0;
 }
 

@@ -7,8 +7,8 @@
 // (:148-154) and, with A = image embeds / W = text embeds, the logits (:814).
 //
 // gfx950 design
-//   * MFMA 32x32 tiles: v_mfma_f32_32x32x16_bf16 (bf16) or v_mfma_f32_32x32x2_f32
-//     (exact fp32, fmaf-chain numerics).  Operands are SWAPPED -- the weight
+//   * MFMA 32x32 tiles: v_mfma_f32_32x32x16_bf16 / _f16 (the two 16-bit engines) or
+//     v_mfma_f32_32x32x2_f32 (exact fp32, fmaf-chain numerics).  Operands are SWAPPED -- the weight
 //     fragment is the MFMA "A" operand and the activation fragment the "B"
 //     operand -- so a lane ends up with 4 CONSECUTIVE output columns of one
 //     output row per accumulator quad: 16-byte fp32 / 8-byte bf16 epilogue stores
@@ -17,11 +17,10 @@
 //     chunks; chunk c of row r lives at slot c ^ ((r>>1)&7).  With that XOR every
 //     ds_read_b128 lane group (MI355X_MICROARCH LDS table) touches 16 distinct
 //     16-byte slots of the 256-byte bank row: conflict-free fragment reads.
-//   * global -> LDS staging either through `global_load_lds_dwordx4` (LDS-DMA, the
-//     LDS image is lane-linear so the swizzle is applied to the per-lane SOURCE
-//     address) or through registers (global_load_dwordx4 + ds_write_b128 issued
-//     after the MFMA block, so HBM/L2 latency hides under compute).
-//   * double-buffered LDS, one barrier per K tile.
+//   * global -> LDS staging through LDS-DMA (`buffer_load_dwordx4 ... lds`, or `global_load_lds_dwordx4` for
+//     operands of 4 GiB and more): the LDS image is lane-linear, so the swizzle is applied to the per-lane SOURCE address.
+//   * two LDS stages (one tile of lookahead) or, where three fit in the 160 KB, a ring of three (two tiles of
+//     lookahead, counted vmcnt); one barrier per K tile either way.
 //   * blockIdx -> tile map is XCD-aware: hardware round-robins blocks over the 8
 //     XCDs, so block b is given logical tile (b%8)*ceil(n/8)+b/8 (bijective form)
 //     and each XCD's private L2 sees a contiguous strip of M tiles sweeping N.
@@ -40,7 +39,7 @@ enum Epilogue : int {
   EPI_BIAS_RESID = 2,  // C(f32) += acc + bias[n]            (in-place residual stream)
   EPI_SCALE = 3,       // C(f32) = alpha * acc
   EPI_PATCH = 4,       // C(f32)[img*(np+1)+1+p, n] = acc + pos[(1+p), n]   (m = img*np + p)
-  // LayerNorm folded into the GEMMs on either side of it (bf16 engine; modeling_clip.py:370-381: LN -> Linear):
+  // LayerNorm folded into the GEMMs on either side of it (16-bit engines; modeling_clip.py:370-381: LN -> Linear):
   //   the Linear's weights carry LayerNorm's gain AND its centring (W' = W * g with each row's mean over k removed, so
   //   x . W'^T == (x - mean(x)) . (W * g)^T: the mean subtraction happens inside the contraction), its bias carries
   //   LayerNorm's bias (c2 = W b + bias), the A operand is the bf16 residual stream itself, and only the row's rstd
@@ -72,9 +71,6 @@ struct GemmParams {
   int lda, ldw, ldc;  // in elements
   float alpha;
   int np;             // patches per image (EPI_PATCH)
-  // fp8 operands only: C = acc * row_scale[m] * col_scale[n] (+ bias ...); nullptr = 1
-  const float* row_scale = nullptr;
-  const float* col_scale = nullptr;
   // EPI_*_LN consumers: per-row statistics partials [M, ln_ns, 2] fp32 over 64-column slices of the LayerNorm input
   // (ln_combine; bias carries c2), 1/D and eps of that LayerNorm
   const float* ln_stats = nullptr;
@@ -99,6 +95,8 @@ struct GemmParams {
   // test hook (PLIPMI_GEMM_ABLATE, timeline runs only; results are wrong by construction):
   // bit 0 = skip the global->LDS fills of the K loop, bit 1 = skip the MFMA block, bit 2 = skip the epilogue
   int ablate = 0;
+  // output stores write through the XCD's L2 (sc0 sc1) instead of leaving dirty lines for the end-of-kernel write-back
+  int store_wt = 0;
 };
 
 // LDS-DMA (global_load_lds_dwordx4): each lane's 16 bytes at `gsrc` land at
@@ -180,23 +178,28 @@ __device__ __forceinline__ void glds16_buf_n(unsigned lds_base, unsigned soff, c
   }
 }
 __device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-
-// One 16-byte chunk of K per lane -> one (bf16) or four (fp32) MFMAs.
+// One 16-byte chunk of K per lane -> one (16-bit operand types) or four (fp32) MFMAs.
 template <typename T>
-__device__ __forceinline__ void mma16(f32x16& acc, const u32x4& wfrag, const u32x4& xfrag);
-
-template <>
-__device__ __forceinline__ void mma16<bf16_t>(f32x16& acc, const u32x4& wfrag, const u32x4& xfrag) {
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wfrag), __builtin_bit_cast(bf16x8, xfrag),
-                                                acc, 0, 0, 0);
-}
-template <>
-__device__ __forceinline__ void mma16<float>(f32x16& acc, const u32x4& wfrag, const u32x4& xfrag) {
-  // lane group g = lane>>5 holds k = 4*(2*kq+g)+j, j=0..3, for BOTH operands, so
-  // MFMA j multiplies matching k's (any k permutation shared by A and B is valid).
-  f32x4 w = __builtin_bit_cast(f32x4, wfrag), x = __builtin_bit_cast(f32x4, xfrag);
+__device__ __forceinline__ void mma16(f32x16& acc, const u32x4& wfrag, const u32x4& xfrag) {
+  if constexpr (sizeof(T) == 2) {
+    using X8 = typename half_traits<T>::x8;
+    acc = half_traits<T>::mfma32(__builtin_bit_cast(X8, wfrag), __builtin_bit_cast(X8, xfrag), acc);
+  } else {
+    // lane group g = lane>>5 holds k = 4*(2*kq+g)+j, j=0..3, for BOTH operands, so
+    // MFMA j multiplies matching k's (any k permutation shared by A and B is valid).
+    f32x4 w = __builtin_bit_cast(f32x4, wfrag), x = __builtin_bit_cast(f32x4, xfrag);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[j], x[j], acc, 0, 0, 0);
+    for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[j], x[j], acc, 0, 0, 0);
+  }
+}
+
+// 16-byte output store.  wt: write through the XCD's L2 (sc0 sc1) -- the line goes to the fabric now, while other
+// workgroups are still in their K loops, instead of staying dirty until the end-of-kernel write-back every launch
+// otherwise ends with (MI355X_MICROARCH.md, "boundary": + B / 6 TB/s for B dirty bytes).  The asm store ends with s_nop 1:
+// hipcc does not know the statement reads its data registers after issue (cdna_hip_programming.md 5.7 item 1).
+__device__ __forceinline__ void store16(void* ptr, const u32x4 v, bool wt) {
+  if (wt) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(ptr), "v"(v) : "memory");
+  else *reinterpret_cast<u32x4*>(ptr) = v;
 }
 
 // Epilogue split in a LOAD half (bias / residual / position rows; issued back to
@@ -204,6 +207,7 @@ __device__ __forceinline__ void mma16<float>(f32x16& acc, const u32x4& wfrag, co
 template <typename T, int EPI>
 struct EpilogueOp {
   static constexpr bool kAccurate = sizeof(T) == 4;
+  using OutT = std::conditional_t<sizeof(T) == 4, float, T>;
   __device__ __forceinline__ static float4 load(const GemmParams& p, int m, int n0) {
     if constexpr (epi_is_colwise(EPI)) {
       return *reinterpret_cast<const float4*>(p.bias + n0);
@@ -229,7 +233,6 @@ struct EpilogueOp {
         v0 = quick_gelu<kAccurate>(v0); v1 = quick_gelu<kAccurate>(v1);
         v2 = quick_gelu<kAccurate>(v2); v3 = quick_gelu<kAccurate>(v3);
       }
-      using OutT = std::conditional_t<sizeof(T) == 4, float, bf16_t>;
       store4(reinterpret_cast<OutT*>(p.C) + (size_t)m * p.ldc + n0, v0, v1, v2, v3);
     } else if constexpr (epi_is_resid(EPI)) {
       store4(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n0, add.x + v0, add.y + v1, add.z + v2, add.w + v3);
@@ -244,43 +247,46 @@ struct EpilogueOp {
   }
 };
 
-// BM x BN block tile, WM x WN waves, each wave a (BM/WM) x (BN/WN) sub-tile of 32x32 MFMA tiles.
-// SCHED 0: fragment reads / MFMAs in compiler order (it sinks every ds_read next to its first use);
-//       1: reads of K-step ks+1 pinned in front of the MFMAs of step ks (register double buffering);
-//       2: as 1, plus s_setprio 1 around each MFMA group;
-//       3: as 1, and the next K tile's LDS-DMA requests are issued in 4 parts, one in front of each K step's
-//          MFMA group, instead of all at once after the barrier.
-// L2PF d > 0: every K iteration also touches (one dword per 128-byte line) the K tile d steps further on, so
-//       the LDS-DMA fill that needs it later hits the XCD's L2 instead of paying a MALL/HBM round trip.
-//       The ablation timeline showed a K-tile fill taking ~2300 cycles on its own (latency, not bandwidth)
-//       against ~2050 cycles of MFMA work; with one tile of lookahead the two do not overlap fully.
-// NSTAGE 3 (LDS-DMA only): three LDS stages, the fill runs TWO K tiles ahead and the end-of-iteration wait is a
-//       counted vmcnt(PA+PW) (in-order retirement: the older tile has landed, the newest may still fly).
-// waves per SIMD the kernel is built for: 2 (LDS caps residency there, so let the allocator use 256 VGPRs), or
-// 1 for the 4-wave 256x256 form whose 128x128 wave tile keeps 256 accumulator registers (unified 512-entry file)
-template <int BM, int BN, int WM, int WN>
-constexpr int gemm_waves_per_simd() { return (WM * WN == 4 && BM * BN >= 256 * 256) ? 1 : 2; }
-
-template <typename T, int BM, int BN, int WM, int WN, int EPI, bool GLDS, int SCHED = 0, int L2PF = 0, int NSTAGE = 2, int ADDR = 0>
-__global__ __launch_bounds__(WM* WN * 64)
-__attribute__((amdgpu_waves_per_eu(gemm_waves_per_simd<BM, BN, WM, WN>(), gemm_waves_per_simd<BM, BN, WM, WN>())))
+// BM x BN block tile, WM x WN waves.  A wave owns (BN / WN) columns and a run of the tile's 32-row blocks: BM / 32 blocks
+// are dealt to the WM wave rows MI = ceil(BM / 32 / WM) at a time, so the LAST wave row may hold fewer (160 x 256 on 2 x 4
+// waves: 3 + 2 blocks).  Waves w and w + 4 of a workgroup share a SIMD (MI355X_MICROARCH.md, LDS section: dispatch order
+// 0->2->1->3), i.e. with WN = 4 every SIMD hosts one wave of each wave row and the MFMA work per SIMD stays even.
+// SCHED 0: fragment reads / MFMAs in compiler order, the whole fill issued at the top of the iteration;
+//       1: reads of K-step ks+1 pinned in front of the MFMAs of step ks (register double buffering), fill at the top;
+//       5 / 6: as 1, and the next fill's LDS-DMA requests are packed into the first 2 / 3 K steps of the iteration, one batch
+//          in front of each step's MFMA group, instead of queueing all of them on the texture-address unit at once.
+// NSTAGE 2: the fill runs ONE K tile ahead, the end-of-iteration wait is vmcnt(0);
+//        3: three LDS stages, the fill runs TWO K tiles ahead and the wait is a counted vmcnt (in-order retirement: the
+//           older tile has landed, the newest may still fly).  Needs 3 * (BM + BN) * 128 B of the 160 KB.
+// ADDR 0: 64-bit per-lane global addresses (any operand size); 1: buffer resource + 32-bit lane offset (< 4 GiB).
+// waves per SIMD the kernel is built for: 2 (LDS caps residency there, so let the allocator use 256 VGPRs)
+template <typename T, int BM, int BN, int WM, int WN, int EPI, int SCHED = 0, int NSTAGE = 2, int ADDR = 0>
+__global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void gemm_nt_kernel(const GemmParams p) {
   constexpr int NT = WM * WN * 64;
-  constexpr int TM = BM / WM, TN = BN / WN;
-  constexpr int MI = TM / 32, NI = TN / 32;
+  constexpr int RB = BM / 32;                  // 32-row blocks of the tile
+  constexpr int MI = (RB + WM - 1) / WM;       // ... per wave row (the last one may hold fewer)
+  constexpr bool kUneven = RB % WM != 0;
+  constexpr int TM = MI * 32, TN = BN / WN;
+  constexpr int NI = TN / 32;
   constexpr int ELEMS16 = 16 / sizeof(T);  // elements per 16-byte chunk
-  // fp8 operands (T = fp8_t, experimental): 128 K per 128-byte LDS row, bf16 outputs, v_mfma_scale_f32_32x32x64_f8f6f4
-  using OutT = std::conditional_t<sizeof(T) == 4, float, bf16_t>;
-  static_assert(sizeof(T) != 1 || ((EPI == EPI_BIAS || EPI == EPI_BIAS_QGELU) && GLDS && NSTAGE == 2 && L2PF == 0),
-                "the fp8 form exists for the bf16-output column-wise epilogues of the LDS-DMA kernels");
-  static_assert(!(epi_is_ln(EPI) || epi_emits_stats(EPI)) || sizeof(T) == 2, "LayerNorm folding is a bf16-engine form");
-  static_assert(!epi_is_ln(EPI) || NSTAGE == 2, "the row statistics are staged by the two-stage kernels' prologue");
+  using OutT = std::conditional_t<sizeof(T) == 4, float, T>;
+  static_assert(!(epi_is_ln(EPI) || epi_emits_stats(EPI)) || sizeof(T) == 2, "LayerNorm folding is a 16-bit-engine form");
+  static_assert(SCHED == 0 || SCHED == 1 || SCHED == 5 || SCHED == 6, "schedules: 0, 1, 5 (fill2), 6 (fill3)");
+  static_assert(NSTAGE == 2 || NSTAGE == 3, "two LDS stages or a ring of three");
+  constexpr bool kSpread = SCHED == 5 || SCHED == 6;
+  static_assert(!kSpread || ADDR == 1, "the spread fill batches buffer-form requests");
   constexpr int BK = 8 * ELEMS16;          // 128-byte rows
   constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, STAGE = A_BYTES + W_BYTES;
-  constexpr int PA = BM * 8 / NT, PW = BN * 8 / NT;  // 16-byte chunks per thread per tile
-  static_assert(TM % 32 == 0 && TN % 32 == 0, "wave tile must be a multiple of the 32x32 MFMA tile");
-  static_assert((BM * 8) % NT == 0 && (BN * 8) % NT == 0, "staging passes must be whole");
+  static_assert(NSTAGE * STAGE + (epi_is_ln(EPI) ? BM * 4 : 0) <= 160 * 1024, "LDS stages exceed the CU's 160 KB");
+  // 16-byte chunks per thread per tile.  A piece = one wave instruction = 8 rows; when BM * 8 is not a multiple of the
+  // thread count the last A piece exists for the first waves only (wave-uniform test a_piece(i))
+  constexpr int PA = (BM * 8 + NT - 1) / NT, PW = BN * 8 / NT;
+  constexpr int PA_MIN = BM * 8 / NT;      // pieces every wave issues (counted vmcnt of the 3-stage ring)
+  static_assert(BM % 32 == 0 && TN % 32 == 0, "wave tile must be a multiple of the 32x32 MFMA tile");
+  static_assert((BM * 8) % 64 == 0 && (BN * 8) % NT == 0, "staging passes must be whole wave pieces");
   static_assert((NT / 8) % 16 == 0, "swizzle term must not depend on the staging pass");
+  static_assert(PA == PA_MIN || (NT / 8) % 8 == 0, "partial last A pass: whole waves in or out");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -288,6 +294,10 @@ void gemm_nt_kernel(const GemmParams p) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
+  const int mi_w = kUneven ? (RB - wm * MI < MI ? RB - wm * MI : MI) : MI;   // this wave's 32-row blocks (wave-uniform)
+  auto a_piece = [&](int i) -> bool {      // does this wave own A piece i of a tile?
+    return PA == PA_MIN || i < PA_MIN || i * (NT / 8) + wave * 8 < BM;
+  };
 
   // ---- XCD-aware tile assignment (bijective for any block count) -------------
   const int nbn = p.N / BN;
@@ -326,7 +336,6 @@ void gemm_nt_kernel(const GemmParams p) {
   }
   const unsigned lds0 =
       __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem);
-  static_assert(ADDR == 0 || (GLDS && L2PF == 0), "buffer addressing is an LDS-DMA form");
   i32x4 rs_a, rs_w;
   unsigned a_off[PA], w_off[PW];
   if constexpr (ADDR == 1) {
@@ -339,6 +348,7 @@ void gemm_nt_kernel(const GemmParams p) {
   }
   unsigned koff = 0;  // ADDR 1: K byte offset of the tile being fetched (SGPR); advanced when its last piece is out
   auto dma_a = [&](int i, unsigned lds) {
+    if (!a_piece(i)) return;
     if constexpr (ADDR == 1) glds16_buf(rs_a, a_off[i], koff, lds);
     else { glds16(a_src[i], lds); a_src[i] += 128; }
   };
@@ -348,39 +358,20 @@ void gemm_nt_kernel(const GemmParams p) {
     if constexpr (ADDR == 1) { if (i == PW - 1) koff += 128; }  // W pieces follow the A pieces: PW-1 is a tile's last
   };
 
-  u32x4 ra[GLDS ? 1 : PA], rw[GLDS ? 1 : PW];
-
-  auto stage_issue = [&](int buf) {  // reads a_src/w_src, then advances them by one K tile
-    if constexpr (GLDS) {
-      const unsigned base = lds0 + buf * STAGE + wave * 1024;
-#pragma unroll
-      for (int i = 0; i < PA; ++i) dma_a(i, base + i * NT * 16);
-#pragma unroll
-      for (int i = 0; i < PW; ++i) dma_w(i, base + A_BYTES + i * NT * 16);
-      return;
-    } else {
-#pragma unroll
-      for (int i = 0; i < PA; ++i) ra[i] = *reinterpret_cast<const u32x4*>(a_src[i]);
-#pragma unroll
-      for (int i = 0; i < PW; ++i) rw[i] = *reinterpret_cast<const u32x4*>(w_src[i]);
-      // keep the loads HERE (ahead of the MFMA block); left alone, the scheduler sinks them next to
-      // the ds_writes that consume them and the prefetch distance collapses.
-      __builtin_amdgcn_sched_barrier(0);
-    }
-#pragma unroll
-    for (int i = 0; i < PA; ++i) a_src[i] += 128;
-#pragma unroll
-    for (int i = 0; i < PW; ++i) w_src[i] += 128;
-  };
-  // the same fill cut in 4 parts (one per K step of the MFMA block): SCHED 3 spreads the LDS-DMA issue over the
-  // iteration instead of queueing all PA+PW requests of every wave on the texture-address unit right after the barrier
-  // SCHED 5 / 6: the same requests packed into the first 2 / 3 K steps, so the last one has most of the iteration
-  // (not a quarter of it) to land before the end-of-iteration wait
-  constexpr int kFillParts = SCHED == 5 ? 2 : SCHED == 6 ? 3 : 4;
-  auto stage_issue_part = [&](int buf, int part) {
-    constexpr int PER = (PA + PW + kFillParts - 1) / kFillParts;
+  auto stage_issue = [&](int buf) {  // the whole tile at once; reads a_src/w_src (koff), then advances them by one K tile
     const unsigned base = lds0 + buf * STAGE + wave * 1024;
-    if constexpr (ADDR == 1) {
+#pragma unroll
+    for (int i = 0; i < PA; ++i) dma_a(i, base + i * NT * 16);
+#pragma unroll
+    for (int i = 0; i < PW; ++i) dma_w(i, base + A_BYTES + i * NT * 16);
+  };
+  // the same fill cut in parts, one per K step of the MFMA block (SCHED 5 / 6: packed into the first 2 / 3 K steps, so the
+  // last request has most of the iteration -- not a quarter of it -- to land before the end-of-iteration wait)
+  constexpr int kFillParts = SCHED == 5 ? 2 : 3;
+  auto stage_issue_part = [&](int buf, int part) {
+    const unsigned base = lds0 + buf * STAGE + wave * 1024;
+    if constexpr (ADDR == 1 && PA == PA_MIN) {
+      constexpr int PER = (PA + PW + kFillParts - 1) / kFillParts;
       // piece idx of the tile: resource, lane offset and (compile-time) LDS offset
       auto RS = [&](int idx) -> const i32x4& { return idx < PA ? rs_a : rs_w; };
       auto VO = [&](int idx) { return idx < PA ? a_off[idx < PA ? idx : 0] : w_off[idx - PA < PW ? (idx >= PA ? idx - PA : 0) : 0]; };
@@ -399,42 +390,30 @@ void gemm_nt_kernel(const GemmParams p) {
       if (part == 0) go(std::integral_constant<int, 0>{});
       else if (part == 1) go(std::integral_constant<int, 1>{});
       else if (part == 2) go(std::integral_constant<int, 2>{});
-      else go(std::integral_constant<int, 3>{});
+      return;
+    } else if constexpr (ADDR == 1) {
+      // partial last A pass: part 0 = this wave's A pieces (2 or 3 single requests), the W pieces split over the other parts
+      static_assert(PW % 2 == 0 && PW <= 8, "W pieces are batched in two halves");
+      constexpr int HW = PW / 2;
+      constexpr auto WO = [](int i) constexpr { return A_BYTES + i * NT * 16; };
+      if (part == 0) {
+#pragma unroll
+        for (int i = 0; i < PA; ++i)
+          if (a_piece(i)) glds16_buf(rs_a, a_off[i], koff, base + i * NT * 16);
+        if constexpr (kFillParts == 2)
+          glds16_buf_n<HW, WO(0), WO(HW > 1 ? 1 : 0), WO(HW > 2 ? 2 : 0), WO(HW > 3 ? 3 : 0)>(
+              base, koff, rs_w, w_off[0], rs_w, w_off[HW > 1 ? 1 : 0], rs_w, w_off[HW > 2 ? 2 : 0], rs_w, w_off[HW > 3 ? 3 : 0]);
+      } else if (part == kFillParts - 2 && kFillParts == 3) {
+        glds16_buf_n<HW, WO(0), WO(HW > 1 ? 1 : 0), WO(HW > 2 ? 2 : 0), WO(HW > 3 ? 3 : 0)>(
+            base, koff, rs_w, w_off[0], rs_w, w_off[HW > 1 ? 1 : 0], rs_w, w_off[HW > 2 ? 2 : 0], rs_w, w_off[HW > 3 ? 3 : 0]);
+      } else if (part == kFillParts - 1) {
+        glds16_buf_n<HW, WO(HW), WO(HW + (HW > 1 ? 1 : 0)), WO(HW + (HW > 2 ? 2 : 0)), WO(HW + (HW > 3 ? 3 : 0))>(
+            base, koff, rs_w, w_off[HW], rs_w, w_off[HW + (HW > 1 ? 1 : 0)], rs_w, w_off[HW + (HW > 2 ? 2 : 0)], rs_w,
+            w_off[HW + (HW > 3 ? 3 : 0)]);
+        koff += 128;
+      }
       return;
     }
-#pragma unroll
-    for (int e = 0; e < PER; ++e) {
-      const int idx = part * PER + e;  // compile-time after unrolling
-      if (idx < PA) dma_a(idx, base + idx * NT * 16);
-      else if (idx < PA + PW) dma_w(idx - PA, base + A_BYTES + (idx - PA) * NT * 16);
-    }
-  };
-  auto stage_commit = [&](int buf) {  // make the staged tile visible in LDS buffer `buf`
-    if constexpr (GLDS) {
-      wait_vm0();
-    } else {
-      char* base = smem + buf * STAGE;
-#pragma unroll
-      for (int i = 0; i < PA; ++i) *reinterpret_cast<u32x4*>(base + (i * NT + tid) * 16) = ra[i];
-#pragma unroll
-      for (int i = 0; i < PW; ++i) *reinterpret_cast<u32x4*>(base + A_BYTES + (i * NT + tid) * 16) = rw[i];
-    }
-  };
-
-  // ---- L2 prefetch: thread tid owns line tid of the (BM + BN)-row K tile ---------------------
-  unsigned touch = 0;  // destination of the touch loads; kept live so its register is never reused under them
-  const char* touch_ptr = nullptr;
-  if constexpr (L2PF > 0) {
-    const int line = tid < BM + BN ? tid : BM + BN - 1;  // every lane touches (no exec-masked wave may skip the op)
-    if (line < BM) {
-      const int r = m0 + line < Mrt ? m0 + line : Mrt - 1;
-      touch_ptr = reinterpret_cast<const char*>(p.A) + (size_t)r * p.lda * sizeof(T);
-    } else {
-      touch_ptr = reinterpret_cast<const char*>(p.W) + (size_t)(n0 + line - BM) * p.ldw * sizeof(T);
-    }
-  }
-  auto l2_touch = [&](int ktile) {
-    asm volatile("global_load_dword %0, %1, off" : "+v"(touch) : "v"(touch_ptr + (size_t)ktile * 128) : "memory");
   };
 
   // ---- fragment read offsets (lane-constant) -----------------------------------
@@ -457,9 +436,9 @@ void gemm_nt_kernel(const GemmParams p) {
   // epilogue operands in the row-contiguous layout of the transposed store (16 lanes x 16 B per output row)
   // Register budget (256 per lane at two waves per SIMD): accumulators + K-loop fragments + one operand block must
   // fit for the early request, accumulators + two operand blocks + the transposed values for the double buffer;
-  // the 192x256 tile affords both, 320x256 and the 4x2-wave 256x256 tile neither (they would spill).
+  // the 192x256 / 160x256 tiles afford both, 320x256 and the 4x2-wave 256x256 tile neither (they would spill).
   constexpr int kAccRegs = MI * NI * 16, kBlkRegs = (NI / 2) * 32;
-  constexpr bool kRowOperand = (epi_is_resid(EPI) || EPI == EPI_PATCH) && NSTAGE == 2 && sizeof(T) == 2 &&
+  constexpr bool kRowOperand = (epi_is_resid(EPI) || EPI == EPI_PATCH) && sizeof(T) == 2 &&
                                kAccRegs + 2 * (MI + NI) * 4 + kBlkRegs + 24 <= 256;
   constexpr int kAddBufs = (kAccRegs + 2 * kBlkRegs + 32 + 24 <= 256) ? 2 : 1;
   const int rd_row = lane >> 4, rd_col = (lane & 15) * 4;
@@ -468,7 +447,7 @@ void gemm_nt_kernel(const GemmParams p) {
   auto load_block = [&](int i, float4 (&dst)[NI / 2][8]) {
     if constexpr (EPI == EPI_RESID_SPLIT) {
       // the residual planes in 16-byte pieces: a lane owns 8 consecutive columns of a row (8 lanes = one 64-column slice),
-      // 8 rows per pass; dst[jp][2*it] = hi piece (8 bf16), dst[jp][2*it+1] = lo piece (8 int16), raw
+      // 8 rows per pass; dst[jp][2*it] = hi piece (8 x 16-bit operand type), dst[jp][2*it+1] = lo piece (8 int16), raw
 #pragma unroll
       for (int jp = 0; jp < NI / 2; ++jp)
 #pragma unroll
@@ -492,48 +471,8 @@ void gemm_nt_kernel(const GemmParams p) {
 
   auto compute = [&](int buf, int fill_buf) {
     const char* sb = smem + buf * STAGE;
-    if constexpr (sizeof(T) == 1) {
-      // fp8: one MFMA consumes 64 K = 32 bytes per lane = the 16-byte pieces of K steps 2h and 2h+1 (any k permutation
-      // shared by both operands is valid); two MFMAs per accumulator tile per 128-K tile, at twice the bf16 rate
-      u32x4 xa[2][MI][2], wa[2][NI][2];
-      auto fetch = [&](int h, int set) {
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-          xa[set][i][0] = *reinterpret_cast<const u32x4*>(sb + a_tile + i * 32 * 128 + foff[2 * h]);
-          xa[set][i][1] = *reinterpret_cast<const u32x4*>(sb + a_tile + i * 32 * 128 + foff[2 * h + 1]);
-        }
-#pragma unroll
-        for (int j = 0; j < NI; ++j) {
-          wa[set][j][0] = *reinterpret_cast<const u32x4*>(sb + w_tile + j * 32 * 128 + foff[2 * h]);
-          wa[set][j][1] = *reinterpret_cast<const u32x4*>(sb + w_tile + j * 32 * 128 + foff[2 * h + 1]);
-        }
-      };
-      fetch(0, 0);
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        if (h == 0) fetch(1, 1);
-        if constexpr ((SCHED == 3 || SCHED == 5 || SCHED == 6) && GLDS) {
-          if (fill_buf >= 0) {
-            if (h == 0) { stage_issue_part(fill_buf, 0); if (kFillParts > 2) stage_issue_part(fill_buf, 1); }
-            else { stage_issue_part(fill_buf, kFillParts > 2 ? 2 : 1); if (kFillParts > 3) stage_issue_part(fill_buf, 3); }
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-          for (int j = 0; j < NI; ++j) {
-            const i32x8 wv = {(int)wa[h][j][0][0], (int)wa[h][j][0][1], (int)wa[h][j][0][2], (int)wa[h][j][0][3],
-                              (int)wa[h][j][1][0], (int)wa[h][j][1][1], (int)wa[h][j][1][2], (int)wa[h][j][1][3]};
-            const i32x8 xv = {(int)xa[h][i][0][0], (int)xa[h][i][0][1], (int)xa[h][i][0][2], (int)xa[h][i][0][3],
-                              (int)xa[h][i][1][0], (int)xa[h][i][1][1], (int)xa[h][i][1][2], (int)xa[h][i][1][3]};
-            acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wv, xv, acc[i][j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
-          }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      return;
-    }
-    // fragments of K-step ks+1 are fetched from LDS before the MFMAs of step ks issue
+    // fragments of K-step ks+1 are fetched from LDS before the MFMAs of step ks issue.  (Rows past an uneven wave row's
+    // last block are read too -- in-bounds LDS bytes nobody multiplies -- so the reads stay branch-free.)
     u32x4 xf[2][MI], wf[2][NI];
 #pragma unroll
     for (int i = 0; i < MI; ++i) xf[0][i] = *reinterpret_cast<const u32x4*>(sb + a_tile + i * 32 * 128 + foff[0]);
@@ -549,50 +488,35 @@ void gemm_nt_kernel(const GemmParams p) {
         for (int j = 0; j < NI; ++j)
           wf[(ks + 1) & 1][j] = *reinterpret_cast<const u32x4*>(sb + w_tile + j * 32 * 128 + foff[ks + 1]);
       }
-      if constexpr ((SCHED == 3 || SCHED == 5 || SCHED == 6) && GLDS) {
+      if constexpr (kSpread) {
         if (fill_buf >= 0 && ks < kFillParts) stage_issue_part(fill_buf, ks);
       }
       if constexpr (SCHED >= 1) __builtin_amdgcn_sched_barrier(0);
-      if constexpr (SCHED == 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-      for (int i = 0; i < MI; ++i)
+      for (int i = 0; i < MI; ++i) {
+        if (kUneven && i >= mi_w) break;   // wave-uniform
 #pragma unroll
-        for (int j = 0; j < NI; ++j) {
-          if constexpr (sizeof(T) != 1) mma16<T>(acc[i][j], wf[ks & 1][j], xf[ks & 1][i]);
-        }
-      if constexpr (SCHED == 2) __builtin_amdgcn_s_setprio(0);
+        for (int j = 0; j < NI; ++j) mma16<T>(acc[i][j], wf[ks & 1][j], xf[ks & 1][i]);
+      }
       if constexpr (SCHED >= 1) __builtin_amdgcn_sched_barrier(0);
     }
   };
 
-  // SCHED 4 (3-stage ring only): the fragments of the NEXT K tile's first K step are read during the last K
-  // step of the current tile -- that tile has been visible since the previous barrier -- so no wave starts an
-  // iteration with an exposed LDS round trip behind the barrier.
-  u32x4 xfp[2][MI], wfp[2][NI];
-  auto load_frags = [&](int buf, int ks, int set) {
-    const char* sb = smem + buf * STAGE;
-#pragma unroll
-    for (int i = 0; i < MI; ++i) xfp[set][i] = *reinterpret_cast<const u32x4*>(sb + a_tile + i * 32 * 128 + foff[ks]);
-#pragma unroll
-    for (int j = 0; j < NI; ++j) wfp[set][j] = *reinterpret_cast<const u32x4*>(sb + w_tile + j * 32 * 128 + foff[ks]);
-  };
-  auto compute_x = [&](int buf, int next_buf) {  // set 0 already holds K step 0 of `buf`
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      if (ks < 3) load_frags(buf, ks + 1, (ks + 1) & 1);
-      else if (next_buf >= 0) load_frags(next_buf, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j) {
-          if constexpr (sizeof(T) != 1) mma16<T>(acc[i][j], wfp[ks & 1][j], xfp[ks & 1][i]);
-        }
-      __builtin_amdgcn_sched_barrier(0);
+  // rstd of this tile's BM LayerNorm-input rows goes to LDS once, while the first K tile is in flight: the epilogue
+  // then reads one float per row instead of walking the partials (a chain of L2 round trips per row) before the stores.
+  auto stage_ln_rows = [&]() {
+    if constexpr (epi_is_ln(EPI)) {
+      float* ln_rows = reinterpret_cast<float*>(smem + NSTAGE * STAGE);
+      for (int r = tid; r < BM; r += NT) {
+        const int mr = m0 + r < Mrt ? m0 + r : Mrt - 1;
+        float mu, rs;
+        ln_combine(p.ln_stats + (size_t)mr * p.ln_ns * 2, p.ln_ns, p.ln_inv_d, p.ln_eps, mu, rs);
+        ln_rows[r] = rs;
+      }
     }
   };
 
-  // ---- main loop: tile kt+1 streams in while tile kt is multiplied; one barrier per tile.
+  // ---- main loop: tiles kt+1 (and kt+2) stream in while tile kt is multiplied; one barrier per tile.
   const int KT = p.K / BK;
   unsigned long long* trace = p.trace ? p.trace + (size_t)bid * 8 : nullptr;
   unsigned long long trace_real0 = 0;
@@ -604,99 +528,57 @@ void gemm_nt_kernel(const GemmParams p) {
                ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20 /* XCC_ID [3:0] */) << 32);
     trace[6] = KT;
   }
-  if constexpr (NSTAGE == 3 && SCHED == 4) {
-    static_assert(SCHED != 4 || (GLDS && L2PF == 0), "cross-tile fragment prefetch needs the LDS-DMA 3-stage ring");
+  if constexpr (NSTAGE == 3) {
+    // ring of three: at the top of iteration kt tile kt is visible, tile kt+1 is landing or landed, and the fill of tile
+    // kt+2 goes into the stage every wave left at the last barrier.  The wait at the end of the iteration leaves one
+    // tile's requests of this wave outstanding (vmcnt retires in order): tile kt+1 has landed, tile kt+2 may still fly.
+    constexpr int kLeave = PA_MIN + PW;
     stage_issue(0);
     if (KT > 1) stage_issue(1);
-    wait_vm0();
-    __syncthreads();  // tiles 0 and 1 visible
-    if (trace && tid == 0) trace[1] = __builtin_amdgcn_s_memtime();
-    load_frags(0, 0, 0);
-    int cur = 0, nxt1 = 1, nxt2 = 2;
-    for (int kt = 0; kt < KT; ++kt) {
-      if (kt + 2 < KT) stage_issue(nxt2);          // stage of tile kt-1: every wave left it at the last barrier
-      compute_x(cur, kt + 1 < KT ? nxt1 : -1);
-      if (kt + 1 < KT) {
-        wait_vm0();                                // tile kt+2 landed (one whole iteration in flight)
-        __syncthreads();                           // ... and is visible; stage `cur` is free
-      }
-      const int tmp = cur; cur = nxt1; nxt1 = nxt2; nxt2 = tmp;
-    }
-  } else if constexpr (NSTAGE == 3) {
-    static_assert(NSTAGE != 3 || (GLDS && L2PF == 0 && SCHED != 3), "3-stage ring: LDS-DMA fills issued at the loop top");
-    stage_issue(0);
-    if (KT > 1) {
-      stage_issue(1);
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PA + PW) : "memory");  // tile 0 landed, tile 1 may be in flight
-    } else {
-      wait_vm0();
-    }
+    stage_ln_rows();
+    if (KT > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kLeave) : "memory");  // tile 0 landed, tile 1 may be in flight
+    else wait_vm0();
     __syncthreads();
     if (trace && tid == 0) trace[1] = __builtin_amdgcn_s_memtime();
     int cur = 0, nxt2 = 2;  // stage of tile kt, stage of tile kt+2
-    for (int kt = 0; kt < KT; ++kt) {
-      const bool fetch = kt + 2 < KT;
-      if (fetch && !(p.ablate & 1)) stage_issue(nxt2);
-      if (!(p.ablate & 2)) compute(cur, -1);
-      if (kt + 1 < KT) {
-        if (fetch) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PA + PW) : "memory");
-        else wait_vm0();
-        __syncthreads();  // tile kt+1 visible to all waves; stage `cur` free for tile kt+3
-      }
+    for (int kt = 0; kt < KT - 1; ++kt) {
+      const bool fetch = kt + 2 < KT && !(p.ablate & 1);
+      if constexpr (!kSpread) { if (fetch) stage_issue(nxt2); }
+      if (!(p.ablate & 2)) compute(cur, fetch ? nxt2 : -1);
+      if (fetch) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kLeave) : "memory");
+      else wait_vm0();
+      __syncthreads();  // tile kt+1 visible to all waves; stage `cur` free for tile kt+3
       cur = cur == 2 ? 0 : cur + 1;
       nxt2 = nxt2 == 2 ? 0 : nxt2 + 1;
     }
+    if constexpr (kRowOperand) {  // the residual / position rows of the first 32-row block travel during the last K tile
+      load_block(0, add[0]);
+      add_ready = true;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (!(p.ablate & 2)) compute(cur, -1);
   } else {
-  stage_issue(0);
-  if constexpr (epi_is_ln(EPI)) {
-    // rstd of this tile's BM LayerNorm-input rows goes to LDS once, while the first K tile is in flight: the epilogue
-    // then reads one float per row instead of walking the partials (a chain of L2 round trips per row) before the stores.
-    float* ln_rows = reinterpret_cast<float*>(smem + NSTAGE * STAGE);
-    for (int r = tid; r < BM; r += NT) {
-      const int mr = m0 + r < Mrt ? m0 + r : Mrt - 1;
-      float mu, rs;
-      ln_combine(p.ln_stats + (size_t)mr * p.ln_ns * 2, p.ln_ns, p.ln_inv_d, p.ln_eps, mu, rs);
-      ln_rows[r] = rs;
-    }
-  }
-  if constexpr (L2PF > 0) {
-#pragma unroll
-    for (int d = 1; d <= L2PF; ++d)
-      if (d < KT) l2_touch(d);
-  }
-  stage_commit(0);
-  __syncthreads();
-  if (trace && tid == 0) trace[1] = __builtin_amdgcn_s_memtime();
-  for (int kt = 0; kt < KT - 1; ++kt) {
-    const int cur = kt & 1;
-    if constexpr (!((SCHED == 3 || SCHED == 5 || SCHED == 6) && GLDS)) {
-      if (!(p.ablate & 1)) stage_issue(cur ^ 1);
-    }
-    bool touched = false;
-    if constexpr (L2PF > 0) {
-      touched = kt + 1 + L2PF < KT;  // uniform
-      if (touched) l2_touch(kt + 1 + L2PF);
-    }
-    if (!(p.ablate & 2)) compute(cur, (p.ablate & 1) ? -1 : (cur ^ 1));
-    if (GLDS && touched) {
-      // vmcnt retires in order: everything but the youngest op (the touch) done == the K tile has landed
-      asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-    } else {
-      stage_commit(cur ^ 1);
-    }
-    __syncthreads();
-  }
-  if constexpr (kRowOperand) {  // the residual / position rows of the first 32-row block travel during the last K step
-    load_block(0, add[0]);
-    add_ready = true;
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  if (!(p.ablate & 2)) compute((KT - 1) & 1, -1);
-  if constexpr (L2PF > 0) {
+    stage_issue(0);
+    stage_ln_rows();
     wait_vm0();
-    asm volatile("" ::"v"(touch));
+    __syncthreads();
+    if (trace && tid == 0) trace[1] = __builtin_amdgcn_s_memtime();
+    for (int kt = 0; kt < KT - 1; ++kt) {
+      const int cur = kt & 1;
+      if constexpr (!kSpread) {
+        if (!(p.ablate & 1)) stage_issue(cur ^ 1);
+      }
+      if (!(p.ablate & 2)) compute(cur, (p.ablate & 1) ? -1 : (cur ^ 1));
+      wait_vm0();
+      __syncthreads();
+    }
+    if constexpr (kRowOperand) {  // the residual / position rows of the first 32-row block travel during the last K step
+      load_block(0, add[0]);
+      add_ready = true;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (!(p.ablate & 2)) compute((KT - 1) & 1, -1);
   }
-  }  // NSTAGE == 2
   if (trace && tid == 0) trace[2] = __builtin_amdgcn_s_memtime();
 
   // ---- epilogue -------------------------------------------------------------------------------
@@ -705,25 +587,26 @@ void gemm_nt_kernel(const GemmParams p) {
   // pieces), and the in-kernel timeline showed that costing 22-34k cycles per 256x256 tile -- a third of the
   // workgroup's lifetime.  So each wave transposes its sub-tile through a private LDS slab (32 rows x 64
   // columns fp32, row pitch 272 B: conflict-free ds_write_b128) and writes it back ROW-contiguous: 16 lanes
-  // cover 256 B (fp32) / 128 B (bf16) of one row, so loads/stores are whole cache lines.
+  // cover 256 B (fp32) / 128 B (16-bit) of one row, so loads/stores are whole cache lines.
   constexpr int SLAB_PITCH = 64 * 4 + 16;
   constexpr int SLAB_BYTES = 32 * SLAB_PITCH;
   static_assert(WM * WN * SLAB_BYTES <= NSTAGE * STAGE, "epilogue slabs must fit in the staging buffers");
   static_assert(NI % 2 == 0, "epilogue handles two 32-column MFMA tiles per slab");
   __syncthreads();  // every wave is done reading the last K tile: the staging LDS can be reused
   if (p.ablate & 4) return;
+  const bool wt = p.store_wt != 0;
   char* slab = smem + wave * SLAB_BYTES;
-  if constexpr (sizeof(T) <= 2 && epi_is_colwise(EPI)) {
-    // bf16 outputs whose epilogue is column-wise (bias, QuickGELU): finish the arithmetic in the ACCUMULATOR layout
+  if constexpr (sizeof(T) == 2 && epi_is_colwise(EPI)) {
+    // 16-bit outputs whose epilogue is column-wise (bias, QuickGELU): finish the arithmetic in the ACCUMULATOR layout
     // -- the bias of a lane's 4 x 4 columns per MFMA tile is loaded once per tile column, not once per output row --
-    // round to bf16 there, and transpose HALF the bytes: 8 ds_write_b64 + 4 ds_read_b128 + 4 16-byte global stores
+    // round there, and transpose HALF the bytes: 8 ds_write_b64 + 4 ds_read_b128 + 4 16-byte global stores
     // per 32 x 64 slab instead of 8 ds_write_b128 + 8 ds_read_b128 + 8 bias loads + 8 8-byte stores.
-    // bf16 slab: 32 rows x 128 B, no padding.  16-byte chunk c of row r sits in slot c ^ (r & 7) and, for rows with
+    // 16-bit slab: 32 rows x 128 B, no padding.  16-byte chunk c of row r sits in slot c ^ (r & 7) and, for rows with
     // bit 3 set, its two 8-byte halves are swapped: the transposing ds_write_b64 (16 consecutive rows, same column)
     // then covers all 32 write banks once, the row-contiguous ds_read_b128 all 64 read banks once
     // (SQ_LDS_BANK_CONFLICT = 0); the half swap is undone in registers, statically per store iteration.
     constexpr int HP = 128;
-    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+    using X4 = typename half_traits<OutT>::x4;
     float4 bq[NI][4];
 #pragma unroll
     for (int j = 0; j < NI; ++j)
@@ -731,23 +614,9 @@ void gemm_nt_kernel(const GemmParams p) {
       for (int q = 0; q < 4; ++q)
         bq[j][q] = *reinterpret_cast<const float4*>(p.bias + n0 + wn * TN + j * 32 + 8 * q + 4 * lgrp);
     const int hr_row = lane >> 3, hr_chunk = lane & 7;  // 8 lanes x 16 B = one 128-byte output row piece
-    const bool scaled = sizeof(T) == 1 && p.row_scale != nullptr && p.col_scale != nullptr;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
-      if constexpr (sizeof(T) == 1) {
-        if (scaled) {  // dequantise: one scale per output row (this lane's row of the block) x one per column
-          const int mr = m0 + wm * TM + i * 32 + lrow;
-          const float sa = p.row_scale[mr < Mrt ? mr : Mrt - 1];
-#pragma unroll
-          for (int j = 0; j < NI; ++j)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const float4 sw = *reinterpret_cast<const float4*>(p.col_scale + n0 + wn * TN + j * 32 + 8 * q + 4 * lgrp);
-              acc[i][j][4 * q + 0] *= sa * sw.x; acc[i][j][4 * q + 1] *= sa * sw.y;
-              acc[i][j][4 * q + 2] *= sa * sw.z; acc[i][j][4 * q + 3] *= sa * sw.w;
-            }
-        }
-      }
+      if (kUneven && i >= mi_w) break;   // wave-uniform
       float ln_rs = 1.f;
       if constexpr (epi_is_ln(EPI))  // this lane's row of the block: rstd of the LayerNorm input row (staged at kernel start)
         ln_rs = *reinterpret_cast<const float*>(smem + NSTAGE * STAGE + (wm * TM + i * 32 + lrow) * 4);
@@ -770,9 +639,9 @@ void gemm_nt_kernel(const GemmParams p) {
               v0 = quick_gelu<false>(v0); v1 = quick_gelu<false>(v1);
               v2 = quick_gelu<false>(v2); v3 = quick_gelu<false>(v3);
             }
-            const bf16x4 pk = {(bf16_t)v0, (bf16_t)v1, (bf16_t)v2, (bf16_t)v3};
-            *reinterpret_cast<bf16x4*>(slab + lrow * HP + (((jj * 4 + q) ^ (lrow & 7)) << 4) +
-                                       ((lgrp ^ ((lrow >> 3) & 1)) << 3)) = pk;
+            const X4 pk = {from_f32<OutT>(v0), from_f32<OutT>(v1), from_f32<OutT>(v2), from_f32<OutT>(v3)};
+            *reinterpret_cast<X4*>(slab + lrow * HP + (((jj * 4 + q) ^ (lrow & 7)) << 4) +
+                                   ((lgrp ^ ((lrow >> 3) & 1)) << 3)) = pk;
           }
         __builtin_amdgcn_wave_barrier();
         u32x4 o[4];
@@ -787,13 +656,14 @@ void gemm_nt_kernel(const GemmParams p) {
           const bool in_range = m < Mrt;
           if (p.ablate & 32) m &= 255;  // timeline experiment: every tile stores to the same 256 rows (L2-resident)
           if (in_range)
-            *reinterpret_cast<u32x4*>(reinterpret_cast<OutT*>(p.C) + (size_t)m * p.ldc + n0 + wn * TN + jp * 64 + hr_chunk * 8) = o[it];
+            store16(reinterpret_cast<OutT*>(p.C) + (size_t)m * p.ldc + n0 + wn * TN + jp * 64 + hr_chunk * 8, o[it], wt);
         }
         __builtin_amdgcn_wave_barrier();
       }
     }
     if (trace) {
       __builtin_amdgcn_s_waitcnt(0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (tid == 0) {
         trace[3] = __builtin_amdgcn_s_memtime();
         trace[7] = (trace_real0 & 0xffffffffull) | ((__builtin_amdgcn_s_memrealtime() - trace_real0) << 32);
@@ -806,8 +676,9 @@ void gemm_nt_kernel(const GemmParams p) {
   if (!add_ready) load_block(0, add[0]);
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
+    if (kUneven && i >= mi_w) break;   // wave-uniform
     if constexpr (kAddBufs == 2) {
-      if (i + 1 < MI) load_block(i + 1, add[(i + 1) & 1]);
+      if (i + 1 < MI && !(kUneven && i + 1 >= mi_w)) load_block(i + 1, add[(i + 1) & 1]);
     } else {
       if (i > 0) load_block(i, add[0]);
     }
@@ -842,8 +713,8 @@ void gemm_nt_kernel(const GemmParams p) {
           float o[8];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            o[2 * e] = join_f32(h[e] & 0xffffu, l[e] & 0xffffu);
-            o[2 * e + 1] = join_f32(h[e] >> 16, l[e] >> 16);
+            o[2 * e] = join_f32<T>(h[e] & 0xffffu, l[e] & 0xffffu);
+            o[2 * e + 1] = join_f32<T>(h[e] >> 16, l[e] >> 16);
           }
           // (residual + bias) + product: the order of the plain-array epilogues, so the stream is bit-identical to theirs
           o[0] = (o[0] + b0.x) + va[it][0]; o[1] = (o[1] + b0.y) + va[it][1]; o[2] = (o[2] + b0.z) + va[it][2];
@@ -860,14 +731,14 @@ void gemm_nt_kernel(const GemmParams p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               unsigned ha, la, hb, lb;
-              split_f32(o[2 * e], ha, la);
-              split_f32(o[2 * e + 1], hb, lb);
+              split_f32<T>(o[2 * e], ha, la);
+              split_f32<T>(o[2 * e + 1], hb, lb);
               ho[e] = ha | (hb << 16);
               lo4[e] = la | (lb << 16);
             }
             const size_t off = (size_t)m * p.ldc + nn;
-            *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(p.xb_out) + off) = ho;
-            *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(p.lo_io) + off) = lo4;
+            store16(reinterpret_cast<unsigned short*>(p.xb_out) + off, ho, wt);
+            store16(reinterpret_cast<unsigned short*>(p.lo_io) + off, lo4, wt);
             if ((lane & 7) == 0)
               *reinterpret_cast<float2*>(p.st_out + ((size_t)m * (p.N / kLnSlice) + (n0 + wn * TN + jp * 64) / kLnSlice) * 2) =
                   make_float2(ssum, m2);
@@ -888,7 +759,7 @@ void gemm_nt_kernel(const GemmParams p) {
         if (p.ablate & 32) m &= 255;  // timeline experiment: every tile stores to the same 256 rows (L2-resident)
         if constexpr (EPI == EPI_RESID_EMIT) {
           // the updated residual row piece (4 columns per lane, 16 lanes = one 64-column slice of one row): fp32 in
-          // place, its bf16 copy for the next GEMM's A operand, and the slice's LayerNorm partials {sum, centred M2}
+          // place, its 16-bit copy for the next GEMM's A operand, and the slice's LayerNorm partials {sum, centred M2}
           // (EPI_RESID_SPLIT has its own block above)
           const float4 a4 = add[kAddBufs == 2 ? (i & 1) : 0][jp][it];
           const float o0 = a4.x + v[it][0], o1 = a4.y + v[it][1], o2 = a4.z + v[it][2], o3 = a4.w + v[it][3];
@@ -898,7 +769,7 @@ void gemm_nt_kernel(const GemmParams p) {
           const float m2 = row16_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
           if (in_range) {
             store4(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n, o0, o1, o2, o3);
-            store4(reinterpret_cast<bf16_t*>(p.xb_out) + (size_t)m * p.ldc + n, o0, o1, o2, o3);
+            store4(reinterpret_cast<OutT*>(p.xb_out) + (size_t)m * p.ldc + n, o0, o1, o2, o3);
             if ((lane & 15) == 0)
               *reinterpret_cast<float2*>(p.st_out + ((size_t)m * (p.N / kLnSlice) + (n0 + wn * TN + jp * 64) / kLnSlice) * 2) =
                   make_float2(ssum, m2);
@@ -912,6 +783,7 @@ void gemm_nt_kernel(const GemmParams p) {
   }
   if (trace) {
     __builtin_amdgcn_s_waitcnt(0);  // stores issued and acknowledged before the stamp
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (tid == 0) {
       trace[3] = __builtin_amdgcn_s_memtime();
       trace[7] = (trace_real0 & 0xffffffffull) | ((__builtin_amdgcn_s_memrealtime() - trace_real0) << 32);
@@ -941,22 +813,21 @@ __global__ void gemm_nt_naive_kernel(const GemmParams p) {
 struct GemmVariant {
   const char* name;
   int bm, bn, threads;
-  bool glds;
 };
 int gemm_num_variants();
 const GemmVariant& gemm_variant(int v);
-// dtype: 0 fp32, 1 bf16.  variant -1 = auto, -2 = naive.  Returns hipError_t as int; *kernel_name (optional)
+// dtype: 0 fp32, 1 bf16, 2 f16.  variant -1 = auto, -2 = naive.  Returns hipError_t as int; *kernel_name (optional)
 // receives a static string naming the kernel that ran.
 // policy (tile choice of variant -1): 0 = wave-quantisation cost model (kernels own the GPU one at a time),
-// 1..3 = the caller co-schedules the two towers on two streams (fixed tile per epilogue, see gemm.hip)
+// 1 = the caller co-schedules the two towers on two streams (fixed tile per epilogue, see gemm.hip)
 int gemm_launch(int dtype, int epi, int variant, const GemmParams& p, hipStream_t stream, const char** kernel_name,
                 int policy = 0);
 int gemm_default_variant(int dtype, int M, int N, int K, int epi = -1, int policy = 0);
 bool gemm_variant_is_built(int dtype, int variant);
-int gemm_launch_fp8(int epi, int variant, const GemmParams& p, hipStream_t stream);  // experimental test hook
-// small-M bf16 kernel (gemm_skinny.hip): 32 x 64 output tile per workgroup, K split over its four waves, operands from L2
+// small-M kernel of the 16-bit engines (gemm_skinny.hip): 32 x 64 output tile per workgroup, K split over its waves
 bool gemm_skinny_supports(int epi, int M, int N, int K);
-int gemm_launch_skinny(int epi, const GemmParams& p, hipStream_t stream, const char** kernel_name);
+int gemm_launch_skinny(int dtype, int epi, const GemmParams& p, hipStream_t stream, const char** kernel_name);
 void gemm_set_default_override(int variant);  // PLIPMI_GEMM_VARIANT / tests (process-wide A/B hook, not a product knob)
+void gemm_set_store_wt(int on);               // experiment hook: write-through epilogue stores (process-wide)
 
 }  // namespace plipmi

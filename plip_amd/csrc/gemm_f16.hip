@@ -1,0 +1,6 @@
+// f16 instantiations (v_mfma_f32_32x32x16_f16, fp32 accumulate) of the NT GEMM.
+#include "gemm_inst.h"
+namespace plipmi {
+GemmLaunchFn gemm_get_f16(int variant, int epi) { return GemmTable<f16_t>::get(variant, epi); }
+bool gemm_built_f16(int variant) { return gemm_variant_built<f16_t>(variant); }
+}  // namespace plipmi

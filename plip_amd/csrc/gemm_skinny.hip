@@ -1,4 +1,4 @@
-// gemm_skinny.hip -- the NT GEMM for SMALL M (latency regime):  C = epilogue(A[M,K] . W[N,K]^T), bf16 operands.
+// gemm_skinny.hip -- the NT GEMM for SMALL M (latency regime):  C = epilogue(A[M,K] . W[N,K]^T), 16-bit operands (bf16 / f16).
 //
 // Where the big-tile kernel (gemm.h) walks K one 64-deep tile after the other on a handful of workgroups -- M = 256
 // rows x N = 768 is 12 workgroups of 128x128, each 48 dependent K iterations for fc2 = 35-55 us -- this kernel spends
@@ -25,8 +25,9 @@ namespace {
 
 constexpr int SK_BM = 32, SK_BN = 64, SK_PITCH = 68;   // floats per LDS row of a partial tile (272 B: conflict-free b128)
 
-template <int EPI, int NW, int NB>
+template <typename T, int EPI, int NW, int NB>
 __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(const GemmParams p) {
+  using X8 = typename half_traits<T>::x8;
   __shared__ __attribute__((aligned(16))) float part[NW][SK_BM][SK_PITCH];
   __shared__ float rs_s[SK_BM];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -35,9 +36,9 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(const GemmParams p
   const int n0 = blockIdx.x * SK_BN, m0 = blockIdx.y * SK_BM;
   const int kw = p.K / NW;                                   // this wave's share of K (a multiple of 64 * NB)
   const int mr = m0 + lrow < p.M ? m0 + lrow : p.M - 1;      // M edge: re-read the last row, stores are masked
-  const bf16_t* ap = reinterpret_cast<const bf16_t*>(p.A) + (size_t)mr * p.lda + wave * kw + 32 * hi;
-  const bf16_t* w0 = reinterpret_cast<const bf16_t*>(p.W) + (size_t)(n0 + lrow) * p.ldw + wave * kw + 32 * hi;
-  const bf16_t* w1 = w0 + (size_t)32 * p.ldw;
+  const T* ap = reinterpret_cast<const T*>(p.A) + (size_t)mr * p.lda + wave * kw + 32 * hi;
+  const T* w0 = reinterpret_cast<const T*>(p.W) + (size_t)(n0 + lrow) * p.ldw + wave * kw + 32 * hi;
+  const T* w1 = w0 + (size_t)32 * p.ldw;
 
   if constexpr (epi_is_ln(EPI)) {                            // rstd of the tile's rows, while the first operands travel
     if (tid < SK_BM) {
@@ -69,8 +70,8 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(const GemmParams p
     for (int b = 0; b < NB; ++b)
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wa[b][t]), __builtin_bit_cast(bf16x8, xa[b][t]), acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wb[b][t]), __builtin_bit_cast(bf16x8, xa[b][t]), acc1, 0, 0, 0);
+        acc0 = half_traits<T>::mfma32(__builtin_bit_cast(X8, wa[b][t]), __builtin_bit_cast(X8, xa[b][t]), acc0);
+        acc1 = half_traits<T>::mfma32(__builtin_bit_cast(X8, wb[b][t]), __builtin_bit_cast(X8, xa[b][t]), acc1);
       }
   }
   // partial tile of this wave, row-major: acc[4q+e] = C[m = lrow][n = 8q + 4hi + e] of its 32-column half
@@ -101,17 +102,16 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(const GemmParams p
   const bool in_range = m < p.M;
   const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n), b1 = *reinterpret_cast<const float4*>(p.bias + n + 4);
   const float bias[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-  typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8v;
   if constexpr (epi_is_colwise(EPI)) {
     const float rs = epi_is_ln(EPI) ? rs_s[r] : 1.0f;
-    bf16x8v o;
+    X8 o;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       float y = fmaf(rs, v[e], bias[e]);
       if constexpr (EPI == EPI_BIAS_QGELU || EPI == EPI_QGELU_LN) y = quick_gelu<false>(y);
-      o[e] = (bf16_t)y;
+      o[e] = from_f32<T>(y);
     }
-    if (in_range) *reinterpret_cast<bf16x8v*>(reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + n) = o;
+    if (in_range) *reinterpret_cast<X8*>(reinterpret_cast<T*>(p.C) + (size_t)m * p.ldc + n) = o;
   } else {
     static_assert(epi_is_resid(EPI), "skinny epilogues: bias / QuickGELU (optionally LayerNorm-folded) and the residual forms");
     float* crow = reinterpret_cast<float*>(p.C) + (size_t)(in_range ? m : p.M - 1) * p.ldc + n;
@@ -132,37 +132,37 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(const GemmParams p
       for (int e = 0; e < 8; ++e) { const float d = o[e] - mj; q += d * d; }
       const float m2 = row8_sum(q);
       if (in_range) {
-        bf16x8v ob;
+        X8 ob;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) ob[e] = (bf16_t)o[e];
-        *reinterpret_cast<bf16x8v*>(reinterpret_cast<bf16_t*>(p.xb_out) + (size_t)m * p.ldc + n) = ob;
+        for (int e = 0; e < 8; ++e) ob[e] = from_f32<T>(o[e]);
+        *reinterpret_cast<X8*>(reinterpret_cast<T*>(p.xb_out) + (size_t)m * p.ldc + n) = ob;
         if ((tid & 7) == 0) *reinterpret_cast<float2*>(p.st_out + ((size_t)m * (p.N / kLnSlice) + n0 / kLnSlice) * 2) = make_float2(ssum, m2);
       }
     }
   }
 }
 
-template <int EPI, int NW, int NB>
+template <typename T, int EPI, int NW, int NB>
 int launch_skinny_nb(const GemmParams& p, hipStream_t s) {
   const dim3 grid(p.N / SK_BN, (p.M + SK_BM - 1) / SK_BM);
-  hipLaunchKernelGGL((gemm_skinny_kernel<EPI, NW, NB>), grid, dim3(64 * NW), 0, s, p);
+  hipLaunchKernelGGL((gemm_skinny_kernel<T, EPI, NW, NB>), grid, dim3(64 * NW), 0, s, p);
   return (int)hipGetLastError();
 }
 // K split: 8 waves when each still gets whole 64-deep blocks, else 4; blocks requested together: 3, 2 or 1.  The choice
 // depends on K only (never on M): a row's bits do not depend on the batch it arrives in.
-template <int EPI>
+template <typename T, int EPI>
 int launch_skinny(const GemmParams& p, hipStream_t s) {
   const int blocks = p.K / 64;
   if (blocks % 8 == 0) {
     const int nb = blocks / 8;
-    if (nb % 3 == 0) return launch_skinny_nb<EPI, 8, 3>(p, s);
-    if (nb % 2 == 0) return launch_skinny_nb<EPI, 8, 2>(p, s);
-    return launch_skinny_nb<EPI, 8, 1>(p, s);
+    if (nb % 3 == 0) return launch_skinny_nb<T, EPI, 8, 3>(p, s);
+    if (nb % 2 == 0) return launch_skinny_nb<T, EPI, 8, 2>(p, s);
+    return launch_skinny_nb<T, EPI, 8, 1>(p, s);
   }
   const int nb = blocks / 4;
-  if (nb % 3 == 0) return launch_skinny_nb<EPI, 4, 3>(p, s);
-  if (nb % 2 == 0) return launch_skinny_nb<EPI, 4, 2>(p, s);
-  return launch_skinny_nb<EPI, 4, 1>(p, s);
+  if (nb % 3 == 0) return launch_skinny_nb<T, EPI, 4, 3>(p, s);
+  if (nb % 2 == 0) return launch_skinny_nb<T, EPI, 4, 2>(p, s);
+  return launch_skinny_nb<T, EPI, 4, 1>(p, s);
 }
 
 }  // namespace
@@ -173,23 +173,31 @@ bool gemm_skinny_supports(int epi, int M, int N, int K) {
   return epi_ok && M > 0 && N % SK_BN == 0 && K % 256 == 0;
 }
 
-int gemm_launch_skinny(int epi, const GemmParams& p, hipStream_t s, const char** kernel_name) {
-  if (p.M <= 0) return 0;
-  if (!gemm_skinny_supports(epi, p.M, p.N, p.K) || p.lda % 8 || p.ldw % 8) return (int)hipErrorInvalidValue;
-  static const char* names[EPI_COUNT] = {"gemm_skinny<bf16,32x64_splitk,bias>", "gemm_skinny<bf16,32x64_splitk,bias_qgelu>",
-                                         "gemm_skinny<bf16,32x64_splitk,bias_resid>", nullptr, nullptr,
-                                         "gemm_skinny<bf16,32x64_splitk,ln_bias>", "gemm_skinny<bf16,32x64_splitk,ln_qgelu>",
-                                         "gemm_skinny<bf16,32x64_splitk,resid_emit>", nullptr};
-  if (kernel_name) *kernel_name = names[epi];
+template <typename T>
+static int launch_skinny_epi(int epi, const GemmParams& p, hipStream_t s) {
   switch (epi) {
-    case EPI_BIAS: return launch_skinny<EPI_BIAS>(p, s);
-    case EPI_BIAS_QGELU: return launch_skinny<EPI_BIAS_QGELU>(p, s);
-    case EPI_BIAS_RESID: return launch_skinny<EPI_BIAS_RESID>(p, s);
-    case EPI_BIAS_LN: return launch_skinny<EPI_BIAS_LN>(p, s);
-    case EPI_QGELU_LN: return launch_skinny<EPI_QGELU_LN>(p, s);
-    case EPI_RESID_EMIT: return launch_skinny<EPI_RESID_EMIT>(p, s);
+    case EPI_BIAS: return launch_skinny<T, EPI_BIAS>(p, s);
+    case EPI_BIAS_QGELU: return launch_skinny<T, EPI_BIAS_QGELU>(p, s);
+    case EPI_BIAS_RESID: return launch_skinny<T, EPI_BIAS_RESID>(p, s);
+    case EPI_BIAS_LN: return launch_skinny<T, EPI_BIAS_LN>(p, s);
+    case EPI_QGELU_LN: return launch_skinny<T, EPI_QGELU_LN>(p, s);
+    case EPI_RESID_EMIT: return launch_skinny<T, EPI_RESID_EMIT>(p, s);
     default: return (int)hipErrorInvalidValue;
   }
+}
+
+int gemm_launch_skinny(int dtype, int epi, const GemmParams& p, hipStream_t s, const char** kernel_name) {
+  if (p.M <= 0) return 0;
+  if ((dtype != 1 && dtype != 2) || !gemm_skinny_supports(epi, p.M, p.N, p.K) || p.lda % 8 || p.ldw % 8) return (int)hipErrorInvalidValue;
+  static const char* names[2][EPI_COUNT] = {
+      {"gemm_skinny<bf16,32x64_splitk,bias>", "gemm_skinny<bf16,32x64_splitk,bias_qgelu>", "gemm_skinny<bf16,32x64_splitk,bias_resid>",
+       nullptr, nullptr, "gemm_skinny<bf16,32x64_splitk,ln_bias>", "gemm_skinny<bf16,32x64_splitk,ln_qgelu>",
+       "gemm_skinny<bf16,32x64_splitk,resid_emit>", nullptr},
+      {"gemm_skinny<f16,32x64_splitk,bias>", "gemm_skinny<f16,32x64_splitk,bias_qgelu>", "gemm_skinny<f16,32x64_splitk,bias_resid>",
+       nullptr, nullptr, "gemm_skinny<f16,32x64_splitk,ln_bias>", "gemm_skinny<f16,32x64_splitk,ln_qgelu>",
+       "gemm_skinny<f16,32x64_splitk,resid_emit>", nullptr}};
+  if (kernel_name) *kernel_name = names[dtype - 1][epi];
+  return dtype == 1 ? launch_skinny_epi<bf16_t>(epi, p, s) : launch_skinny_epi<f16_t>(epi, p, s);
 }
 
 }  // namespace plipmi

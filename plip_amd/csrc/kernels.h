@@ -4,34 +4,29 @@
 
 namespace plipmi {
 
-// dtype codes used by the launchers: 0 = fp32, 1 = bf16 (same as PLIPMI_F32 / PLIPMI_BF16)
+// dtype codes used by the launchers: 0 = fp32, 1 = bf16, 2 = f16 (same as PLIPMI_F32 / PLIPMI_BF16 / PLIPMI_F16)
 
 // y[r,:] = LayerNorm(x[r*x_row_stride : +D]) * g + b ; y is fp32 or bf16, contiguous [rows, D].
 // One wavefront per row, statistics in fp32 (two-pass, values held in registers).
 hipError_t launch_layernorm(const float* x, size_t x_row_stride, const float* g, const float* b, void* y, int y_dtype,
                             int rows, int D, float eps, hipStream_t s);
 
-// LayerNorm folded into the GEMMs (bf16 engine, gemm.h EPI_*_LN): the one LayerNorm pass a tower keeps -- fp32 rows in,
-// the normalised rows out as the split residual stream (common.h split_f32: hi = bf16 plane [rows, D], lo = int16
-// remainder plane, hi + lo == the fp32 value exactly) plus their statistics partials st [rows, D/64, 2] (D % 64 == 0)
+// LayerNorm folded into the GEMMs (16-bit engines, gemm.h EPI_*_LN): the one LayerNorm pass a tower keeps -- fp32 rows in,
+// the normalised rows out as the split residual stream (common.h split_f32<H>: hi = the 16-bit operand plane [rows, D],
+// lo = int16 remainder plane, the pair == the fp32 value exactly) plus their statistics partials st [rows, D/64, 2]
+// (D % 64 == 0).  dtype (1 = bf16, 2 = f16) selects H.
 hipError_t launch_layernorm_emit(const float* x, const float* g, const float* b, void* hi, void* lo, float* st, int rows, int D,
-                                 float eps, hipStream_t s);
+                                 float eps, int dtype, hipStream_t s);
 // the two planes back to plain fp32 (n % 4 == 0 elements)
-hipError_t launch_join_planes(const void* hi, const void* lo, float* x, size_t n, hipStream_t s);
-// weight folding at plipmi_create: Wf[n,:] = bf16(pre * (W[n,:] * g - mean_k(W[n,:] * g))), c2[n] = pre * (W[n,:].b + bias[n])
+hipError_t launch_join_planes(const void* hi, const void* lo, float* x, size_t n, int dtype, hipStream_t s);
+// weight folding at plipmi_create: Wf[n,:] = H(pre * (W[n,:] * g - mean_k(W[n,:] * g))), c2[n] = pre * (W[n,:].b + bias[n])
 hipError_t launch_fold_ln(const float* W, const float* bias, const float* g, const float* b, void* Wf, float* c2, int rows,
-                          int K, float pre, hipStream_t s);
-// token + position embedding with the same by-products (text tower's first block)
+                          int K, float pre, int dtype, hipStream_t s);
+// token + position embedding with the same by-products (text tower's first block).  bad_id: see launch_text_embed
 hipError_t launch_text_embed_emit(const int64_t* ids, const float* tok, const float* pos, void* hi, void* lo, float* st, int B,
-                                  int S, int D, int vocab, hipStream_t s);
+                                  int S, int D, int vocab, int* bad_id, int dtype, hipStream_t s);
 
 // pixels fp32 [B,3,H,W] -> patch rows [B*np, Kpad] (dtype), column (c,u,v), zero padded to Kpad.
-// fp8-weights engine: LayerNorm output as fp8 rows + one dynamic scale per row; weight rows -> fp8 + scale per row
-hipError_t launch_layernorm_fp8(const float* x, size_t x_row_stride, const float* g, const float* b, void* y_fp8,
-                                float* row_scale, int rows, int D, float eps, hipStream_t s);
-hipError_t launch_quantize_rows_fp8(const float* src, void* dst_fp8, float* scale, int rows, int cols, float pre,
-                                    hipStream_t s);
-
 hipError_t launch_unfold_patches(const float* pixels, void* out, int out_dtype, int B, int image, int patch, int Kpad,
                                  hipStream_t s);
 
@@ -43,9 +38,10 @@ hipError_t launch_unfold_patches_u8(const uint8_t* tiles, void* out, int out_dty
 // x[b,0,:] = class_embedding + pos[0,:]   (token rows 1.. are written by the patch GEMM epilogue)
 hipError_t launch_cls_rows(const float* cls, const float* pos, float* x, int B, int tokens, int D, hipStream_t s);
 
-// x[b,s,:] = tok[ids[b,s],:] + pos[s,:]   (ids clamped to [0,vocab) -- the host validates them)
+// x[b,s,:] = tok[ids[b,s],:] + pos[s,:].  An id outside [0,vocab) is clamped for the lookup and raises *bad_id (a flag
+// in host-visible memory; nullptr = no report): the reference's lookup raises there (plip.py:68)
 hipError_t launch_text_embed(const int64_t* ids, const float* tok, const float* pos, float* x, int B, int S, int D,
-                             int vocab, hipStream_t s);
+                             int vocab, int* bad_id, hipStream_t s);
 
 // Pooled head: row = CLS (ids == nullptr) or the EOS row of each caption, then
 // LayerNorm -> bias-free projection (Wt is the projection TRANSPOSED: [D, P]) -> optional L2 normalise.
@@ -63,7 +59,7 @@ hipError_t launch_pool_layernorm(const float* x, int S, int D, const int64_t* id
 // out_proj / fc1 / fc2
 // cu != nullptr: packed rows, the pooled row of sample b is its last one, cu[b+1]-1
 hipError_t launch_pool_gather(const void* att, const void* hi, const void* lo, int S, int D, const int64_t* ids, int eos_id,
-                              void* attp, float* xp, int B, hipStream_t s, const int* cu = nullptr);
+                              void* attp, float* xp, int B, int dtype, hipStream_t s, const int* cu = nullptr);
 
 hipError_t launch_l2_normalize(float* x, int N, int D, hipStream_t s);
 // C[M,N] = A[M,K] . W[N,K]^T, exact fp32 MFMA, split-K over the four waves of a 32x32-tile workgroup (N, K % 32 == 0)
@@ -101,7 +97,7 @@ hipError_t launch_scale_copy(const float* src, float* dst, int n, float scale, h
 
 // Multi-head attention over the fused qkv buffer [B*S, 3*D] (q | k | v, head h at columns h*64..), the 1/sqrt(64)
 // scale already folded into q.  out [B*S, D].  causal: key j <= query i.  key_mask: int64 [B,S] or nullptr.
-//   impl 0 = exact fp32 VALU kernel (any dtype), 1 = bf16 MFMA kernel (dtype must be bf16)
+//   impl 0 = exact fp32 VALU kernel (any dtype), 1 = MFMA kernel (dtype bf16 or f16)
 //   cu (impl 1, S <= 128): packed rows -- sample b owns rows cu[b] .. cu[b+1]-1 of qkv / out (its first cu[b+1]-cu[b]
 //   positions; the rest of its S positions do not exist); key_mask keeps its [B, S] layout
 hipError_t launch_attention(const void* qkv, void* out, int dtype, int B, int S, int H, int causal,
@@ -114,6 +110,6 @@ hipError_t launch_text_pack(const int64_t* ids, int B, int S, int eos_id, int* c
 // token + position embedding of the packed rows (split planes + statistics partials, as launch_text_embed_emit)
 hipError_t launch_text_embed_emit_packed(const int64_t* ids, const float* tok, const float* pos, void* hi, void* lo, float* st,
                                          const int* rowmap, const int* m_dev, int max_rows, int S, int D, int vocab,
-                                         hipStream_t s);
+                                         int* bad_id, int dtype, hipStream_t s);
 
 }  // namespace plipmi

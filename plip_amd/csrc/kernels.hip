@@ -102,110 +102,6 @@ __global__ __launch_bounds__(256) void layernorm_fixed_kernel(const float* x, si
 }
 
 // ---------------------------------------------------------------------------------
-// fp8 (OCP e4m3fn) operand producers of the fp8-weights engine (plipmi compute_dtype 2):
-//   * LayerNorm rows quantised with one dynamic scale per row (amax / 448), the A operand of the QKV / fc1 GEMMs;
-//   * Linear weights quantised once at plipmi_create with one scale per output channel.
-// The GEMM epilogue multiplies the fp32 accumulator by row_scale[m] * col_scale[n].
-// ---------------------------------------------------------------------------------
-constexpr float kFp8Max = 448.0f;
-__device__ __forceinline__ unsigned pack4_fp8(float a, float b, float c, float d) {
-  int w = 0;
-  w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);
-  w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
-  return (unsigned)w;
-}
-__global__ __launch_bounds__(256) void layernorm_fp8_kernel(const float* __restrict__ x, size_t xs,
-                                                            const float* __restrict__ g, const float* __restrict__ b,
-                                                            unsigned char* __restrict__ y, float* __restrict__ row_scale,
-                                                            int rows, int D, float eps) {
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
-  const float* xr = x + (size_t)row * xs;
-  float4 v[kLnMaxVec];
-  float s = 0.f;
-#pragma unroll
-  for (int it = 0; it < kLnMaxVec; ++it) {
-    const int idx = it * 256 + lane * 4;
-    if (idx < D) {
-      v[it] = *reinterpret_cast<const float4*>(xr + idx);
-      s += (v[it].x + v[it].y) + (v[it].z + v[it].w);
-    }
-  }
-  const float mean = wave_sum(s) / (float)D;
-  float q = 0.f;
-#pragma unroll
-  for (int it = 0; it < kLnMaxVec; ++it) {
-    const int idx = it * 256 + lane * 4;
-    if (idx < D) {
-      const float a = v[it].x - mean, c = v[it].y - mean, d = v[it].z - mean, e = v[it].w - mean;
-      q += (a * a + c * c) + (d * d + e * e);
-    }
-  }
-  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
-  float amax = 0.f;
-#pragma unroll
-  for (int it = 0; it < kLnMaxVec; ++it) {
-    const int idx = it * 256 + lane * 4;
-    if (idx < D) {
-      const float4 gg = *reinterpret_cast<const float4*>(g + idx);
-      const float4 bb = *reinterpret_cast<const float4*>(b + idx);
-      v[it].x = (v[it].x - mean) * rstd * gg.x + bb.x; v[it].y = (v[it].y - mean) * rstd * gg.y + bb.y;
-      v[it].z = (v[it].z - mean) * rstd * gg.z + bb.z; v[it].w = (v[it].w - mean) * rstd * gg.w + bb.w;
-      amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v[it].x), fabsf(v[it].y))), fmaxf(fabsf(v[it].z), fabsf(v[it].w)));
-    }
-  }
-  amax = wave_max(amax);
-  const float scale = amax > 0.f ? amax / kFp8Max : 1.0f;
-  const float inv = 1.0f / scale;
-  unsigned char* yr = y + (size_t)row * D;
-#pragma unroll
-  for (int it = 0; it < kLnMaxVec; ++it) {
-    const int idx = it * 256 + lane * 4;
-    if (idx < D)
-      *reinterpret_cast<unsigned*>(yr + idx) = pack4_fp8(v[it].x * inv, v[it].y * inv, v[it].z * inv, v[it].w * inv);
-  }
-  if (lane == 0) row_scale[row] = scale;
-}
-hipError_t launch_layernorm_fp8(const float* x, size_t xs, const float* g, const float* b, void* y, float* row_scale,
-                                int rows, int D, float eps, hipStream_t s) {
-  if (rows <= 0) return hipSuccess;
-  if (D % 4 || D > kLnMaxVec * 256) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(layernorm_fp8_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, xs, g, b, (unsigned char*)y,
-                     row_scale, rows, D, eps);
-  return hipGetLastError();
-}
-
-// dst[r, :] = fp8(pre * src[r, :] / scale_r), scale_r = pre * amax_r / 448 (one wave per weight row)
-__global__ __launch_bounds__(256) void quantize_rows_fp8_kernel(const float* __restrict__ src, unsigned char* __restrict__ dst,
-                                                                float* __restrict__ scale, int rows, int cols, float pre) {
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
-  const float* sr = src + (size_t)row * cols;
-  float amax = 0.f;
-  for (int c = lane * 4; c < cols; c += 256) {
-    const float4 v = *reinterpret_cast<const float4*>(sr + c);
-    amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
-  }
-  amax = wave_max(amax) * fabsf(pre);
-  const float sc = amax > 0.f ? amax / kFp8Max : 1.0f;
-  const float inv = pre / sc;
-  for (int c = lane * 4; c < cols; c += 256) {
-    const float4 v = *reinterpret_cast<const float4*>(sr + c);
-    *reinterpret_cast<unsigned*>(dst + (size_t)row * cols + c) = pack4_fp8(v.x * inv, v.y * inv, v.z * inv, v.w * inv);
-  }
-  if (lane == 0) scale[row] = sc;
-}
-hipError_t launch_quantize_rows_fp8(const float* src, void* dst, float* scale, int rows, int cols, float pre, hipStream_t s) {
-  if (rows <= 0) return hipSuccess;
-  if (cols % 4) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(quantize_rows_fp8_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, src, (unsigned char*)dst, scale,
-                     rows, cols, pre);
-  return hipGetLastError();
-}
-
-// ---------------------------------------------------------------------------------
 // LayerNorm folded into the neighbouring GEMMs (bf16 engine; gemm.h EPI_*_LN / EPI_RESID_EMIT).
 //   * layernorm_emit_kernel: the ONE LayerNorm pass a tower keeps (vision pre_layrnorm, modeling_clip.py:642): reads the
 //     fp32 embedding rows, writes the normalised rows as the engine's split residual stream (common.h split_f32: the hi
@@ -215,6 +111,7 @@ hipError_t launch_quantize_rows_fp8(const float* src, void* dst, float* scale, i
 //     row centred, so that x . W'^T == (x - mean(x)) . (W * g)^T and LayerNorm's mean subtraction needs no epilogue term;
 //     c2[n] = pre * (sum_k W[n,k] b[k] + bias[n]); sums in fp64.
 // ---------------------------------------------------------------------------------
+template <typename H>
 __global__ __launch_bounds__(256) void layernorm_emit_kernel(const float* __restrict__ x, const float* __restrict__ g,
                                                              const float* __restrict__ b, unsigned short* __restrict__ hi,
                                                              unsigned short* __restrict__ lo, float* __restrict__ st, int rows,
@@ -260,38 +157,48 @@ __global__ __launch_bounds__(256) void layernorm_emit_kernel(const float* __rest
     const float d0 = y.x - mj, d1 = y.y - mj, d2 = y.z - mj, d3 = y.w - mj;
     const float m2 = row16_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
     if (live) {
-      store4_split(hi + (size_t)row * D + idx, lo + (size_t)row * D + idx, y.x, y.y, y.z, y.w);
+      store4_split<H>(hi + (size_t)row * D + idx, lo + (size_t)row * D + idx, y.x, y.y, y.z, y.w);
       if ((lane & 15) == 0) *reinterpret_cast<float2*>(st + ((size_t)row * ns + idx / kLnSlice) * 2) = make_float2(ssum, m2);
     }
   }
 }
 hipError_t launch_layernorm_emit(const float* x, const float* g, const float* b, void* hi, void* lo, float* st, int rows, int D,
-                                 float eps, hipStream_t s) {
+                                 float eps, int dtype, hipStream_t s) {
   if (rows <= 0) return hipSuccess;
-  if (D % kLnSlice || D > kLnMaxVec * 256) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(layernorm_emit_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, g, b, (unsigned short*)hi,
-                     (unsigned short*)lo, st, rows, D, eps);
+  if (D % kLnSlice || D > kLnMaxVec * 256 || (dtype != 1 && dtype != 2)) return hipErrorInvalidValue;
+  if (dtype == 1)
+    hipLaunchKernelGGL(layernorm_emit_kernel<bf16_t>, dim3((rows + 3) / 4), dim3(256), 0, s, x, g, b, (unsigned short*)hi,
+                       (unsigned short*)lo, st, rows, D, eps);
+  else
+    hipLaunchKernelGGL(layernorm_emit_kernel<f16_t>, dim3((rows + 3) / 4), dim3(256), 0, s, x, g, b, (unsigned short*)hi,
+                       (unsigned short*)lo, st, rows, D, eps);
   return hipGetLastError();
 }
 
 // hi/lo planes -> plain fp32 rows (plipmi_debug_hidden, and the head of an engine that runs its last block on every token)
+template <typename H>
 __global__ __launch_bounds__(256) void join_planes_kernel(const unsigned short* __restrict__ hi, const unsigned short* __restrict__ lo,
                                                           float* __restrict__ x, size_t n4) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n4) return;
-  *reinterpret_cast<float4*>(x + i * 4) = load4_split(hi + i * 4, lo + i * 4);
+  *reinterpret_cast<float4*>(x + i * 4) = load4_split<H>(hi + i * 4, lo + i * 4);
 }
-hipError_t launch_join_planes(const void* hi, const void* lo, float* x, size_t n, hipStream_t s) {
+hipError_t launch_join_planes(const void* hi, const void* lo, float* x, size_t n, int dtype, hipStream_t s) {
   if (n == 0) return hipSuccess;
-  if (n % 4) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(join_planes_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, (const unsigned short*)hi,
-                     (const unsigned short*)lo, x, n / 4);
+  if (n % 4 || (dtype != 1 && dtype != 2)) return hipErrorInvalidValue;
+  if (dtype == 1)
+    hipLaunchKernelGGL(join_planes_kernel<bf16_t>, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, (const unsigned short*)hi,
+                       (const unsigned short*)lo, x, n / 4);
+  else
+    hipLaunchKernelGGL(join_planes_kernel<f16_t>, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, (const unsigned short*)hi,
+                       (const unsigned short*)lo, x, n / 4);
   return hipGetLastError();
 }
 
+template <typename H>
 __global__ __launch_bounds__(256) void fold_ln_kernel(const float* __restrict__ W, const float* __restrict__ bias,
                                                       const float* __restrict__ g, const float* __restrict__ b,
-                                                      bf16_t* __restrict__ Wf, float* __restrict__ c2, int rows, int K,
+                                                      H* __restrict__ Wf, float* __restrict__ c2, int rows, int K,
                                                       float pre) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -313,18 +220,17 @@ __global__ __launch_bounds__(256) void fold_ln_kernel(const float* __restrict__ 
   for (int k = lane * 4; k < K; k += 256) {
     const float4 w = *reinterpret_cast<const float4*>(wr + k);
     const float4 gg = *reinterpret_cast<const float4*>(g + k);
-    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-    const bf16x4 pk = {(bf16_t)(pre * (w.x * gg.x - wmean)), (bf16_t)(pre * (w.y * gg.y - wmean)),
-                       (bf16_t)(pre * (w.z * gg.z - wmean)), (bf16_t)(pre * (w.w * gg.w - wmean))};
-    *reinterpret_cast<bf16x4*>(Wf + (size_t)row * K + k) = pk;
+    store4(Wf + (size_t)row * K + k, pre * (w.x * gg.x - wmean), pre * (w.y * gg.y - wmean), pre * (w.z * gg.z - wmean),
+           pre * (w.w * gg.w - wmean));
   }
   if (lane == 0) c2[row] = (float)((double)pre * (s2 + (double)bias[row]));
 }
 hipError_t launch_fold_ln(const float* W, const float* bias, const float* g, const float* b, void* Wf, float* c2, int rows,
-                          int K, float pre, hipStream_t s) {
+                          int K, float pre, int dtype, hipStream_t s) {
   if (rows <= 0) return hipSuccess;
-  if (K % 4) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(fold_ln_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, W, bias, g, b, (bf16_t*)Wf, c2, rows, K, pre);
+  if (K % 4 || (dtype != 1 && dtype != 2)) return hipErrorInvalidValue;
+  if (dtype == 1) hipLaunchKernelGGL(fold_ln_kernel<bf16_t>, dim3((rows + 3) / 4), dim3(256), 0, s, W, bias, g, b, (bf16_t*)Wf, c2, rows, K, pre);
+  else hipLaunchKernelGGL(fold_ln_kernel<f16_t>, dim3((rows + 3) / 4), dim3(256), 0, s, W, bias, g, b, (f16_t*)Wf, c2, rows, K, pre);
   return hipGetLastError();
 }
 
@@ -332,17 +238,22 @@ hipError_t launch_layernorm(const float* x, size_t xs, const float* g, const flo
                             int D, float eps, hipStream_t s) {
   if (rows <= 0) return hipSuccess;
   if (D % 4 || D > kLnMaxVec * 256) return hipErrorInvalidValue;
-  if (y_dtype == 1 && (D == 512 || D == 768 || D == 1024)) {  // one kernel for every batch size: batch invariance is bitwise
+  if (y_dtype != 0 && (D == 512 || D == 768 || D == 1024)) {  // one kernel for every batch size: batch invariance is bitwise
     constexpr int RPW = 2;
     const dim3 grid((rows + 4 * RPW - 1) / (4 * RPW)), block(256);
-    if (D == 512) hipLaunchKernelGGL((layernorm_fixed_kernel<bf16_t, 2, RPW>), grid, block, 0, s, x, xs, g, b, (bf16_t*)y, rows, eps);
-    else if (D == 768) hipLaunchKernelGGL((layernorm_fixed_kernel<bf16_t, 3, RPW>), grid, block, 0, s, x, xs, g, b, (bf16_t*)y, rows, eps);
-    else hipLaunchKernelGGL((layernorm_fixed_kernel<bf16_t, 4, RPW>), grid, block, 0, s, x, xs, g, b, (bf16_t*)y, rows, eps);
+#define PLIPMI_LNF(H) \
+    if (D == 512) hipLaunchKernelGGL((layernorm_fixed_kernel<H, 2, RPW>), grid, block, 0, s, x, xs, g, b, (H*)y, rows, eps); \
+    else if (D == 768) hipLaunchKernelGGL((layernorm_fixed_kernel<H, 3, RPW>), grid, block, 0, s, x, xs, g, b, (H*)y, rows, eps); \
+    else hipLaunchKernelGGL((layernorm_fixed_kernel<H, 4, RPW>), grid, block, 0, s, x, xs, g, b, (H*)y, rows, eps)
+    if (y_dtype == 1) { PLIPMI_LNF(bf16_t); } else { PLIPMI_LNF(f16_t); }
+#undef PLIPMI_LNF
     return hipGetLastError();
   }
   const dim3 grid((rows + 3) / 4), block(256);
   if (y_dtype == 1)
     hipLaunchKernelGGL(layernorm_kernel<bf16_t>, grid, block, 0, s, x, xs, g, b, (bf16_t*)y, rows, D, eps);
+  else if (y_dtype == 2)
+    hipLaunchKernelGGL(layernorm_kernel<f16_t>, grid, block, 0, s, x, xs, g, b, (f16_t*)y, rows, D, eps);
   else
     hipLaunchKernelGGL(layernorm_kernel<float>, grid, block, 0, s, x, xs, g, b, (float*)y, rows, D, eps);
   return hipGetLastError();
@@ -395,6 +306,7 @@ hipError_t launch_unfold_patches(const float* pixels, void* out, int out_dtype, 
 #define PLIPMI_UNFOLD(T, V) \
   hipLaunchKernelGGL((unfold_kernel<T, V>), grid, block, 0, s, pixels, (T*)out, image, patch, K, Kpad)
   if (out_dtype == 1) { if (vec) PLIPMI_UNFOLD(bf16_t, true); else PLIPMI_UNFOLD(bf16_t, false); }
+  else if (out_dtype == 2) { if (vec) PLIPMI_UNFOLD(f16_t, true); else PLIPMI_UNFOLD(f16_t, false); }
   else                { if (vec) PLIPMI_UNFOLD(float, true);  else PLIPMI_UNFOLD(float, false); }
 #undef PLIPMI_UNFOLD
   return hipGetLastError();
@@ -435,6 +347,8 @@ hipError_t launch_unfold_patches_u8(const uint8_t* tiles, void* out, int out_dty
   const dim3 grid(B * g * g), block(256);
   if (out_dtype == 1)
     hipLaunchKernelGGL(unfold_u8_kernel<bf16_t>, grid, block, 0, s, tiles, (bf16_t*)out, image, patch, K, Kpad);
+  else if (out_dtype == 2)
+    hipLaunchKernelGGL(unfold_u8_kernel<f16_t>, grid, block, 0, s, tiles, (f16_t*)out, image, patch, K, Kpad);
   else
     hipLaunchKernelGGL(unfold_u8_kernel<float>, grid, block, 0, s, tiles, (float*)out, image, patch, K, Kpad);
   return hipGetLastError();
@@ -456,11 +370,21 @@ hipError_t launch_cls_rows(const float* cls, const float* pos, float* x, int B, 
 }
 
 // x[b,s,:] = token_embedding[ids[b,s]] + position_embedding[s]   (modeling_clip.py:251-254)
+// A token id outside [0, vocab): the reference's embedding lookup raises (plip.py:68 -> HF nn.Embedding; on a GPU as a
+// device-side assert that surfaces at the next synchronisation).  Here the lookup is clamped so that no wild address is
+// read, and *bad_id -- a flag in host-visible memory owned by the handle -- is raised; the engine reports it at the
+// next call / plipmi_check_async (engine.hip).
+__device__ __forceinline__ long long checked_token(long long id, int vocab, int* bad_id, int lane) {
+  if (id >= 0 && id < vocab) return id;
+  if (bad_id && lane == 0) *bad_id = 1;
+  return id < 0 ? 0 : vocab - 1;
+}
 __global__ void text_embed_kernel(const int64_t* __restrict__ ids, const float* __restrict__ tok,
-                                  const float* __restrict__ pos, float* __restrict__ x, int S, int D, int vocab) {
+                                  const float* __restrict__ pos, float* __restrict__ x, int S, int D, int vocab,
+                                  int* __restrict__ bad_id) {
   const int row = blockIdx.x;
   long long id = ids[row];
-  id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+  id = checked_token(id, vocab, bad_id, threadIdx.x);
   const float* t = tok + (size_t)id * D;
   const float* p = pos + (size_t)(row % S) * D;
   float* xr = x + (size_t)row * D;
@@ -470,23 +394,24 @@ __global__ void text_embed_kernel(const int64_t* __restrict__ ids, const float* 
   }
 }
 hipError_t launch_text_embed(const int64_t* ids, const float* tok, const float* pos, float* x, int B, int S, int D,
-                             int vocab, hipStream_t s) {
+                             int vocab, int* bad_id, hipStream_t s) {
   if (B <= 0) return hipSuccess;
-  hipLaunchKernelGGL(text_embed_kernel, dim3(B * S), dim3(128), 0, s, ids, tok, pos, x, S, D, vocab);
+  hipLaunchKernelGGL(text_embed_kernel, dim3(B * S), dim3(128), 0, s, ids, tok, pos, x, S, D, vocab, bad_id);
   return hipGetLastError();
 }
 
 // the same lookup for the LayerNorm-folded engine: writes the rows as the split residual stream (hi/lo planes) and emits
 // their statistics partials (one wave per row; 16 lanes cover one 64-column slice)
+template <typename H>
 __global__ __launch_bounds__(256) void text_embed_emit_kernel(const int64_t* __restrict__ ids, const float* __restrict__ tok,
                                                               const float* __restrict__ pos, unsigned short* __restrict__ hi,
                                                               unsigned short* __restrict__ lo, float* __restrict__ st, int rows,
-                                                              int S, int D, int vocab) {
+                                                              int S, int D, int vocab, int* __restrict__ bad_id) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   long long id = ids[row];
-  id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+  id = checked_token(id, vocab, bad_id, lane);
   const float* t = tok + (size_t)id * D;
   const float* p = pos + (size_t)(row % S) * D;
   const int ns = D / kLnSlice;
@@ -503,17 +428,21 @@ __global__ __launch_bounds__(256) void text_embed_emit_kernel(const int64_t* __r
     const float d0 = y.x - mj, d1 = y.y - mj, d2 = y.z - mj, d3 = y.w - mj;
     const float m2 = row16_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
     if (live) {
-      store4_split(hi + (size_t)row * D + idx, lo + (size_t)row * D + idx, y.x, y.y, y.z, y.w);
+      store4_split<H>(hi + (size_t)row * D + idx, lo + (size_t)row * D + idx, y.x, y.y, y.z, y.w);
       if ((lane & 15) == 0) *reinterpret_cast<float2*>(st + ((size_t)row * ns + idx / kLnSlice) * 2) = make_float2(ssum, m2);
     }
   }
 }
 hipError_t launch_text_embed_emit(const int64_t* ids, const float* tok, const float* pos, void* hi, void* lo, float* st, int B,
-                                  int S, int D, int vocab, hipStream_t s) {
+                                  int S, int D, int vocab, int* bad_id, int dtype, hipStream_t s) {
   if (B <= 0) return hipSuccess;
-  if (D % kLnSlice) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(text_embed_emit_kernel, dim3((B * S + 3) / 4), dim3(256), 0, s, ids, tok, pos, (unsigned short*)hi,
-                     (unsigned short*)lo, st, B * S, S, D, vocab);
+  if (D % kLnSlice || (dtype != 1 && dtype != 2)) return hipErrorInvalidValue;
+  if (dtype == 1)
+    hipLaunchKernelGGL(text_embed_emit_kernel<bf16_t>, dim3((B * S + 3) / 4), dim3(256), 0, s, ids, tok, pos, (unsigned short*)hi,
+                       (unsigned short*)lo, st, B * S, S, D, vocab, bad_id);
+  else
+    hipLaunchKernelGGL(text_embed_emit_kernel<f16_t>, dim3((B * S + 3) / 4), dim3(256), 0, s, ids, tok, pos, (unsigned short*)hi,
+                       (unsigned short*)lo, st, B * S, S, D, vocab, bad_id);
   return hipGetLastError();
 }
 
@@ -639,9 +568,10 @@ __device__ __forceinline__ int eos_position(const int64_t* row, int S, int eos_i
 // The LAST block of a tower only matters for the row that is pooled afterwards (CLS, or the caption's EOS row): one
 // wavefront per sample picks that row and copies its attention output (bf16) and residual row (hi/lo planes -> fp32) into
 // compact [B, D] buffers, on which out_proj / fc1 / fc2 of the last block then run (engine.hip run_last_block_pooled).
-__global__ __launch_bounds__(256) void pool_gather_kernel(const bf16_t* __restrict__ att, const unsigned short* __restrict__ hi,
+template <typename H>
+__global__ __launch_bounds__(256) void pool_gather_kernel(const H* __restrict__ att, const unsigned short* __restrict__ hi,
                                                           const unsigned short* __restrict__ lo, int S, int D,
-                                                          const int64_t* __restrict__ ids, int eos_id, bf16_t* __restrict__ attp,
+                                                          const int64_t* __restrict__ ids, int eos_id, H* __restrict__ attp,
                                                           float* __restrict__ xp, int B, const int* __restrict__ cu) {
   const int lane = threadIdx.x & 63;
   const int smp = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -652,16 +582,20 @@ __global__ __launch_bounds__(256) void pool_gather_kernel(const bf16_t* __restri
   const size_t src = row * D, dst = (size_t)smp * D;
   for (int i = lane * 8; i < D; i += 512) {     // D % 8 == 0 (widths are multiples of 128)
     *reinterpret_cast<u32x4_t*>(attp + dst + i) = *reinterpret_cast<const u32x4_t*>(att + src + i);
-    *reinterpret_cast<float4*>(xp + dst + i) = load4_split(hi + src + i, lo + src + i);
-    *reinterpret_cast<float4*>(xp + dst + i + 4) = load4_split(hi + src + i + 4, lo + src + i + 4);
+    *reinterpret_cast<float4*>(xp + dst + i) = load4_split<H>(hi + src + i, lo + src + i);
+    *reinterpret_cast<float4*>(xp + dst + i + 4) = load4_split<H>(hi + src + i + 4, lo + src + i + 4);
   }
 }
 hipError_t launch_pool_gather(const void* att, const void* hi, const void* lo, int S, int D, const int64_t* ids, int eos_id,
-                              void* attp, float* xp, int B, hipStream_t s, const int* cu) {
+                              void* attp, float* xp, int B, int dtype, hipStream_t s, const int* cu) {
   if (B <= 0) return hipSuccess;
-  if (D % 8) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(pool_gather_kernel, dim3((B + 3) / 4), dim3(256), 0, s, (const bf16_t*)att, (const unsigned short*)hi,
-                     (const unsigned short*)lo, S, D, ids, eos_id, (bf16_t*)attp, xp, B, cu);
+  if (D % 8 || (dtype != 1 && dtype != 2)) return hipErrorInvalidValue;
+  if (dtype == 1)
+    hipLaunchKernelGGL(pool_gather_kernel<bf16_t>, dim3((B + 3) / 4), dim3(256), 0, s, (const bf16_t*)att, (const unsigned short*)hi,
+                       (const unsigned short*)lo, S, D, ids, eos_id, (bf16_t*)attp, xp, B, cu);
+  else
+    hipLaunchKernelGGL(pool_gather_kernel<f16_t>, dim3((B + 3) / 4), dim3(256), 0, s, (const f16_t*)att, (const unsigned short*)hi,
+                       (const unsigned short*)lo, S, D, ids, eos_id, (f16_t*)attp, xp, B, cu);
   return hipGetLastError();
 }
 
@@ -708,17 +642,18 @@ hipError_t launch_text_pack(const int64_t* ids, int B, int S, int eos_id, int* c
   return hipGetLastError();
 }
 
+template <typename H>
 __global__ __launch_bounds__(256) void text_embed_emit_packed_kernel(const int64_t* __restrict__ ids, const float* __restrict__ tok,
                                                                      const float* __restrict__ pos, unsigned short* __restrict__ hi,
                                                                      unsigned short* __restrict__ lo, float* __restrict__ st,
                                                                      const int* __restrict__ rowmap, const int* __restrict__ m_dev,
-                                                                     int S, int D, int vocab) {
+                                                                     int S, int D, int vocab, int* __restrict__ bad_id) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= *m_dev) return;                  // wave-uniform
   const int bt = rowmap[row], b = bt >> 8, tpos = bt & 255;
   long long id = ids[(size_t)b * S + tpos];
-  id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+  id = checked_token(id, vocab, bad_id, lane);
   const float* t = tok + (size_t)id * D;
   const float* p = pos + (size_t)tpos * D;
   const int ns = D / kLnSlice;
@@ -735,18 +670,22 @@ __global__ __launch_bounds__(256) void text_embed_emit_packed_kernel(const int64
     const float d0 = y.x - mj, d1 = y.y - mj, d2 = y.z - mj, d3 = y.w - mj;
     const float m2 = row16_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
     if (live) {
-      store4_split(hi + (size_t)row * D + idx, lo + (size_t)row * D + idx, y.x, y.y, y.z, y.w);
+      store4_split<H>(hi + (size_t)row * D + idx, lo + (size_t)row * D + idx, y.x, y.y, y.z, y.w);
       if ((lane & 15) == 0) *reinterpret_cast<float2*>(st + ((size_t)row * ns + idx / kLnSlice) * 2) = make_float2(ssum, m2);
     }
   }
 }
 hipError_t launch_text_embed_emit_packed(const int64_t* ids, const float* tok, const float* pos, void* hi, void* lo, float* st,
                                          const int* rowmap, const int* m_dev, int max_rows, int S, int D, int vocab,
-                                         hipStream_t s) {
+                                         int* bad_id, int dtype, hipStream_t s) {
   if (max_rows <= 0) return hipSuccess;
-  if (D % kLnSlice || S > 256) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(text_embed_emit_packed_kernel, dim3((max_rows + 3) / 4), dim3(256), 0, s, ids, tok, pos,
-                     (unsigned short*)hi, (unsigned short*)lo, st, rowmap, m_dev, S, D, vocab);
+  if (D % kLnSlice || S > 256 || (dtype != 1 && dtype != 2)) return hipErrorInvalidValue;
+  if (dtype == 1)
+    hipLaunchKernelGGL(text_embed_emit_packed_kernel<bf16_t>, dim3((max_rows + 3) / 4), dim3(256), 0, s, ids, tok, pos,
+                       (unsigned short*)hi, (unsigned short*)lo, st, rowmap, m_dev, S, D, vocab, bad_id);
+  else
+    hipLaunchKernelGGL(text_embed_emit_packed_kernel<f16_t>, dim3((max_rows + 3) / 4), dim3(256), 0, s, ids, tok, pos,
+                       (unsigned short*)hi, (unsigned short*)lo, st, rowmap, m_dev, S, D, vocab, bad_id);
   return hipGetLastError();
 }
 
@@ -1195,6 +1134,8 @@ hipError_t launch_convert(const float* src, void* dst, int dst_dtype, int rows, 
   const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
   if (dst_dtype == 1)
     hipLaunchKernelGGL(convert_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, src, (bf16_t*)dst, rows, cols, dst_ld, scale);
+  else if (dst_dtype == 2)
+    hipLaunchKernelGGL(convert_kernel<f16_t>, dim3(grid), dim3(256), 0, s, src, (f16_t*)dst, rows, cols, dst_ld, scale);
   else
     hipLaunchKernelGGL(convert_kernel<float>, dim3(grid), dim3(256), 0, s, src, (float*)dst, rows, cols, dst_ld, scale);
   return hipGetLastError();

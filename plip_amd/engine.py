@@ -15,8 +15,13 @@ from .config import PlipConfig
 
 _DTYPES = {"fp32": _lib.F32, "f32": _lib.F32, "float32": _lib.F32, torch.float32: _lib.F32,
            "bf16": _lib.BF16, "bfloat16": _lib.BF16, torch.bfloat16: _lib.BF16,
-           # experimental: bf16 engine with fp8 (e4m3fn) QKV / fc1 projections -- BASELINE configs[4] "fp8 MFMA weights"
-           "fp8": _lib.FP8W, "fp8w": _lib.FP8W}
+           # IEEE half operands: same matrix-core rate as bf16, 8x smaller operand rounding; the reference's own GPU dtype
+           "f16": _lib.F16, "fp16": _lib.F16, "float16": _lib.F16, "half": _lib.F16, torch.float16: _lib.F16}
+_TORCH_DTYPE = {_lib.F32: torch.float32, _lib.BF16: torch.bfloat16, _lib.F16: torch.float16}
+
+
+def _code(dt) -> int:
+    return _DTYPES[dt]
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -27,7 +32,12 @@ class Engine:
     """One MI355X engine = packed weights + workspace for ``max_batch`` images/captions."""
 
     def __init__(self, cfg: PlipConfig, state_dict: Mapping[str, object], device="cuda:0", dtype="bf16",
-                 max_batch: int = 256):
+                 max_batch: int = 256, *, ln_fold: bool = True, pooled_last_block: bool = True,
+                 pack_captions: bool = False, mfma_attention: bool = True, graph_batch: Optional[int] = None):
+        """``ln_fold`` / ``pooled_last_block`` / ``mfma_attention`` = False select the A/B forms of the 16-bit engines
+        (separate LayerNorm kernels, the last block on every token, the exact VALU attention kernel);
+        ``graph_batch``: None = default small-batch hipGraph replay (<= 32 samples), 0 = never, n = up to n samples.
+        All of it is per-handle configuration (include/plipmi.h plipmi_config.flags): no environment variables."""
         cfg.validate()
         if not torch.cuda.is_available():
             raise RuntimeError("plip_amd needs a ROCm GPU (MI355X / gfx950): torch.cuda.is_available() is False "
@@ -39,7 +49,10 @@ class Engine:
         if self.device.index is None:
             self.device = torch.device("cuda", torch.cuda.current_device())
         self.dtype_code = _DTYPES[dtype]
-        self.dtype_name = {_lib.BF16: "bf16", _lib.F32: "f32", _lib.FP8W: "fp8w"}[self.dtype_code]
+        self.dtype_name = {_lib.BF16: "bf16", _lib.F32: "f32", _lib.F16: "f16"}[self.dtype_code]
+        self.flags = ((0 if ln_fold else _lib.FLAG_SEPARATE_LAYERNORM) | (0 if pooled_last_block else _lib.FLAG_DENSE_LAST_BLOCK) |
+                      (_lib.FLAG_PACK_CAPTIONS if pack_captions else 0) | (0 if mfma_attention else _lib.FLAG_VALU_ATTENTION))
+        gb = 0 if graph_batch is None else (-1 if int(graph_batch) <= 0 else int(graph_batch))
         self.max_batch = int(max_batch)
         self.lib = _lib.load()
         self._h = C.c_void_p()
@@ -54,7 +67,7 @@ class Engine:
                 dev[k] = t.detach().to(device=self.device, dtype=torch.float32).contiguous()
             c = _lib.Config(cfg.image_size, cfg.patch_size, cfg.v_width, cfg.v_layers, cfg.v_heads, cfg.v_mlp,
                             cfg.vocab_size, cfg.context_length, cfg.t_width, cfg.t_layers, cfg.t_heads, cfg.t_mlp,
-                            cfg.projection_dim, cfg.layer_norm_eps, self.dtype_code, self.max_batch)
+                            cfg.projection_dim, cfg.layer_norm_eps, self.dtype_code, self.max_batch, self.flags, gb)
             w = _lib.Weights()
 
             def layers(prefix, n):
@@ -149,6 +162,8 @@ class Engine:
             lo, hi = int(input_ids.min()), int(input_ids.max())
             if lo < 0 or hi >= cfg.vocab_size:
                 raise IndexError(f"token id out of range [0,{cfg.vocab_size}): min {lo}, max {hi}")
+        # device-resident ids are range-checked BY the embedding kernel; the outcome is known once that work has run:
+        # check_async() after a synchronisation, or the next encode call on this engine, raises (plipmi_check_async)
         eos = cfg.eos_token_id if eos_token_id is None else int(eos_token_id)
         with torch.cuda.device(self.device):
             ids = input_ids.to(device=self.device, dtype=torch.int64).contiguous()
@@ -166,7 +181,11 @@ class Engine:
         the towers are independent (separate workspaces), so the tail of one tower's GEMM grid -- 150..600
         workgroups over 256 CUs -- is filled by the other tower's kernels instead of idling."""
         if not overlap:
-            return self.encode_image(pixels, normalize), self.encode_text(input_ids, attention_mask, normalize)
+            self._set_policy(getattr(self, "single_policy", 0))
+            try:
+                return self.encode_image(pixels, normalize), self.encode_text(input_ids, attention_mask, normalize)
+            finally:
+                self._set_policy(0)
         # co-scheduled towers: tile choice per epilogue instead of by wave quantisation -- a field of THIS handle, set
         # for the duration of the call (handles are not thread-safe, include/plipmi.h), never process-wide state
         self._set_policy(getattr(self, "pair_policy", 3))
@@ -174,6 +193,14 @@ class Engine:
             return self._encode_pair_two_streams(pixels, input_ids, attention_mask, normalize)
         finally:
             self._set_policy(0)
+
+    def check_async(self, synchronize: bool = True) -> None:
+        """Raise IndexError if an earlier ``encode_text`` was given a token id outside the vocabulary -- the reference's
+        embedding lookup raises there (plip.py:68; on a GPU at the next synchronisation, like here)."""
+        if synchronize:
+            torch.cuda.synchronize(self.device)
+        if self.lib.plipmi_check_async(self._h) != 0:
+            raise IndexError(_lib.last_error())
 
     def set_graph_batch(self, max_batch: int):
         """Batches of at most ``max_batch`` samples replay a captured hipGraph (0 = always launch eagerly)."""
@@ -329,13 +356,11 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = Non
     """Kernel-level entry (tests / micro-bench): epilogue(A[M,K] @ W[N,K]^T); a, w fp32 or bf16 CUDA tensors."""
     lib = _lib.load()
     assert a.is_cuda and w.is_cuda and a.dtype == w.dtype and a.is_contiguous() and w.is_contiguous()
-    fp8 = a.dtype == torch.float8_e4m3fn            # experimental test hook: fp8 operands, bf16 output
-    code = 2 if fp8 else (_lib.BF16 if a.dtype == torch.bfloat16 else _lib.F32)
+    code = _code(a.dtype)
     M, K = a.shape
     N = w.shape[0]
     if out is None:
-        odt = torch.bfloat16 if fp8 else (a.dtype if epilogue in (0, 1) else torch.float32)
-        out = torch.zeros((M, N), dtype=odt, device=a.device)
+        out = torch.zeros((M, N), dtype=a.dtype if epilogue in (0, 1) else torch.float32, device=a.device)
     with torch.cuda.device(a.device):
         _lib.check(lib.plipmi_gemm_nt_traced(code, epilogue, variant, M, N, K, _ptr(a), _ptr(w), _ptr(bias), float(alpha),
                                              _ptr(out), _ptr(trace),
@@ -349,7 +374,7 @@ def gemm_nt_ld(a: torch.Tensor, w: torch.Tensor, K: int, bias: Optional[torch.Te
     """epilogue(A[:, :K] @ W[:, :K]^T) on row-padded operands: a [M, lda >= K], w [N, ldw >= K] (tests)."""
     lib = _lib.load()
     assert a.is_cuda and w.is_cuda and a.dtype == w.dtype and a.is_contiguous() and w.is_contiguous()
-    code = _lib.BF16 if a.dtype == torch.bfloat16 else _lib.F32
+    code = _code(a.dtype)
     M, N = a.shape[0], w.shape[0]
     if out is None:
         out = torch.zeros((M, N), dtype=a.dtype if epilogue in (0, 1) else torch.float32, device=a.device)
@@ -365,7 +390,7 @@ def attention(qkv: torch.Tensor, B: int, S: int, H: int, causal: bool = False, k
     """Kernel-level entry (tests): qkv [B*S, 3*H*64] (scale folded into q) -> [B*S, H*64]."""
     lib = _lib.load()
     assert qkv.is_cuda and qkv.is_contiguous() and qkv.shape == (B * S, 3 * H * 64)
-    code = _lib.BF16 if qkv.dtype == torch.bfloat16 else _lib.F32
+    code = _code(qkv.dtype)
     out = torch.empty((B * S, H * 64), dtype=qkv.dtype, device=qkv.device)
     with torch.cuda.device(qkv.device):
         _lib.check(lib.plipmi_attention(code, impl, _ptr(qkv), _ptr(out), B, S, H, int(causal), _ptr(key_mask),
@@ -380,42 +405,58 @@ def gemm_nt_ln(mode: int, a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, 
     update on the split residual stream: ``out`` = (hi bf16 [M,N], lo int16 [M,N]), both updated in place; returns
     (hi, lo, st)."""
     lib = _lib.load()
-    assert a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and a.is_contiguous() and w.is_contiguous()
+    assert a.dtype in (torch.bfloat16, torch.float16) and w.dtype == a.dtype and a.is_contiguous() and w.is_contiguous()
+    code, hdt = _code(a.dtype), a.dtype
     M, K = a.shape
     N = w.shape[0]
     stream = C.c_void_p(torch.cuda.current_stream(a.device).cuda_stream)
     with torch.cuda.device(a.device):
         if mode in (0, 1):
             if out is None:
-                out = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
-            _lib.check(lib.plipmi_gemm_nt_ln(mode, variant, M, N, K, _ptr(a), _ptr(w), _ptr(bias), _ptr(stats),
+                out = torch.empty((M, N), dtype=hdt, device=a.device)
+            _lib.check(lib.plipmi_gemm_nt_ln(code, mode, variant, M, N, K, _ptr(a), _ptr(w), _ptr(bias), _ptr(stats),
                                              stats.shape[1], float(eps), _ptr(out), None, None, stream), "plipmi_gemm_nt_ln")
             return out
         st = torch.empty((M, N // 64, 2), dtype=torch.float32, device=a.device)
         if mode == 3:
             hi, lo = out
-            assert hi.dtype == torch.bfloat16 and lo.dtype == torch.int16 and hi.is_contiguous() and lo.is_contiguous()
-            _lib.check(lib.plipmi_gemm_nt_ln(3, variant, M, N, K, _ptr(a), _ptr(w), _ptr(bias), None, 0, float(eps),
+            assert hi.dtype == hdt and lo.dtype == torch.int16 and hi.is_contiguous() and lo.is_contiguous()
+            _lib.check(lib.plipmi_gemm_nt_ln(code, 3, variant, M, N, K, _ptr(a), _ptr(w), _ptr(bias), None, 0, float(eps),
                                              _ptr(lo), _ptr(hi), _ptr(st), stream), "plipmi_gemm_nt_ln")
             return hi, lo, st
-        xb = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
-        _lib.check(lib.plipmi_gemm_nt_ln(2, variant, M, N, K, _ptr(a), _ptr(w), _ptr(bias), None, 0, float(eps),
+        xb = torch.empty((M, N), dtype=hdt, device=a.device)
+        _lib.check(lib.plipmi_gemm_nt_ln(code, 2, variant, M, N, K, _ptr(a), _ptr(w), _ptr(bias), None, 0, float(eps),
                                          _ptr(out), _ptr(xb), _ptr(st), stream), "plipmi_gemm_nt_ln")
         return out, xb, st
 
 
-def split_planes(x: torch.Tensor):
-    """fp32 -> the engine's two-plane residual form (csrc/common.h split_f32): hi = bf16 plane (round to nearest, ties
-    away from zero), lo = int16 remainder of the bit pattern; ``join_planes`` is the exact inverse."""
-    u = x.contiguous().view(torch.int32).to(torch.int64) & 0xFFFFFFFF
-    t = (u + 0x8000) & 0xFFFFFFFF
-    hi = (t >> 16).to(torch.int32)
-    lo = (u - (t & 0xFFFF0000))                                   # in [-32768, 32767]
-    hi16 = torch.where(hi >= 32768, hi - 65536, hi).to(torch.int16).view(torch.bfloat16)
-    return hi16, lo.to(torch.int16)
+def split_planes(x: torch.Tensor, dtype=torch.bfloat16):
+    """fp32 -> the engine's two-plane residual form (csrc/common.h split_f32<H>), on the host in torch integer / float64
+    arithmetic; ``join_planes`` is the exact inverse.
+    bf16: hi = nearest bf16 (ties away from zero), lo = int16 remainder of the bit pattern, bits(x) == (hi << 16) + lo.
+    f16:  hi = nearest f16 (ties to even, saturating), lo = (x - hi) / 2^(E(hi) - 24) with E >= -14: an integer, |lo| <= 8192."""
+    if dtype == torch.bfloat16:
+        u = x.contiguous().view(torch.int32).to(torch.int64) & 0xFFFFFFFF
+        t = (u + 0x8000) & 0xFFFFFFFF
+        hi = (t >> 16).to(torch.int32)
+        lo = (u - (t & 0xFFFF0000))                                   # in [-32768, 32767]
+        hi16 = torch.where(hi >= 32768, hi - 65536, hi).to(torch.int16).view(torch.bfloat16)
+        return hi16, lo.to(torch.int16)
+    assert dtype == torch.float16
+    xc = x.contiguous().float()
+    hi = xc.clamp(-65504.0, 65504.0).to(torch.float16)
+    hf = hi.float()
+    eb = ((hf.view(torch.int32) >> 23) & 0xFF).clamp(min=113).to(torch.float64)
+    lo = ((xc.double() - hf.double()) * torch.pow(torch.tensor(2.0, dtype=torch.float64, device=x.device), 151.0 - eb))
+    return hi, lo.clamp(-32768, 32767).trunc().to(torch.int16)
 
 
 def join_planes(hi: torch.Tensor, lo: torch.Tensor) -> torch.Tensor:
+    if hi.dtype == torch.float16:
+        hf = hi.float()
+        eb = ((hf.view(torch.int32) >> 23) & 0xFF).clamp(min=113).to(torch.float64)
+        two = torch.tensor(2.0, dtype=torch.float64, device=hi.device)
+        return (hf.double() + lo.double() * torch.pow(two, eb - 151.0)).float()
     h = hi.view(torch.int16).to(torch.int64) & 0xFFFF
     u = ((h << 16) + lo.to(torch.int64)) & 0xFFFFFFFF
     u = torch.where(u >= 2 ** 31, u - 2 ** 32, u)
@@ -423,8 +464,7 @@ def join_planes(hi: torch.Tensor, lo: torch.Tensor) -> torch.Tensor:
 
 
 def gemm_variant_built(dtype, variant: int) -> bool:
-    code = _lib.BF16 if dtype in (torch.bfloat16, "bf16") else _lib.F32
-    return bool(_lib.load().plipmi_gemm_variant_built(code, int(variant)))
+    return bool(_lib.load().plipmi_gemm_variant_built(_code(dtype), int(variant)))
 
 
 def gemm_variants():

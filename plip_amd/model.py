@@ -44,9 +44,12 @@ class PlipOutput:
 
 class PlipModel:
     def __init__(self, cfg: PlipConfig, state_dict: Mapping[str, object], device="cuda:0", dtype="bf16",
-                 max_batch: int = 256):
+                 max_batch: int = 256, **engine_options):
+        """``dtype``: "bf16", "f16" (the reference's own GPU type; 8x smaller operand rounding at the same speed) or "f32".
+        ``engine_options``: the per-handle switches of :class:`plip_amd.engine.Engine` (ln_fold, pooled_last_block,
+        pack_captions, mfma_attention, graph_batch)."""
         self.config = cfg
-        self.engine = Engine(cfg, state_dict, device=device, dtype=dtype, max_batch=max_batch)
+        self.engine = Engine(cfg, state_dict, device=device, dtype=dtype, max_batch=max_batch, **engine_options)
         self.device = self.engine.device
         self.dtype = torch.float32          # I/O dtype; the compute dtype is engine.dtype_name
         self.training = False

@@ -283,12 +283,12 @@ def test_native_library_is_what_runs():
     """The extension must be the in-tree libplipmi.so (the driver records loaded .so files)."""
     from plip_amd import _lib
     lib = _lib.load()
-    assert lib.plipmi_version() >= 100
+    assert lib.plipmi_version() >= 300
     with open("/proc/self/maps") as f:
         assert "plip_amd/csrc/libplipmi.so" in f.read()
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
 def test_small_batch_graph_replay_is_bit_identical(dtype, engines):
     """plipmi_set_graph_batch: encode calls of <= 32 samples replay a captured hipGraph from the third call of a shape on
     (call 1 eager, call 2 capture + launch).  Same kernels in the same order: results must be BIT-identical to the eager
@@ -329,15 +329,16 @@ def test_small_batch_graph_replay_is_bit_identical(dtype, engines):
     eng.set_graph_batch(32)
 
 
+@pytest.mark.parametrize("half", ["bf16", "f16"])
 @pytest.mark.parametrize("case,max_batch", [("tiny_b6", 32), ("vitb32_b4", 32), ("vitb32_b4", 256)])
-def test_packed_captions_are_bit_identical(case, max_batch, engines):
+def test_packed_captions_are_bit_identical(case, max_batch, half, engines):
     """plipmi_set_text_packing: the text tower runs on rows 0 .. EOS of every caption only (causal attention + EOS pooling:
     the padding behind EOS cannot reach text_embeds).  Lengths, row offsets and the live-row count never leave the device.
     The embeddings must equal the padded computation BIT FOR BIT -- for both EOS rules (modeling_clip.py:561-581), both
     padding conventions (HF: EOS, OpenAI clip.tokenize: 0), with and without the tokenizer's mask, for captions of one
     token and of the full context, and when a captured graph is replayed on captions of other lengths."""
     from plip_amd import weights as W
-    model, cfg, sd, px, ids0, mask0 = engines(case, "bf16", max_batch)
+    model, cfg, sd, px, ids0, mask0 = engines(case, half, max_batch)
     eng = model.engine
     S = cfg.context_length
     B = 256 if max_batch == 256 else 8
@@ -386,7 +387,7 @@ def test_packed_captions_are_bit_identical(case, max_batch, engines):
         eng.set_graph_batch(32)
 
 
-def test_text_packing_needs_the_pooled_bf16_engine(engines):
+def test_text_packing_needs_a_pooled_16bit_engine(engines):
     model, *_ = engines("tiny_b6", "f32")
     with pytest.raises(RuntimeError):
         model.engine.set_text_packing(True)
@@ -405,3 +406,53 @@ def test_plip_class_pack_captions_is_bit_identical(engines):
     finally:
         model.engine.set_text_packing(False)
     assert np.array_equal(np.asarray(want), np.asarray(got))
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
+def test_device_resident_out_of_range_ids_surface_an_error(dtype, engines):
+    """plip.py:68 -> HF nn.Embedding raises on a token id outside the vocabulary (on a GPU: a device-side assert that
+    surfaces at the next synchronisation).  Ids that already live on the device are range-checked BY the embedding kernel;
+    the error surfaces at check_async() / the next encode call, exactly once, and a CPU tensor still raises at once."""
+    model, cfg, sd, px, ids, mask = engines("tiny_b6", dtype)
+    eng = model.engine
+    good = torch.from_numpy(ids).to(eng.device)
+    want = eng.encode_text(good, None).clone()
+    eng.check_async()                                             # nothing pending
+    for bad_value in (cfg.vocab_size, -1, 2 ** 40):
+        bad = good.clone()
+        bad[2, 3] = bad_value
+        eng.encode_text(bad, None)                                # enqueues; the ids are device memory
+        with pytest.raises(IndexError):
+            eng.check_async()
+        eng.check_async()                                         # reported once
+        eng.encode_text(bad, None)
+        torch.cuda.synchronize()
+        with pytest.raises(RuntimeError):                         # ... or by the next call on the handle
+            eng.encode_image(torch.from_numpy(px))
+        assert torch.equal(eng.encode_text(good, None), want)    # the handle keeps working
+        eng.check_async()
+    with pytest.raises(IndexError):
+        eng.encode_text(torch.from_numpy(ids).clamp(min=cfg.vocab_size), None)    # host-resident ids: checked up front
+
+
+def test_engine_switches_are_constructor_arguments_not_environment(engines, monkeypatch):
+    """Every behavioural switch of a handle is plipmi_config.flags / a setter: the library reads no environment variable, so
+    the variables earlier versions honoured must change nothing."""
+    from plip_amd.model import PlipModel
+    model, cfg, sd, px, ids, mask = engines("tiny_b6", "bf16")
+    tpx = torch.from_numpy(px)
+    want = model.get_image_features(pixel_values=tpx)
+    for var in ("PLIPMI_LN_FOLD", "PLIPMI_POOLED_LAST_BLOCK", "PLIPMI_ATTENTION", "PLIPMI_GRAPH_BATCH", "PLIPMI_TEXT_PACKING"):
+        monkeypatch.setenv(var, "0")
+    same = PlipModel(cfg, sd, dtype="bf16", max_batch=8)
+    other = PlipModel(cfg, sd, dtype="bf16", max_batch=8, ln_fold=False, mfma_attention=False, graph_batch=0)
+    try:
+        assert torch.equal(same.get_image_features(pixel_values=tpx), want)
+        rows = []
+        with other.engine.profile(rows):
+            got = other.get_image_features(pixel_values=tpx)
+        names = " ".join(r["name"] for r in rows)
+        assert "attention_valu" in names and "ln_bias" not in names and sum(r["calls"] for r in rows if r["name"] == "layernorm") > 2
+        assert (got - want).abs().max().item() < 6e-2           # another rounding plan of the same network
+    finally:
+        same.engine.close(); other.engine.close()

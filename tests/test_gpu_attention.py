@@ -31,25 +31,25 @@ CASES = [(3, 50, 12, False, False), (4, 77, 8, True, True), (2, 77, 8, True, Fal
 
 
 @pytest.mark.parametrize("B,S,H,causal,use_mask", CASES)
-@pytest.mark.parametrize("mode", ["valu_f32", "valu_bf16", "mfma_bf16"])
+@pytest.mark.parametrize("mode", ["valu_f32", "valu_bf16", "mfma_bf16", "valu_f16", "mfma_f16"])
 def test_attention_kernels(B, S, H, causal, use_mask, mode):
     from plip_amd.engine import attention
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(100 * S + H)
     qkv = torch.randn(B * S, 3 * H * 64, generator=g)
     qkv[:, : H * 64] *= 0.125 * 3.0          # q pre-scaled; x3 sharpens the softmax
-    dtype = torch.float32 if mode == "valu_f32" else torch.bfloat16
+    dtype = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}[mode.split("_")[1]]
     qkv = qkv.to(dev).to(dtype)
     mask = None
     if use_mask:
         lens = torch.randint(1, S + 1, (B,), generator=g)
         mask = (torch.arange(S)[None, :] < lens[:, None]).long().to(dev)
-    out = attention(qkv, B, S, H, causal, mask, impl=1 if mode == "mfma_bf16" else 0)
+    out = attention(qkv, B, S, H, causal, mask, impl=1 if mode.startswith("mfma") else 0)
     torch.cuda.synchronize()
     ref = _ref(qkv, B, S, H, causal, mask)
     err = (out.double() - ref).abs().max().item()
-    # fp32 kernel: roundoff; bf16 I/O: output rounding 2^-9 * |o| (|o| <~ 4) and, for MFMA, bf16 P
-    tol = {"valu_f32": 2e-5, "valu_bf16": 2e-2, "mfma_bf16": 3e-2}[mode]
+    # fp32 kernel: roundoff; 16-bit I/O: output rounding 2^-9 (bf16) / 2^-12 (f16) * |o| (|o| <~ 4) and, for MFMA, P in that type
+    tol = {"valu_f32": 2e-5, "valu_bf16": 2e-2, "mfma_bf16": 3e-2, "valu_f16": 2.5e-3, "mfma_f16": 4e-3}[mode]
     assert torch.isfinite(out).all()
     assert err < tol, f"{mode} B{B} S{S} H{H} causal={causal} mask={use_mask}: max err {err:.3e}"
 
@@ -59,7 +59,7 @@ def test_attention_argument_checks():
     from plip_amd.engine import attention
     qkv = torch.zeros(200, 3 * 64, device="cuda:0", dtype=torch.float32)
     with pytest.raises(PlipmiError):
-        attention(qkv, 1, 200, 1, impl=1)            # the MFMA kernels are bf16-only
+        attention(qkv, 1, 200, 1, impl=1)            # the MFMA kernels take the 16-bit types only
     out = attention(qkv, 1, 200, 1, impl=0)          # the exact kernel takes any S <= 1024
     assert out.shape == (200, 64)
     long = torch.zeros(2000, 3 * 64, device="cuda:0", dtype=torch.bfloat16)

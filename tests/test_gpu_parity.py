@@ -14,23 +14,29 @@ pytestmark = pytest.mark.gpu
 # Tolerances (max-abs).  fp32 engine: fp32-roundoff class (HF sdpa-vs-eager is 2e-6 on cosines).
 # bf16 engine: BASELINE.json north_star -- cosine-similarity logits within 1e-3 of the reference.
 # ("cos" is the stated bar and is applied to the cosine-similarity logits; single embedding components
-# of the 512-d unit vectors get 2x that; the 64-d toy model has 3x larger components, hence cos_tiny.)
+# of the 512-d unit vectors get 2x that -- the bf16 OPERAND rounding alone, everything else exact, puts text_embeds of the
+# bs=256 fixture at 1.2e-3, tests/test_oracle.py::test_operand_rounding_floor_of_the_text_tower --; the 64-d toy model has
+# 3x larger components, hence the TINY rows.)
+# f16 engine (11 significand bits against 8): a quarter of the bar.
 TOL = {
     "f32": dict(feat=2e-4, cos=1e-5, emb=1e-5, hidden=5e-4),
     "bf16": dict(feat=6e-2, cos=1e-3, emb=2e-3, hidden=1.5e-1),
+    "f16": dict(feat=1.5e-2, cos=2.5e-4, emb=4e-4, hidden=4e-2),
 }
-TINY_BF16 = dict(feat=6e-2, cos=3e-3, emb=4e-3, hidden=1.5e-1)
+TINY = {"bf16": dict(feat=6e-2, cos=3e-3, emb=4e-3, hidden=1.5e-1), "f16": dict(feat=1.5e-2, cos=7.5e-4, emb=1e-3, hidden=4e-2)}
+TINY_BF16 = TINY["bf16"]
+DTYPES = ["f32", "bf16", "f16"]
 
 
 def _tol(name, dtype):
-    return TINY_BF16 if (dtype == "bf16" and name.startswith("tiny")) else TOL[dtype]
+    return TINY[dtype] if (dtype in TINY and name.startswith("tiny")) else TOL[dtype]
 
 
 def _cos_logits(d, sd):
     return d / np.exp(np.float64(sd["logit_scale"]))
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_full_matrix_parity_bs256_vs_hf_golden(dtype, engines, golden):
     """BASELINE.json configs[2] as stated: bs=256, ALL 256 x 256 logits_per_image against HF CLIPModel itself
     (tests/golden/vitb32_b256.npz = oracle/make_golden.py on the batch bench.py times on rank 0)."""
@@ -57,25 +63,7 @@ def test_full_matrix_parity_bs256_vs_hf_golden(dtype, engines, golden):
         assert (got.argmax(1) == want.argmax(1)).mean() > 0.99
 
 
-def test_heavy_tailed_checkpoint_fp8_error_is_stated(engines, golden):
-    """The experimental fp8-weights mode on the heavy-tailed checkpoint (outlier channels x30-100, LayerNorm gains over
-    two decades): one fp8 scale per LayerNorm row is exactly what outliers break.  No parity credit is claimed for
-    it; the bound asserted here is the stated error (cosine logits), an order of magnitude above the bf16 bar."""
-    from plip_amd.model import PlipModel
-    g = golden("vitb32_b8_heavy")
-    cfg, sd, px, ids, mask = case_inputs("vitb32_b8_heavy")
-    model = PlipModel(cfg, sd, dtype="fp8", max_batch=8)
-    try:
-        out = model(input_ids=torch.from_numpy(ids), pixel_values=torch.from_numpy(px), attention_mask=torch.from_numpy(mask))
-        scale = np.exp(np.float64(sd["logit_scale"]))
-        err = np.abs(out.logits_per_image.cpu().numpy() - g["logits_per_image"]).max() / scale
-        print(f"fp8-weights engine, heavy-tailed checkpoint: cosine-logit max-abs-err {err:.2e}")
-        assert err < 3e-2, err
-    finally:
-        model.engine.close()
-
-
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("name", FULL_CASES)
 def test_golden_features_and_logits(name, dtype, engines, golden):
     g = golden(name)
@@ -96,7 +84,7 @@ def test_golden_features_and_logits(name, dtype, engines, golden):
         np.testing.assert_array_equal(lpi.argmax(1), g["logits_per_image"].argmax(1))
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_hidden_states_layer_by_layer_tiny(dtype, engines, golden):
     """HF hidden_states[l] of both towers after every block (modeling_clip.py:398-401)."""
     g = golden("tiny_b6")
@@ -112,7 +100,7 @@ def test_hidden_states_layer_by_layer_tiny(dtype, engines, golden):
 
 
 @pytest.mark.parametrize("name", ["vitb32_b4", "vitb32_b8_heavy"])
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_hidden_states_vitb32(dtype, name, engines, golden):
     """HF hidden_states of ViT-B/32 at layers 0, 1, 6, 12 (stored rows: CLS / last token, BOS / token 1).  Besides the
     max-abs bound, the RELATIVE rms error per layer is bounded -- a systematic per-layer drift (a wrong residual
@@ -121,7 +109,7 @@ def test_hidden_states_vitb32(dtype, name, engines, golden):
     g = golden(name)
     model, cfg, sd, px, ids, mask = engines(name, dtype)
     t = TOL[dtype]
-    rel_tol = 1.5e-2 if dtype == "bf16" else 2e-5
+    rel_tol = {"bf16": 1.5e-2, "f16": 2.5e-3, "f32": 2e-5}[dtype]
 
     def check(got, want, what):
         scale = max(1.0, float(np.abs(want).max()) / 4.0)            # heavy-tailed streams carry |x| ~ 100
@@ -138,7 +126,7 @@ def test_hidden_states_vitb32(dtype, name, engines, golden):
         check(h[:, 1], g["text_hidden_tok1"][layer], f"text layer {layer} tok1")
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_full_batch_properties_bs256(dtype, engines):
     """BASELINE size (bs=256, 224 px, 77 tokens): size-independent properties + oracle spot rows."""
     from plip_amd import weights as W
@@ -179,11 +167,12 @@ def test_full_batch_properties_bs256(dtype, engines):
     assert np.abs(sub_logits - o["logits_per_image"] / scale).max() < t["cos"]
 
 
-def test_bf16_argmax_agreement_with_fp32(engines):
-    """Zero-shot style decision: bf16 engine picks the same caption as the fp32 engine."""
+@pytest.mark.parametrize("half", ["bf16", "f16"])
+def test_16bit_argmax_agreement_with_fp32(half, engines):
+    """Zero-shot style decision: the 16-bit engines pick the same caption as the fp32 engine."""
     from plip_amd import weights as W
     m32, cfg, sd, *_ = engines("vitb32_b3_zero_pad_ln100", "f32")
-    m16 = engines("vitb32_b3_zero_pad_ln100", "bf16")[0]
+    m16 = engines("vitb32_b3_zero_pad_ln100", half)[0]
     px = torch.from_numpy(W.synthetic_pixels(cfg, 24, seed=21))
     ids = torch.from_numpy(W.synthetic_ids(cfg.replace(eos_token_id=49407), 10, seed=22, pad="zero")[0])
     a = m32(input_ids=ids, pixel_values=px).logits_per_image
@@ -219,14 +208,14 @@ def test_long_sequence_vision_tower_uses_exact_attention():
     px = W.synthetic_pixels(cfg, 3, 5)
     ids, mask = W.synthetic_ids(cfg, 3, 6)
     ref = O.clip_forward(px, ids, sd, cfg, mask)
-    for dtype, tol in (("f32", 2e-4), ("bf16", 6e-2)):
+    for dtype, tol in (("f32", 2e-4), ("bf16", 6e-2), ("f16", 1.5e-2)):
         m = PlipModel(cfg, sd, dtype=dtype, max_batch=4)
         img = m.get_image_features(pixel_values=torch.from_numpy(px)).cpu().numpy()
         assert np.abs(img - ref["image_features"]).max() < tol, dtype
         out = m(input_ids=torch.from_numpy(ids), pixel_values=torch.from_numpy(px), attention_mask=torch.from_numpy(mask))
         scale = float(np.exp(np.float64(sd["logit_scale"])))
         err = np.abs(out.logits_per_image.cpu().numpy() - ref["logits_per_image"]).max() / scale
-        assert err < (1e-5 if dtype == "f32" else 3e-3), (dtype, err)
+        assert err < {"f32": 1e-5, "bf16": 3e-3, "f16": 7.5e-4}[dtype], (dtype, err)
         m.engine.close()
 
 
@@ -244,7 +233,7 @@ def test_batch_edge_cases(engines):
     assert model.get_text_features(input_ids=tids[:0]).shape == (0, cfg.projection_dim)
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_long_sequence_vision_tower(dtype):
     """A ViT with 257 tokens (patch 4 on 64x64, the ViT-L/14 token count): the bf16 engine runs the chunked
     online-softmax MFMA attention, the fp32 engine the exact kernel; both against the CPU oracle."""
@@ -259,7 +248,7 @@ def test_long_sequence_vision_tower(dtype):
     model = PlipModel(cfg, sd, dtype=dtype, max_batch=4)
     try:
         want_h = O.vision_tower(px, sd, cfg, return_hidden=True)
-        t = TINY_BF16 if dtype == "bf16" else TOL["f32"]
+        t = TINY.get(dtype, TOL["f32"])
         for layer in (1, cfg.v_layers):
             h = model.engine.hidden("vision", layer, torch.from_numpy(px)).cpu().numpy()
             assert np.abs(h - want_h[1][layer]).max() < t["hidden"], f"layer {layer}"
@@ -271,55 +260,16 @@ def test_long_sequence_vision_tower(dtype):
         model.engine.close()
 
 
-def test_fp8_weights_engine_stated_tolerance(engines, golden):
-    """EXPERIMENTAL compute_dtype PLIPMI_FP8W (BASELINE configs[4] "fp8 MFMA weights"): QKV and fc1 on fp8 e4m3fn weights
-    (per-output-channel scales) and fp8 LayerNorm rows (per-row dynamic scales), fp32 accumulation.  fp8 activations
-    cannot hold the 1e-3 cosine bar of the bf16 engine; the tolerance stated here is 1e-2 on cosine-similarity logits
-    of ViT-B/32 (measured 2.7e-3) and 3e-2 on the 256-wide toy model (measured 1.3e-2); the arg-max is unchanged
-    wherever the reference's winner is separated by more than twice the tolerance."""
-    from plip_amd import weights as W
-    from plip_amd._lib import PlipmiError
-    from plip_amd.config import get_config
-    from plip_amd.model import PlipModel
-    g = golden("vitb32_b4")
-    _, cfg, sd, px, ids, mask = engines("vitb32_b4", "bf16")
-    model = PlipModel(cfg, sd, dtype="fp8", max_batch=8)
-    try:
-        out = model(input_ids=torch.from_numpy(ids), pixel_values=torch.from_numpy(px), attention_mask=torch.from_numpy(mask))
-        lpi = out.logits_per_image.cpu().numpy()
-        assert np.abs(_cos_logits(lpi, sd) - _cos_logits(g["logits_per_image"], sd)).max() < 1e-2
-        want = _cos_logits(g["logits_per_image"], sd)
-        top2 = np.sort(want, axis=1)[:, -2:]
-        clear = (top2[:, 1] - top2[:, 0]) > 2e-2            # rows whose winner is separated by more than the tolerance
-        np.testing.assert_array_equal(lpi.argmax(1)[clear], want.argmax(1)[clear])
-        assert (out.image_embeds.norm(dim=-1) - 1).abs().max().item() < 2e-6
-    finally:
-        model.engine.close()
-    cfg = get_config("tiny-w256")
-    sd = W.synthetic_state_dict(cfg, 0)
-    px, (ids, mask) = W.synthetic_pixels(cfg, 6, 1), W.synthetic_ids(cfg, 6, 2)
-    ref = O.clip_forward(px, ids, sd, cfg, mask)
-    model = PlipModel(cfg, sd, dtype="fp8", max_batch=8)
-    try:
-        out = model(input_ids=torch.from_numpy(ids), pixel_values=torch.from_numpy(px), attention_mask=torch.from_numpy(mask))
-        assert np.abs(_cos_logits(out.logits_per_image.cpu().numpy(), sd) - _cos_logits(ref["logits_per_image"], sd)).max() < 3e-2
-    finally:
-        model.engine.close()
-    with pytest.raises(PlipmiError):                      # 3 * 128 columns is not a whole number of 256-wide fp8 tiles
-        PlipModel(get_config("tiny"), W.synthetic_state_dict(get_config("tiny"), 0), dtype="fp8", max_batch=2)
-
-
 @pytest.mark.parametrize("name", ["vitb32_b4", "tiny_b6"])
-def test_pooled_last_block_equals_the_full_block(name, engines, monkeypatch):
+@pytest.mark.parametrize("half", ["bf16", "f16"])
+def test_pooled_last_block_equals_the_full_block(name, half, engines):
     """The encode paths run the last block's out_proj / fc1 / fc2 on the pooled row of each sample only (CLS / EOS; the
     other rows of that block cannot reach get_*_features).  Against an engine that computes every row
-    (PLIPMI_POOLED_LAST_BLOCK=0) the embeddings agree to the rounding noise of a different fp32 summation order in
+    (pooled_last_block=False = PLIPMI_FLAG_DENSE_LAST_BLOCK) the embeddings agree to the rounding noise of a different fp32 summation order in
     three GEMMs (bf16 operands identical), far inside the parity tolerance; hidden states are the full block's either way."""
     from plip_amd.model import PlipModel
-    model, cfg, sd, px, ids, mask = engines(name, "bf16")
-    monkeypatch.setenv("PLIPMI_POOLED_LAST_BLOCK", "0")
-    full = PlipModel(cfg, sd, dtype="bf16", max_batch=8)
-    monkeypatch.delenv("PLIPMI_POOLED_LAST_BLOCK")
+    model, cfg, sd, px, ids, mask = engines(name, half)
+    full = PlipModel(cfg, sd, dtype=half, max_batch=8, pooled_last_block=False)
     try:
         tpx, tids, tm = torch.from_numpy(px), torch.from_numpy(ids), torch.from_numpy(mask)
         a = model(input_ids=tids, pixel_values=tpx, attention_mask=tm)

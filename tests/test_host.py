@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.plipmi_version() == 100
+    assert lib.plipmi_version() == 300
     names = []
     i = 0
     while lib.plipmi_gemm_variant_name(i):
@@ -37,7 +37,7 @@ def test_struct_layouts_match_header():
     import ctypes as C
 
     from plip_amd import _lib
-    assert C.sizeof(_lib.Config) == 16 * 4
+    assert C.sizeof(_lib.Config) == 18 * 4
     assert C.sizeof(_lib.LayerWeights) == 16 * 8
     assert C.sizeof(_lib.Weights) == 15 * 8
     assert C.sizeof(_lib.KernelStat) == 96 + 8 + 3 * 8
@@ -301,3 +301,16 @@ def test_split_plane_host_mirror_is_exact():
     assert torch.equal(join_planes(hi, lo).view(torch.int32), x.view(torch.int32))
     assert ((hi.float() - x).abs() <= (x.bfloat16().float() - x).abs()).all()
     assert hi[4].item() == 1.0078125 and hi[5].item() == -1.0078125                  # ties go away from zero
+    # f16 engine: hi = nearest f16 (ties to even, saturating), lo = the remainder in units of 2^(E(hi) - 24): an integer of at
+    # most 14 bits, exact for 2^-15 <= |x| <= 65504 (csrc/common.h split_f32<f16_t>)
+    y = x.clamp(-65504.0, 65504.0)
+    y = torch.where(y.abs() < 2.0 ** -15, torch.zeros_like(y), y)
+    y[:4] = torch.tensor([2.0 ** -14, 65504.0, 1.00048828125, -2047.5])              # smallest normal, largest, a tie, a tie
+    hi, lo = split_planes(y, torch.float16)
+    assert hi.dtype == torch.float16 and lo.dtype == torch.int16 and int(lo.abs().max()) <= 8192
+    assert torch.equal(join_planes(hi, lo), y)
+    assert torch.equal(hi, y.half())
+    z = torch.tensor([1e5, -3e38, 1e-9])                                              # beyond the range: saturates / tiny: 2^-38 steps
+    hi, lo = split_planes(z, torch.float16)
+    assert hi[0].item() == 65504.0 and hi[1].item() == -65504.0
+    assert abs(join_planes(hi, lo)[2].item() - 1e-9) < 2.0 ** -38

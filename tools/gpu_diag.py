@@ -22,6 +22,7 @@ from plip_amd.engine import gemm_nt, gemm_variants  # noqa: E402
 from plip_amd.model import PlipModel  # noqa: E402
 
 dev = torch.device("cuda:0")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def sec_gemm():
@@ -192,7 +193,7 @@ def sec_lnbench():
         w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev).bfloat16()
         bias = torch.randn(N, generator=g).to(dev)
         row = []
-        for v in (36, 37, 42, 41):
+        for v in (3, 4, 2, 5, 1):
             try:
                 if epi in (0, 1):
                     out = torch.zeros(M, N, device=dev, dtype=torch.bfloat16)
@@ -254,74 +255,6 @@ def sec_latency():
     model.engine.close()
 
 
-def sec_prio():
-    """Two-stream step with the vision tower on a high-priority stream vs the default arrangement (in-process, interleaved)."""
-    from plip_amd.dist import sharded_pair_logits
-    cfg = get_config("ViT-B/32")
-    sd = W.synthetic_state_dict(cfg, 0)
-    B = 256
-    px = torch.from_numpy(W.synthetic_pixels(cfg, B, 1)).to(dev)
-    ids_np, mask_np = W.synthetic_ids(cfg, B, 2)
-    ids, mask = torch.from_numpy(ids_np).to(dev), torch.from_numpy(mask_np).to(dev)
-    model = PlipModel(cfg, sd, dtype="bf16", max_batch=B)
-    res = {False: [], True: []}
-    for rep in range(5):
-        for prio in (False, True):
-            model.engine.pair_vision_priority = prio
-            ms = _time(lambda: sharded_pair_logits(model, px, ids, mask, overlap=True), iters=10, warm=2)
-            if rep:
-                res[prio].append(ms)
-    for prio in (False, True):
-        print(f"vision tower on a high-priority stream = {prio}: two streams {np.median(res[prio]):6.3f} ms (min {min(res[prio]):6.3f})")
-    model.engine.close()
-
-
-def sec_fourstream():
-    """Experiment: the bs=256 step as FOUR independent chains (each tower's batch cut in two halves, on four HIP streams, two
-    handles sharing nothing) against the shipped two-stream arrangement -- does finer interleaving of kernels from
-    independent chains hide more of the GEMMs' prologue / epilogue phases?"""
-    cfg = get_config("ViT-B/32")
-    sd = W.synthetic_state_dict(cfg, 0)
-    B = 256
-    px = torch.from_numpy(W.synthetic_pixels(cfg, B, 1)).to(dev)
-    ids_np, mask_np = W.synthetic_ids(cfg, B, 2)
-    ids, mask = torch.from_numpy(ids_np).to(dev), torch.from_numpy(mask_np).to(dev)
-    mA = PlipModel(cfg, sd, dtype="bf16", max_batch=B)
-    mB = PlipModel(cfg, sd, dtype="bf16", max_batch=B)
-    s1, s2 = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
-    h = B // 2
-
-    def two():
-        return mA.engine.encode_pair(px, ids, mask, True, overlap=True)
-
-    def four():
-        main = torch.cuda.current_stream(dev)
-        s1.wait_stream(main); s2.wait_stream(main)
-        with torch.cuda.stream(s1):
-            a = mA.engine.encode_pair(px[:h], ids[:h], mask[:h], True, overlap=True)
-        with torch.cuda.stream(s2):
-            b = mB.engine.encode_pair(px[h:], ids[h:], mask[h:], True, overlap=True)
-        main.wait_stream(s1); main.wait_stream(s2)
-        return a, b
-
-    ia, ta = two()
-    (i1, t1), (i2, t2) = four()
-    torch.cuda.synchronize()
-    print("four-chain vs two-stream embeddings max diff", (torch.cat([i1, i2]) - ia).abs().max().item(), (torch.cat([t1, t2]) - ta).abs().max().item())
-    res = {"two": [], "four": []}
-    for rep in range(5):
-        for name, fn in (("two", two), ("four", four)):
-            ms = _time(fn, iters=10, warm=2)
-            if rep:
-                res[name].append(ms)
-    for name in res:
-        print(f"{name:5s} streams/chains: both towers {np.median(res[name]):6.3f} ms (min {min(res[name]):6.3f})")
-    for pol in (0, 3):
-        mA.engine.pair_policy = pol; mB.engine.pair_policy = pol
-        print(f"  four chains, tile policy {pol}: {_time(four, iters=10, warm=2):6.3f} ms")
-    mA.engine.close(); mB.engine.close()
-
-
 def sec_libgemm():
     """Calibration only (never used by the product): what the vendor GEMM library (hipBLASLt/rocBLAS behind
     torch.nn.functional.linear) reaches on the production shapes -- an external yardstick for gemm_nt."""
@@ -369,82 +302,6 @@ def sec_towerswap():
         model.engine.close()
         del model
         torch.cuda.empty_cache()
-
-
-def sec_fp8():
-    """EXPERIMENTAL fp8 (e4m3fn) GEMM test hook: exactness against fp64 of the same fp8 operands, then TFLOP/s on
-    the production QKV / fc1 shapes beside the bf16 kernels."""
-    g = torch.Generator().manual_seed(0)
-    for (M, N, K, epi) in ((300, 256, 128, 0), (515, 512, 768, 0), (1000, 768, 3072, 1)):
-        a = (torch.randn(M, K, generator=g)).to(dev).to(torch.float8_e4m3fn)
-        w = (torch.randn(N, K, generator=g) / K ** 0.5 * 4).to(dev).to(torch.float8_e4m3fn)
-        bias = torch.randn(N, generator=g).to(dev)
-        ref = a.float().double() @ w.float().double().T + bias.double()
-        if epi == 1:
-            ref = ref * torch.sigmoid(1.702 * ref)
-        for v in range(4):
-            y = gemm_nt(a, w, bias, epilogue=epi, variant=v)
-            torch.cuda.synchronize()
-            err = (y.double() - ref).abs().max().item()
-            print(f"fp8 check {M}x{N}x{K} epi{epi} variant {v}: max err {err:.3e} (|ref| max {ref.abs().max().item():.2f}, bf16 output rounding ~{ref.abs().max().item() * 2 ** -9:.1e})")
-    shapes = [("v.qkv", 12800, 2304, 768, 0), ("v.fc1", 12800, 3072, 768, 1), ("v.fc2*", 12800, 768, 3072, 0),
-              ("t.qkv", 19712, 1536, 512, 0), ("t.fc1", 19712, 2048, 512, 1), ("big", 8192, 8192, 8192, 0)]
-    for name, M, N, K, epi in shapes:
-        a8 = torch.randn(M, K, generator=g).to(dev).to(torch.float8_e4m3fn)
-        w8 = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev).to(torch.float8_e4m3fn)
-        a16, w16 = a8.to(torch.bfloat16), w8.to(torch.bfloat16)
-        bias = torch.randn(N, generator=g).to(dev)
-        out = torch.zeros(M, N, device=dev, dtype=torch.bfloat16)
-        row = []
-        for v in range(4):
-            ms = _time(lambda: gemm_nt(a8, w8, bias, epilogue=epi, variant=v, out=out), iters=20)
-            row.append(f"fp8 v{v} {2.0 * M * N * K / ms / 1e9:7.1f}")
-        ms = _time(lambda: gemm_nt(a16, w16, bias, epilogue=epi, out=out), iters=20)
-        print(f"{name:7s} {M}x{N}x{K} epi{epi}: " + "  ".join(row) + f"   bf16 auto {2.0 * M * N * K / ms / 1e9:7.1f} TFLOP/s")
-
-
-def sec_fp8w():
-    """EXPERIMENTAL fp8-weights engine (QKV + fc1 in fp8): error against the CPU oracle and tower throughput."""
-    from oracle import clip_oracle as O
-    for arch, B in (("tiny-w256", 6), ("ViT-B/32", 4)):
-        cfg = get_config(arch)
-        sd = W.synthetic_state_dict(cfg, 0)
-        px = W.synthetic_pixels(cfg, B, 1)
-        ids, mask = W.synthetic_ids(cfg, B, 2)
-        ref = O.clip_forward(px, ids, sd, cfg, mask)
-        scale = float(np.exp(np.float64(sd["logit_scale"])))
-        for dtype in ("bf16", "fp8"):
-            model = PlipModel(cfg, sd, dtype=dtype, max_batch=8)
-            out = model(input_ids=torch.from_numpy(ids), pixel_values=torch.from_numpy(px), attention_mask=torch.from_numpy(mask))
-            cos = np.abs(out.logits_per_image.cpu().numpy() - ref["logits_per_image"]).max() / scale
-            emb = max(np.abs(out.image_embeds.cpu().numpy() - ref["image_embeds"]).max(),
-                      np.abs(out.text_embeds.cpu().numpy() - ref["text_embeds"]).max())
-            print(f"{arch:10s} {dtype:5s}: cosine-logit max-abs-err {cos:.3e}   embedding component max-abs-err {emb:.3e}")
-            model.engine.close()
-    for arch, B in (("ViT-B/32", 256), ("ViT-L/14@336px", 32)):
-        cfg = get_config(arch)
-        sd = W.synthetic_state_dict(cfg, 0)
-        px = torch.from_numpy(W.synthetic_pixels(cfg, B, 1)).to(dev)
-        ids_np, mask_np = W.synthetic_ids(cfg, B, 2)
-        ids = torch.from_numpy(ids_np).to(dev)
-        for dtype in ("bf16", "fp8"):
-            model = PlipModel(cfg, sd, dtype=dtype, max_batch=B)
-            ms_i = _time(lambda: model.engine.encode_image(px), iters=5, warm=2)
-            ms_t = _time(lambda: model.engine.encode_text(ids, None), iters=5, warm=2)
-            print(f"{arch:16s} B={B} {dtype:5s}: image {ms_i:7.2f} ms ({B / ms_i * 1e3:8.0f} img/s, {cfg.image_flops() * B / ms_i / 1e9:6.1f} TF/s)   "
-                  f"text {ms_t:6.2f} ms ({B / ms_t * 1e3:8.0f} cap/s)")
-            if dtype == "fp8":
-                rows = []
-                with model.engine.profile(rows):
-                    model.engine.encode_image(px)
-                    torch.cuda.synchronize()
-                tot = sum(r["total_ms"] for r in rows)
-                for r in sorted(rows, key=lambda r: -r["total_ms"])[:6]:
-                    tf = f"{r['flops'] / r['total_ms'] / 1e9:7.1f} TF/s" if r["flops"] else ""
-                    print(f"      {r['name']:58s} {r['total_ms']:8.3f} ms {100 * r['total_ms'] / tot:5.1f}%  {tf}")
-            model.engine.close()
-            del model
-            torch.cuda.empty_cache()
 
 
 def sec_ldpad():
@@ -543,36 +400,112 @@ def sec_gemmtrace():
               f"pro {pro[i] / tick_us:6.2f} loop {loop[i] / tick_us:7.2f} epi {epi_t[i] / tick_us:6.2f} end {end[i] / tick_us:7.2f} us")
 
 
+def _step_inputs(B=256):
+    cfg = get_config("ViT-B/32")
+    sd = W.synthetic_state_dict(cfg, 0)
+    px = torch.from_numpy(W.synthetic_pixels(cfg, B, 1000)).to(dev)
+    ids_np, mask_np = W.synthetic_ids(cfg, B, 2000)
+    return cfg, sd, px, torch.from_numpy(ids_np).to(dev), torch.from_numpy(mask_np).to(dev)
+
+
 def sec_policy():
-    """In-process interleaved A/B of GEMM tile policies (forced variant vs the cost model), one and two streams."""
+    """In-process interleaved A/B of the step under tile policies / forced tiles / write-through stores, one and two
+    streams, bf16 and f16.  arguments: list of 'dtype:policy:variant:wt' (variant -1 = the policy's own choice)."""
     from plip_amd import _lib
     from plip_amd.dist import sharded_pair_logits
     lib = _lib.load()
-    cfg = get_config("ViT-B/32")
-    sd = W.synthetic_state_dict(cfg, 0)
     B = 256
-    px = torch.from_numpy(W.synthetic_pixels(cfg, B, 1)).to(dev)
-    ids_np, mask_np = W.synthetic_ids(cfg, B, 2)
-    ids, mask = torch.from_numpy(ids_np).to(dev), torch.from_numpy(mask_np).to(dev)
-    model = PlipModel(cfg, sd, dtype="bf16", max_batch=B)
-    pols = [-10, -1, -12, -13]       # one stream: always the cost model; two streams: pair policy 0 (cost model) / 1 / 2 / 3
-    res = {(p, ov): [] for p in pols for ov in (False, True)}
+    cfg, sd, px, ids, mask = _step_inputs(B)
+    arms = sys.argv[2:] or ["bf16:3:-1:0", "bf16:3:-1:1", "bf16:4:-1:0", "bf16:4:-1:1", "bf16:5:-1:0", "f16:3:-1:0", "f16:4:-1:0"]
+    models = {}
+    res = {(a, ov): [] for a in arms for ov in (False, True)}
     for rep in range(4):
-        for pol in pols:
-            lib.plipmi_set_gemm_variant(pol if pol >= 0 else -1)
-            model.engine.pair_policy = {-10: 0, -12: 2, -13: 3}.get(pol, 1)
+        for arm in arms:
+            dt, pol, var, wt = arm.split(":")
+            if dt not in models:
+                models[dt] = PlipModel(cfg, sd, dtype=dt, max_batch=B)
+            model = models[dt]
+            lib.plipmi_set_gemm_variant(int(var))
+            lib.plipmi_set_gemm_store_wt(int(wt))
+            model.engine.pair_policy = int(pol)
+            model.engine.single_policy = 0 if int(pol) == 3 else int(pol)
             for ov in (False, True):
                 ms = _time(lambda: sharded_pair_logits(model, px, ids, mask, overlap=ov), iters=10, warm=2)
                 if rep:                      # rep 0 = warm-up of clocks / caches
-                    res[(pol, ov)].append(ms)
+                    res[(arm, ov)].append(ms)
     lib.plipmi_set_gemm_variant(-1)
-    names = gemm_variants()
-    for pol in pols:
-        a, b = res[(pol, False)], res[(pol, True)]
-        label = {-10: "cost model/pair policy 0", -1: "cost model/pair policy 1", -12: "cost model/pair policy 2",
-                 -13: "cost model/pair policy 3"}.get(pol) or names[pol]
-        print(f"policy {label:34s} one stream {np.median(a):6.3f} ms (min {min(a):6.3f})   "
+    lib.plipmi_set_gemm_store_wt(0)
+    for arm in arms:
+        a, b = res[(arm, False)], res[(arm, True)]
+        print(f"dtype:policy:variant:write-through {arm:16s} one stream {np.median(a):6.3f} ms (min {min(a):6.3f})   "
               f"two streams {np.median(b):6.3f} ms (min {min(b):6.3f})  -> {B / np.median(b) * 1e3:7.0f} pairs/s")
+
+
+def sec_tiles():
+    """The product epilogues (LayerNorm-folded consumers, split-plane producers) on the bs=256 production shapes: us per
+    launch for every 256-wide tile variant, with and without write-through stores, bf16 (f16 on request) -- interleaved
+    in one process.  The vendor library (plain bias epilogue) on the same shapes as the yardstick."""
+    import torch.nn.functional as F
+    from plip_amd import _lib
+    from plip_amd.engine import gemm_nt_ln, split_planes
+    lib = _lib.load()
+    hdt = torch.float16 if (len(sys.argv) > 2 and sys.argv[2] == "f16") else torch.bfloat16
+    shapes = [("v.qkv", 12800, 2304, 768, 0), ("v.fc1", 12800, 3072, 768, 1), ("v.out", 12800, 768, 768, 3),
+              ("v.fc2", 12800, 768, 3072, 3), ("t.qkv", 19712, 1536, 512, 0), ("t.fc1", 19712, 2048, 512, 1),
+              ("t.out", 19712, 512, 512, 3), ("t.fc2", 19712, 512, 2048, 3)]
+    variants = [2, 3, 4, 5, 6, 7, 8]
+    names = gemm_variants()
+    print("variants:", {v: names[v] for v in variants}, "dtype", hdt)
+    g = torch.Generator().manual_seed(0)
+    for name, M, N, K, mode in shapes:
+        a = torch.randn(M, K, generator=g).to(dev).to(hdt)
+        w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev).to(hdt)
+        bias = torch.randn(N, generator=g).to(dev)
+        fl = 2.0 * M * N * K / 1e6
+        if mode == 3:
+            hi, lo = split_planes(torch.randn(M, N, generator=g).to(dev), hdt)
+            run = lambda v: gemm_nt_ln(3, a, w, bias, variant=v, out=(hi, lo))
+        else:
+            out = torch.zeros(M, N, device=dev, dtype=hdt)
+            xs = torch.randn(M, K, generator=g).to(dev).reshape(M, K // 64, 64)
+            st = torch.stack((xs.sum(-1), ((xs - xs.mean(-1, keepdim=True)) ** 2).sum(-1)), dim=-1).contiguous()
+            run = lambda v: gemm_nt_ln(mode, a, w, bias, st, variant=v, out=out)
+        best = {}
+        for rep in range(2):
+            for wt in (0, 1):
+                lib.plipmi_set_gemm_store_wt(wt)
+                for v in variants:
+                    us = _time(lambda: run(v), iters=20, warm=3) * 1e3
+                    best[(v, wt)] = min(best.get((v, wt), 1e9), us)
+        lib.plipmi_set_gemm_store_wt(0)
+        lib_us = _time(lambda: F.linear(a, w, bias.to(hdt)), iters=20, warm=3) * 1e3
+        row = "  ".join(f"v{v}: {best[(v, 0)]:6.1f}/{best[(v, 1)]:6.1f}" for v in variants)
+        bv = min(best, key=best.get)
+        print(f"{name:6s} {M}x{N}x{K} {('ln_bias', 'ln_qgelu', '', 'resid_split')[mode]:11s} us plain/write-through  {row}   "
+              f"| best v{bv[0]} wt{bv[1]} {fl / best[bv]:7.1f} TF/s | vendor F.linear+bias {lib_us:6.1f} us {fl / lib_us:7.1f} TF/s")
+
+
+def sec_parity():
+    """Where the cosine error of the 16-bit engines comes from at the benchmark size: vitb32_b256 against its HF golden,
+    per engine form (dtype x LayerNorm fold x pooled last block)."""
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "vitb32_b256.npz"))
+    cfg, sd, px, ids, mask = _step_inputs(256)
+    assert np.array_equal(gold["ids"], ids.cpu().numpy())
+    scale = float(np.exp(np.float64(sd["logit_scale"])))
+    for dt in ("f32", "bf16", "f16"):
+        for kw in ({}, {"ln_fold": False}, {"pooled_last_block": False}):
+            if dt == "f32" and kw:
+                continue
+            model = PlipModel(cfg, sd, dtype=dt, max_batch=256, **kw)
+            out = model(input_ids=ids, pixel_values=px, attention_mask=mask)
+            lpi = out.logits_per_image.cpu().numpy() / scale
+            want = gold["logits_per_image"] / scale
+            e_img = np.abs(out.image_embeds.cpu().numpy() - gold["image_embeds"])
+            e_txt = np.abs(out.text_embeds.cpu().numpy() - gold["text_embeds"])
+            print(f"{dt:5s} {str(kw):30s} cosine max {np.abs(lpi - want).max():.3e} rms {np.sqrt(((lpi - want) ** 2).mean()):.3e} | "
+                  f"image_embeds max {e_img.max():.3e} rms {np.sqrt((e_img ** 2).mean()):.3e} | text_embeds max {e_txt.max():.3e} "
+                  f"rms {np.sqrt((e_txt ** 2).mean()):.3e} | argmax agreement {(lpi.argmax(1) == want.argmax(1)).mean():.4f}")
+            model.engine.close()
 
 
 def sec_overlap():
@@ -589,35 +522,6 @@ def sec_overlap():
         for ov in (False, True):
             ms = _time(lambda: sharded_pair_logits(model, px, ids, mask, overlap=ov), iters=20, warm=3)
             print(f"overlap={ov}: {ms:.3f} ms/step  {B / ms * 1e3:.0f} pairs/s")
-    # experiment: more kernel-level blending -- two engines, each on half the batch
-    m2 = PlipModel(cfg, sd, dtype="bf16", max_batch=B)
-    sA, sB = torch.cuda.Stream(), torch.cuda.Stream()
-    h = B // 2
-
-    def four_streams():
-        main = torch.cuda.current_stream()
-        sA.wait_stream(main); sB.wait_stream(main)
-        with torch.cuda.stream(sA):
-            model.engine.encode_pair(px[:h], ids[:h], mask[:h])
-        with torch.cuda.stream(sB):
-            m2.engine.encode_pair(px[h:], ids[h:], mask[h:])
-        main.wait_stream(sA); main.wait_stream(sB)
-
-    def two_streams_swapped():
-        main = torch.cuda.current_stream()
-        sA.wait_stream(main); sB.wait_stream(main)
-        model.engine._set_policy(1)
-        with torch.cuda.stream(sA):
-            model.engine.encode_image(px[:h]); model.engine.encode_text(ids[:h], mask[:h])
-        with torch.cuda.stream(sB):
-            m2.engine.encode_text(ids[h:], mask[h:]); m2.engine.encode_image(px[h:])
-        model.engine._set_policy(0)
-        main.wait_stream(sA); main.wait_stream(sB)
-
-    for rep in range(2):
-        for name, fn in (("four streams (2 engines x half batch)", four_streams), ("two streams, half batches, swapped tower order", two_streams_swapped)):
-            ms = _time(fn, iters=20, warm=3)
-            print(f"{name}: {ms:.3f} ms/step  {B / ms * 1e3:.0f} pairs/s")
     a = sharded_pair_logits(model, px, ids, mask, overlap=False)[0]
     b = sharded_pair_logits(model, px, ids, mask, overlap=True)[0]
     torch.cuda.synchronize()
@@ -653,6 +557,6 @@ def sec_e2e():
 
 if __name__ == "__main__":
     t0 = time.time()
-    {"gemm": sec_gemm, "attn": sec_attn, "tiny": sec_tiny, "vitb32": sec_vitb32, "gemmbench": sec_gemmbench, "lnbench": sec_lnbench, "latency": sec_latency, "prio": sec_prio, "fourstream": sec_fourstream, "libgemm": sec_libgemm, "fp8": sec_fp8, "fp8w": sec_fp8w, "towerswap": sec_towerswap, "e2e": sec_e2e, "gemmone": sec_gemmone, "policy": sec_policy, "ldpad": sec_ldpad, "gemmtrace": sec_gemmtrace,
+    {"gemm": sec_gemm, "attn": sec_attn, "tiny": sec_tiny, "vitb32": sec_vitb32, "gemmbench": sec_gemmbench, "lnbench": sec_lnbench, "latency": sec_latency, "libgemm": sec_libgemm, "tiles": sec_tiles, "parity": sec_parity, "towerswap": sec_towerswap, "e2e": sec_e2e, "gemmone": sec_gemmone, "policy": sec_policy, "ldpad": sec_ldpad, "gemmtrace": sec_gemmtrace,
      "overlap": sec_overlap}[sys.argv[1]]()
     print(f"[{sys.argv[1]} done in {time.time() - t0:.1f} s]")
