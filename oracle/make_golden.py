@@ -38,9 +38,16 @@ CASES = {
     # trained-checkpoint-like statistics (weights.heavy_tailed_state_dict): outlier residual channels x30-100,
     # LayerNorm gains over two decades, logit_scale = ln 100
     "vitb32_b8_heavy": ("ViT-B/32", 8, 5, 31, 32, "eos", LN100),
+    # the same checkpoint judged at the benchmark size: a maximum over 65 536 logits, like vitb32_b256 (slim)
+    "vitb32_b256_heavy": ("ViT-B/32", 256, 5, 1031, 2031, "eos", LN100),
+    # BASELINE.json configs[4]'s architecture end to end: 336 px / patch 14 = 577 vision tokens (chunked MFMA attention inside
+    # a 24-layer tower), 588 -> 640 zero-padded patch rows, width 1024 / 16 heads, text width 768 / 12 heads, projection 768
+    "vitl14_336_b2": ("ViT-L/14@336px", 2, 3, 41, 42, "eos", None),
 }
 # cases whose fixtures hold embeddings and logits only (no features of every row / hidden states)
-SLIM = {"vitb32_b256"}
+SLIM = {"vitb32_b256", "vitb32_b256_heavy"}
+# hidden-state rows are stored at these depths only (fractions of the tower depth) for the big architectures
+HIDDEN_DEPTHS = {"vitl14_336_b2": (0, 1, 12, 24)}
 
 
 def fingerprint(sd) -> np.ndarray:
@@ -83,6 +90,15 @@ def main(only=None):
         elif cfg.v_width <= 128 and cfg.v_tokens <= 64:
             save["vision_hidden"] = np.stack(vh)
             save["text_hidden"] = np.stack(th)
+        elif name in HIDDEN_DEPTHS:
+            dv = HIDDEN_DEPTHS[name]
+            dt = tuple(min(d, cfg.t_layers) for d in (0, 1, cfg.t_layers // 2, cfg.t_layers))
+            eos = np.argmax(ids == get_config(CASES[name][0]).eos_token_id, axis=1)
+            save["vision_depths"], save["text_depths"] = np.array(dv), np.array(dt)
+            save["vision_hidden_cls"] = np.stack([vh[d][:, 0, :] for d in dv])
+            save["vision_hidden_last_token"] = np.stack([vh[d][:, -1, :] for d in dv])
+            save["text_hidden_bos"] = np.stack([th[d][:, 0, :] for d in dt])
+            save["text_hidden_eos"] = np.stack([th[d][np.arange(len(ids)), eos, :] for d in dt])
         else:
             save["vision_hidden_cls"] = np.stack([h[:, 0, :] for h in vh])
             save["vision_hidden_last_token"] = np.stack([h[:, -1, :] for h in vh])

@@ -93,7 +93,8 @@ struct GemmParams {
   // done, logical tile id, HW_ID, k tiles, 0}, s_memtime ticks.  nullptr on the product path.
   unsigned long long* trace = nullptr;
   // test hook (PLIPMI_GEMM_ABLATE, timeline runs only; results are wrong by construction):
-  // bit 0 = skip the global->LDS fills of the K loop, bit 1 = skip the MFMA block, bit 2 = skip the epilogue
+  // bit 0 = skip the global->LDS fills of the K loop, bit 1 = skip the MFMA block, bit 2 = skip the epilogue,
+  // bit 3 = skip the K loop's barriers, bit 4 = skip the K loop's LDS fragment reads
   int ablate = 0;
   // output stores write through the XCD's L2 (sc0 sc1) instead of leaving dirty lines for the end-of-kernel write-back
   int store_wt = 0;
@@ -272,9 +273,10 @@ void gemm_nt_kernel(const GemmParams p) {
   constexpr int ELEMS16 = 16 / sizeof(T);  // elements per 16-byte chunk
   using OutT = std::conditional_t<sizeof(T) == 4, float, T>;
   static_assert(!(epi_is_ln(EPI) || epi_emits_stats(EPI)) || sizeof(T) == 2, "LayerNorm folding is a 16-bit-engine form");
-  static_assert(SCHED == 0 || SCHED == 1 || SCHED == 5 || SCHED == 6, "schedules: 0, 1, 5 (fill2), 6 (fill3)");
+  static_assert(SCHED == 0 || SCHED == 1 || SCHED == 5 || SCHED == 6 || SCHED == 7, "schedules: 0, 1, 5 (fill2), 6 (fill3), 7");
+  static_assert(SCHED != 7 || NSTAGE == 3, "the wave-group-staggered fill needs the slack of the three-stage ring");
   static_assert(NSTAGE == 2 || NSTAGE == 3, "two LDS stages or a ring of three");
-  constexpr bool kSpread = SCHED == 5 || SCHED == 6;
+  constexpr bool kSpread = SCHED == 5 || SCHED == 6 || SCHED == 7;
   static_assert(!kSpread || ADDR == 1, "the spread fill batches buffer-form requests");
   constexpr int BK = 8 * ELEMS16;          // 128-byte rows
   constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, STAGE = A_BYTES + W_BYTES;
@@ -294,6 +296,9 @@ void gemm_nt_kernel(const GemmParams p) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
+  // SCHED 7: as 6, but the second half of the workgroup's waves issue their fill one K step later than the first half, so
+  // the two waves sharing a SIMD never queue LDS-DMA requests in the same K step
+  const int fill_shift = SCHED == 7 ? (wave >= WM * WN / 2 ? 1 : 0) : 0;
   const int mi_w = kUneven ? (RB - wm * MI < MI ? RB - wm * MI : MI) : MI;   // this wave's 32-row blocks (wave-uniform)
   auto a_piece = [&](int i) -> bool {      // does this wave own A piece i of a tile?
     return PA == PA_MIN || i < PA_MIN || i * (NT / 8) + wave * 8 < BM;
@@ -474,13 +479,21 @@ void gemm_nt_kernel(const GemmParams p) {
     // fragments of K-step ks+1 are fetched from LDS before the MFMAs of step ks issue.  (Rows past an uneven wave row's
     // last block are read too -- in-bounds LDS bytes nobody multiplies -- so the reads stay branch-free.)
     u32x4 xf[2][MI], wf[2][NI];
+    const bool rd = !(p.ablate & 16);
+    if (rd) {
 #pragma unroll
-    for (int i = 0; i < MI; ++i) xf[0][i] = *reinterpret_cast<const u32x4*>(sb + a_tile + i * 32 * 128 + foff[0]);
+      for (int i = 0; i < MI; ++i) xf[0][i] = *reinterpret_cast<const u32x4*>(sb + a_tile + i * 32 * 128 + foff[0]);
 #pragma unroll
-    for (int j = 0; j < NI; ++j) wf[0][j] = *reinterpret_cast<const u32x4*>(sb + w_tile + j * 32 * 128 + foff[0]);
+      for (int j = 0; j < NI; ++j) wf[0][j] = *reinterpret_cast<const u32x4*>(sb + w_tile + j * 32 * 128 + foff[0]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < MI; ++i) { xf[0][i] = u32x4{1u, 2u, 3u, 4u}; xf[1][i] = u32x4{1u, 2u, 3u, 4u}; }
+#pragma unroll
+      for (int j = 0; j < NI; ++j) { wf[0][j] = u32x4{1u, 2u, 3u, 4u}; wf[1][j] = u32x4{1u, 2u, 3u, 4u}; }
+    }
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      if (ks < 3) {
+      if (ks < 3 && rd) {
 #pragma unroll
         for (int i = 0; i < MI; ++i)
           xf[(ks + 1) & 1][i] = *reinterpret_cast<const u32x4*>(sb + a_tile + i * 32 * 128 + foff[ks + 1]);
@@ -489,7 +502,7 @@ void gemm_nt_kernel(const GemmParams p) {
           wf[(ks + 1) & 1][j] = *reinterpret_cast<const u32x4*>(sb + w_tile + j * 32 * 128 + foff[ks + 1]);
       }
       if constexpr (kSpread) {
-        if (fill_buf >= 0 && ks < kFillParts) stage_issue_part(fill_buf, ks);
+        if (fill_buf >= 0 && ks - fill_shift >= 0 && ks - fill_shift < kFillParts) stage_issue_part(fill_buf, ks - fill_shift);
       }
       if constexpr (SCHED >= 1) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -547,7 +560,7 @@ void gemm_nt_kernel(const GemmParams p) {
       if (!(p.ablate & 2)) compute(cur, fetch ? nxt2 : -1);
       if (fetch) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kLeave) : "memory");
       else wait_vm0();
-      __syncthreads();  // tile kt+1 visible to all waves; stage `cur` free for tile kt+3
+      if (!(p.ablate & 8)) __syncthreads();  // tile kt+1 visible to all waves; stage `cur` free for tile kt+3
       cur = cur == 2 ? 0 : cur + 1;
       nxt2 = nxt2 == 2 ? 0 : nxt2 + 1;
     }
@@ -570,7 +583,7 @@ void gemm_nt_kernel(const GemmParams p) {
       }
       if (!(p.ablate & 2)) compute(cur, (p.ablate & 1) ? -1 : (cur ^ 1));
       wait_vm0();
-      __syncthreads();
+      if (!(p.ablate & 8)) __syncthreads();
     }
     if constexpr (kRowOperand) {  // the residual / position rows of the first 32-row block travel during the last K step
       load_block(0, add[0]);

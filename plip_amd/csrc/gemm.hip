@@ -12,8 +12,8 @@ static const GemmVariant kVariants[kNumVariants] = {
     {"128x128_w2x2_glds64", 128, 128, 256},       {"128x128_w2x2_bufdma", 128, 128, 256},
     {"256x256_w4x2_bufdma", 256, 256, 512},       {"320x256_w2x4_bufdma", 320, 256, 512},
     {"192x256_w2x4_bufdma", 192, 256, 512},       {"160x256_w2x4_ring3", 160, 256, 512},
-    {"160x256_w2x4_ring3_topfill", 160, 256, 512}, {"160x256_w2x4_2stage", 160, 256, 512},
-    {"128x256_w2x4_ring3", 128, 256, 512},
+    {"160x256_w2x4_ring3_stagger", 160, 256, 512}, {"160x256_w2x4_2stage", 160, 256, 512},
+    {"192x256_w2x4_fill2", 192, 256, 512},
 };
 
 int gemm_num_cus() {

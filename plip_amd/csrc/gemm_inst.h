@@ -41,9 +41,9 @@ int launch_naive(const GemmParams& p, hipStream_t stream) {
 //   3  320x256, 2x4 waves, two LDS stages
 //   4  192x256, 2x4 waves, two LDS stages
 //   5  160x256, 2x4 waves (3 + 2 row blocks), ring of three LDS stages (two tiles of lookahead)
-//   6  160x256, as 5 with the whole fill issued at the top of the iteration      [16-bit types, experiment]
+//   6  160x256, as 5 with the fill of the second wave half one K step later       [16-bit types, experiment]
 //   7  160x256, two LDS stages                                                    [16-bit types, experiment]
-//   8  128x256, 2x4 waves, ring of three                                          [16-bit types, experiment]
+//   8  192x256, fill packed into 2 K steps                                        [16-bit types, experiment]
 constexpr int kNumVariants = 9;
 
 template <typename T>
@@ -70,9 +70,9 @@ struct GemmTable {
         case 3: return launch_tiled<T, 320, 256, 2, 4, EPI, kH ? 6 : 0, 2, 1>;
         case 4: return launch_tiled<T, 192, 256, 2, 4, EPI, kH ? 6 : 1, 2, 1>;
         case 5: return launch_tiled<T, 160, 256, 2, 4, EPI, kH ? 6 : 1, 3, 1>;
-        case 6: if constexpr (kH) return launch_tiled<T, 160, 256, 2, 4, EPI, 1, 3, 1>; else return nullptr;
+        case 6: if constexpr (kH) return launch_tiled<T, 160, 256, 2, 4, EPI, 7, 3, 1>; else return nullptr;
         case 7: if constexpr (kH) return launch_tiled<T, 160, 256, 2, 4, EPI, 6, 2, 1>; else return nullptr;
-        case 8: if constexpr (kH) return launch_tiled<T, 128, 256, 2, 4, EPI, 6, 3, 1>; else return nullptr;
+        case 8: if constexpr (kH) return launch_tiled<T, 192, 256, 2, 4, EPI, 5, 2, 1>; else return nullptr;
         case -2: if constexpr (!kLn) return launch_naive<T, EPI>; else return nullptr;
         default: return nullptr;
       }

@@ -446,17 +446,16 @@ def split_planes(x: torch.Tensor, dtype=torch.bfloat16):
     xc = x.contiguous().float()
     hi = xc.clamp(-65504.0, 65504.0).to(torch.float16)
     hf = hi.float()
-    eb = ((hf.view(torch.int32) >> 23) & 0xFF).clamp(min=113).to(torch.float64)
-    lo = ((xc.double() - hf.double()) * torch.pow(torch.tensor(2.0, dtype=torch.float64, device=x.device), 151.0 - eb))
+    eb = ((hf.view(torch.int32) >> 23) & 0xFF).clamp(min=113)
+    lo = torch.ldexp(xc.double() - hf.double(), 151 - eb)           # exact scaling by a power of two
     return hi, lo.clamp(-32768, 32767).trunc().to(torch.int16)
 
 
 def join_planes(hi: torch.Tensor, lo: torch.Tensor) -> torch.Tensor:
     if hi.dtype == torch.float16:
         hf = hi.float()
-        eb = ((hf.view(torch.int32) >> 23) & 0xFF).clamp(min=113).to(torch.float64)
-        two = torch.tensor(2.0, dtype=torch.float64, device=hi.device)
-        return (hf.double() + lo.double() * torch.pow(two, eb - 151.0)).float()
+        eb = ((hf.view(torch.int32) >> 23) & 0xFF).clamp(min=113)
+        return (hf.double() + torch.ldexp(lo.double(), eb - 151)).float()
     h = hi.view(torch.int16).to(torch.int64) & 0xFFFF
     u = ((h << 16) + lo.to(torch.int64)) & 0xFFFFFFFF
     u = torch.where(u >= 2 ** 31, u - 2 ** 32, u)

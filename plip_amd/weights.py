@@ -169,6 +169,25 @@ def synthetic_pixels(cfg: PlipConfig, batch: int, seed: int = 1) -> np.ndarray:
     return rs.standard_normal((batch, 3, cfg.image_size, cfg.image_size)).astype(np.float32)
 
 
+def synthetic_tiles(cfg: PlipConfig, batch: int, seed: int = 1000) -> np.ndarray:
+    """uint8 [B,H,W,3] tiles with STRUCTURE (BASELINE.json configs[3]'s "synthetic corpus"): a stain-like base colour per
+    tile, a low-frequency field per channel (a random 7 x 7 grid, nearest-upsampled) and pixel noise.  Pure-noise tiles
+    all land on one embedding direction, so a zero-shot arg-max over class prompts would put the whole corpus in one
+    class; these spread over several.  Deterministic (numpy ``RandomState``)."""
+    rs = np.random.RandomState(seed)
+    n = cfg.image_size
+    out = np.empty((batch, n, n, 3), dtype=np.uint8)
+    cell = -(-n // 7)
+    for b in range(batch):
+        base = rs.uniform(40.0, 215.0, size=3)
+        amp = rs.uniform(10.0, 90.0, size=3)
+        grid = rs.uniform(-1.0, 1.0, size=(7, 7, 3))
+        field = np.repeat(np.repeat(grid, cell, axis=0), cell, axis=1)[:n, :n, :]
+        noise = rs.uniform(-12.0, 12.0, size=(n, n, 3))
+        out[b] = np.clip(base[None, None, :] + amp[None, None, :] * field + noise, 0.0, 255.0).astype(np.uint8)
+    return out
+
+
 def synthetic_ids(cfg: PlipConfig, batch: int, seed: int = 2, pad: str = "eos"):
     """int64 [B,ctx] token ids shaped like tokenizer output and the matching mask.
 

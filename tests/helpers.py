@@ -170,3 +170,50 @@ def load_reference_plip_module():
         return mod
     finally:
         sys.dont_write_bytecode = old
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the reference's host pattern, restated (the GPU box has no /root/reference)
+# ---------------------------------------------------------------------------------------------------------------
+class ReferenceHostLoops:
+    """What /root/reference/plip.py:31-103 does on the host, restated so that it can run where the reference tree is not
+    mounted: ``datasets.Dataset`` -> ``set_transform`` / ``map`` -> ``DataLoader`` -> ``self.model.get_*_features(**batch)``
+    -> ``.detach().cpu().numpy()`` -> ``np.stack``; key-side-only normalisation (:73-76); arg-max labels (:89-103).
+    tests/test_reference_loop.py asserts, on the CPU box where both exist, that this produces the very arrays the imported
+    original produces on the same model -- so driving THIS against libplipmi.so on the GPU box exercises surface B1
+     the way the reference's own loop does."""
+
+    def __init__(self, model, processor, device):
+        self.model, self.preprocess, self.device = model.to(device), processor, device
+
+    def _embed(self, dataset, batch_size, features):
+        from torch.utils.data import DataLoader
+        rows = []
+        with torch.no_grad():
+            for batch in DataLoader(dataset, batch_size=batch_size):
+                batch = {name: t.to(self.device) for name, t in batch.items()}        # kwargs by name, tensors on the device
+                rows.extend(features(**batch).detach().cpu().numpy())                 # one synchronising D2H per batch
+        return np.stack(rows)
+
+    def encode_images(self, images, batch_size):            # plip.py:31-53
+        from datasets import Dataset
+        ds = Dataset.from_dict({"image": images})
+        ds.set_format("torch")
+        ds.set_transform(lambda el: self.preprocess(images=el["image"], return_tensors="pt"))
+        return self._embed(ds, batch_size, self.model.get_image_features)
+
+    def encode_text(self, text, batch_size):                # plip.py:55-71
+        from datasets import Dataset
+        ds = Dataset.from_dict({"text": text}).map(
+            lambda el: self.preprocess(text=el["text"], return_tensors="pt", max_length=77, padding="max_length", truncation=True),
+            batched=True, remove_columns=["text"])
+        ds.set_format("torch")
+        return self._embed(ds, batch_size, self.model.get_text_features)
+
+    @staticmethod
+    def cosine_similarity(keys, space):                     # plip.py:73-76: only the key side is normalised
+        return (keys / np.linalg.norm(keys, ord=2, axis=-1, keepdims=True)) @ space.T
+
+    def zero_shot_classification(self, images, labels):     # plip.py:89-103
+        sim = self.cosine_similarity(self.encode_images(images, 8), self.encode_text(labels, 8))
+        return [labels[i] for i in np.argmax(sim, axis=-1)]

@@ -146,6 +146,53 @@ def test_bf16_precision_plans_hold_the_cosine_bar(name, plan, golden):
     assert np.abs(o["text_embeds"] - g["text_embeds"][:n]).max() < 2e-3
 
 
+def test_operand_rounding_floor_of_the_text_tower(golden):
+    """WHY the bf16 engine's text_embeds sit 3x further from HF than its image_embeds at the benchmark size,
+    costed on the CPU: 48 captions of the bs=256 fixture through the numpy emulation with ONE class of operand rounding
+    at a time, everything else exact.  bf16 weight rounding alone already exceeds 6e-4 (the perturbation is the same for
+    every token of a caption, so attention does not average it out); all six bf16 roundings give the 1.2e-3 the engine
+    measures -- it is the operand type, not a kernel -- and the same plan in IEEE half (PLIPMI_F16, same MFMA rate) is
+    8x closer."""
+    from oracle import precision_model as P
+    g = golden("vitb32_b256")
+    cfg, sd, px, ids, mask = case_inputs("vitb32_b256")
+    n = 48
+    want = g["text_embeds"][:n]
+
+    def err(dtype, sites):
+        e = O.l2_normalize(P.text_tower(ids[:n], sd, cfg, mask[:n], "folded", dtype=dtype, sites=sites))
+        d = np.abs(e - want)
+        return float(d.max()), float(np.sqrt((d.astype(np.float64) ** 2).mean()))
+    exact = err("bf16", ())
+    w_only = err("bf16", ("w",))
+    acts = err("bf16", ("xa", "qkv", "p", "att", "mlp"))
+    full = err("bf16", P.ALL_SITES)
+    half = err("f16", P.ALL_SITES)
+    print(f"text_embeds max / rms vs HF: exact {exact}, bf16 weights only {w_only}, bf16 activations only {acts}, "
+          f"bf16 all {full}, f16 all {half}")
+    assert exact[0] < 2e-6
+    assert w_only[0] > 6e-4 and w_only[1] > acts[1]          # the weights are the larger half, and alone past 6e-4
+    assert 8e-4 < full[0] < 2e-3
+    assert abs(full[1] ** 2 - (w_only[1] ** 2 + acts[1] ** 2)) < 0.25 * full[1] ** 2     # the two halves add in quadrature
+    assert half[0] < 2.5e-4 and half[1] < full[1] / 6
+
+
+@pytest.mark.parametrize("name", ["vitb32_b4", "vitb32_b8_heavy"])
+def test_f16_precision_plan(name, golden):
+    """The PLIPMI_F16 engine's plan (IEEE-half MFMA operands, LayerNorm folded) against the HF golden vectors, emulated:
+    a quarter of the cosine bar, also on the heavy-tailed checkpoint whose residual stream reaches |x| ~ 90."""
+    from oracle import precision_model as P
+    g = golden(name)
+    cfg, sd, px, ids, mask = case_inputs(name)
+    n = 4
+    o = P.clip_forward(px[:n], ids[:n], sd, cfg, mask[:n], "folded", dtype="f16")
+    scale = np.exp(np.float64(sd["logit_scale"]))
+    err = np.abs(o["logits_per_image"] - g["logits_per_image"][:n, :n]).max() / scale
+    assert err < 2.5e-4, (name, err)
+    assert np.abs(o["image_embeds"] - g["image_embeds"][:n]).max() < 4e-4
+    assert np.abs(o["text_embeds"] - g["text_embeds"][:n]).max() < 4e-4
+
+
 def test_bf16_rounding_helper_is_rne():
     import torch
     from oracle.precision_model import bf16
@@ -199,3 +246,28 @@ def test_openai_layout_converter_against_independent_openai_style_model():
     bad["visual.transformer.resblocks.0.attn.in_proj_weight"] = np.concatenate([w[D:2 * D], w[:D], w[2 * D:]], 0)
     sd_bad, _ = W.normalize_state_dict(bad)
     assert np.abs(O.vision_tower(px, sd_bad, cfg) - want_i).max() > 1e-3
+
+
+def test_config3_zero_shot_fixture_is_the_reference_head(golden):
+    """tests/golden/config3_zero_shot.npz (HF CLIPModel, oracle/make_config3_fixture.py): inputs regenerate from seeds, the
+    oracle reproduces HF's scores on a few tiles, and the reference's head (zero_shot.py:12-13: dot product, per-row
+    arg-max) populates at least five of the ten classes -- the property VERDICT r2 found missing."""
+    from oracle.make_config3_fixture import tiles_to_pixels
+    from plip_amd import weights as W
+    from plip_amd.config import get_config
+    g = golden("config3_zero_shot")
+    tile_seed, prompt_seed, weight_seed, n, pool = (int(v) for v in g["seeds"])
+    cfg = get_config("ViT-B/32")
+    sd = W.synthetic_state_dict(cfg, weight_seed)
+    u8 = W.synthetic_tiles(cfg, n, tile_seed)
+    np.testing.assert_allclose([u8.astype(np.float64).sum(), (u8.astype(np.float64) ** 2).sum()], g["tiles_fingerprint"],
+                               rtol=0, atol=0)
+    cand, _ = W.synthetic_ids(cfg, pool, seed=prompt_seed)
+    np.testing.assert_array_equal(cand[g["candidate_index"]], g["prompts"])
+    rows = [0, 100, 511]
+    img = O.l2_normalize(O.vision_tower(tiles_to_pixels(u8[rows]), sd, cfg))
+    txt = O.l2_normalize(O.text_tower(g["prompts"], sd, cfg, None))
+    assert np.abs(img @ txt.T - g["scores"][rows]).max() < FP32_COS_TOL
+    np.testing.assert_array_equal(g["scores"].argmax(1), g["argmax"])
+    hist = np.bincount(g["argmax"], minlength=10)
+    assert (hist >= n // 25).sum() >= 5, hist

@@ -10,8 +10,10 @@ unmodified via ``object.__new__(PLIP)`` with ``self.model`` := ``plip_amd.model.
   stand-in of tests/helpers.py, so what is under test is the HOST surface -- kwargs by name, ``.to(device)``, tensor
   results, batch loop -- and ``plip_amd.PLIP``'s own loops against the reference's on identical inputs, including the
   centre-crop rule on a 227 x 224 image.
-* GPU variant: the same loop against the MI355X engine.  It needs BOTH a GPU and /root/reference, which the GPU box
-  does not mount, so there it reports "skipped"; it runs wherever both exist.
+* GPU variant: the GPU box does not mount /root/reference, so there the loop is ``tests.helpers.ReferenceHostLoops`` -- a
+  restatement of plip.py:31-103's host pattern which the CPU variant pins to the imported original (same arrays on the
+  same model) -- driven against the MI355X engine through libplipmi.so, in all three compute dtypes.  Where the reference
+  tree IS mounted next to a GPU, the original itself runs too.
 The reference's ``reproducibility`` ``CLIPEmbedder`` cannot be driven this way at all: it imports the OpenAI ``clip``
 package, which is not installed.
 """
@@ -22,7 +24,7 @@ import torch
 from tests import helpers as Hh
 
 pytest.importorskip("datasets")
-pytestmark = pytest.mark.skipif(not Hh.reference_available(), reason="/root/reference is not mounted on this box")
+needs_reference = pytest.mark.skipif(not Hh.reference_available(), reason="/root/reference is not mounted on this box")
 
 
 def _cfg():
@@ -58,6 +60,7 @@ def _reference_instance(model, processor, device):
     return ref
 
 
+@needs_reference
 def test_reference_host_loops_on_the_drop_in_model_cpu(tmp_path):
     from oracle import clip_oracle as O
     from plip_amd import weights as W
@@ -104,25 +107,46 @@ def test_reference_host_loops_on_the_drop_in_model_cpu(tmp_path):
     # k beyond the corpus: the reference's argsort()[:, -k:] hands back every column
     assert ours.retrieval(CAPTIONS, top_k=10).shape == ref.retrieval(CAPTIONS, top_k=10).shape == (4, 5)
 
+    # --- the restatement the GPU box runs (no /root/reference there) IS the reference's loop: identical arrays -------------
+    restated = Hh.ReferenceHostLoops(model, processor, "cpu")
+    np.testing.assert_array_equal(restated.encode_images(images, batch_size=2), got_img)
+    np.testing.assert_array_equal(restated.encode_text(CAPTIONS, batch_size=3), got_txt)
+    np.testing.assert_array_equal(restated.cosine_similarity(got_img, got_txt), ref._cosine_similarity(got_img, got_txt))
+    assert restated.zero_shot_classification(images, labels) == ref_pred
+
 
 @pytest.mark.gpu
-def test_reference_host_loops_on_the_mi355x_engine(tmp_path):
+@pytest.mark.parametrize("dtype,tol", [("f32", 2e-4), ("bf16", 6e-2), ("f16", 1.5e-2)])
+def test_reference_host_loops_on_the_mi355x_engine(dtype, tol, tmp_path):
+    """Surface B1 through libplipmi.so: the reference's host loop (restated; the original too where the tree is mounted)
+    feeds ``PlipModel`` on the GPU -- ``**batch`` kwargs, device tensors in, ``.detach().cpu().numpy()`` out."""
     from oracle import clip_oracle as O
     from plip_amd import weights as W
     from plip_amd.model import PlipModel
     cfg = _cfg()
     sd = W.synthetic_state_dict(cfg, 2)
-    model = PlipModel(cfg, sd, dtype="f32", max_batch=8)
+    model = PlipModel(cfg, sd, dtype=dtype, max_batch=8)
     try:
         processor, tok = _processor(tmp_path)
-        ref = _reference_instance(model, processor, "cuda")
         images = _images()
-        got_img = ref.encode_images(images, batch_size=2)
-        got_txt = ref.encode_text(CAPTIONS, batch_size=3)
         px = processor(images=images, return_tensors="np")["pixel_values"]
         enc = tok(CAPTIONS, return_tensors="np", max_length=77, padding="max_length", truncation=True)
-        assert np.abs(got_img - O.vision_tower(px, sd, cfg)).max() < 2e-4
-        assert np.abs(got_txt - O.text_tower(enc["input_ids"], sd, cfg, enc["attention_mask"])).max() < 2e-4
-        assert len(ref.zero_shot_classification(images, CAPTIONS[:3])) == 5
+        want_img, want_txt = O.vision_tower(px, sd, cfg), O.text_tower(enc["input_ids"], sd, cfg, enc["attention_mask"])
+        loops = [Hh.ReferenceHostLoops(model, processor, "cuda")]
+        if Hh.reference_available():
+            loops.append(_reference_instance(model, processor, "cuda"))
+        outs = []
+        for loop in loops:
+            got_img = loop.encode_images(images, batch_size=2)
+            got_txt = loop.encode_text(CAPTIONS, batch_size=3)
+            assert got_img.shape == (5, cfg.projection_dim) and got_img.dtype == np.float32
+            assert np.abs(got_img - want_img).max() < tol and np.abs(got_txt - want_txt).max() < tol
+            pred = loop.zero_shot_classification(images, CAPTIONS[:3])
+            assert len(pred) == 5 and set(pred) <= set(CAPTIONS[:3])
+            outs.append((got_img, got_txt, pred))
+        if len(outs) == 2:                       # original and restatement drive the engine identically
+            np.testing.assert_array_equal(outs[0][0], outs[1][0])
+            np.testing.assert_array_equal(outs[0][1], outs[1][1])
+            assert outs[0][2] == outs[1][2]
     finally:
         model.engine.close()
