@@ -13,7 +13,8 @@ per GPU (weak scaling: the global batch is 256*N pairs).
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
         --master-port 29500 bench.py --gpus 8 --steps 20 --warmup 3
 
-Rank 0 prints ONE JSON line (see README / DESIGN.md for the fields).
+Rank 0 prints ONE JSON line (see README / DESIGN.md section 5 for the fields).  `value` comes from the first timed window
+of exactly --steps steps; two more windows of the same length follow and are reported beside it (`windows`).
 """
 from __future__ import annotations
 
@@ -30,6 +31,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}   # dense MFMA peaks, MI355X_MICROARCH.md "Chip-level parameters"
+HBM_PEAK_GBS = 8000.0                                          # HBM3E 8 TB/s, same table
 
 
 def parse():
@@ -43,7 +45,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="lower bound of CPU work for the baseline sample")
     ap.add_argument("--no-profile", action="store_true")
-    ap.add_argument("--no-fp32-tower", action="store_true", help="skip the BASELINE configs[1] side measurement")
+    ap.add_argument("--no-extras", "--no-fp32-tower", dest="no_extras", action="store_true",
+                    help="skip the side measurements (f16 engine, dense last block, caption packing, larger batches, "
+                         "ViT-L/14@336 share, fp32 engine)")
     ap.add_argument("--overlap", type=int, default=1, help="1: text tower on a second HIP stream (default), 0: one stream")
     return ap.parse_args()
 
@@ -96,7 +100,7 @@ def cpu_baseline(cfg, sd, seconds):
     ids, mask = W.synthetic_ids(cfg, B, seed=2)
     try:
         from oracle import hf_reference as H
-        torch.set_num_threads(cores)
+        torch.set_num_threads(cores)       # (torchrun exports OMP_NUM_THREADS=1: the thread count is set explicitly)
         model = H.build_model(cfg, sd, "sdpa")
         tp, ti, tm = torch.from_numpy(px), torch.from_numpy(ids), torch.from_numpy(mask)
 
@@ -149,13 +153,13 @@ def cpu_baseline(cfg, sd, seconds):
     return res
 
 
-def executed_gflop_per_pair(cfg, args):
+def executed_gflop_per_pair(cfg, dtype):
     """`algorithmic_tflops` prices a pair at SURVEY.md section 8d's dense figure (14.777 GFLOP for ViT-B/32: every token
-    through every Linear).  The bf16 engine runs the LAST block's out_proj / fc1 / fc2 only on the row that is pooled
-    afterwards (CLS / EOS) -- the other rows of that block cannot reach get_image_features / get_text_features -- so it
-    executes slightly fewer FLOPs than that; kernel rooflines always use executed FLOPs."""
+    through every Linear).  The 16-bit engines run the LAST block's out_proj / fc1 / fc2 only on the row that is pooled
+    afterwards (CLS / EOS) -- the other rows of that block cannot reach get_image_features / get_text_features -- so they
+    execute slightly fewer FLOPs than that; `executed_tflops` and every kernel roofline use executed FLOPs."""
     full = cfg.pair_flops()
-    pooled = args.dtype in ("bf16", "f16")
+    pooled = dtype in ("bf16", "f16")
     saved = 0.0
     if pooled:
         for tokens, D, F in ((cfg.v_tokens, cfg.v_width, cfg.v_mlp), (cfg.context_length, cfg.t_width, cfg.t_mlp)):
@@ -164,29 +168,30 @@ def executed_gflop_per_pair(cfg, args):
             "pooled_last_block": bool(pooled)}
 
 
-def logits_error_vs_hf_golden(model, cfg, sd, px, ids, mask, B, args):
+def logits_error_vs_hf_golden(model, cfg, sd, px, ids, mask, B, arch, fixture="vitb32_b256"):
     """BASELINE.json metric, second half: "logits max-abs-err vs HF".  Rank 0's timed batch (weights seed 0, pixels seed
     1000, ids seed 2000, bs=256, ViT-B/32) is exactly the input of tests/golden/vitb32_b256.npz, whose logits come from
     HF CLIPModel itself (oracle/make_golden.py) -- so the error is over ALL 256 x 256 logits.  Other batch sizes /
     architectures have no fixture: they fall back to the CPU oracle on 8 pairs and say so."""
     scale = float(np.exp(np.float64(sd["logit_scale"])))
-    path = os.path.join(ROOT, "tests", "golden", "vitb32_b256.npz")
+    path = os.path.join(ROOT, "tests", "golden", fixture + ".npz")
     got = model(input_ids=ids, pixel_values=px, attention_mask=mask)
     lpi = got.logits_per_image.cpu().numpy()
-    if args.arch == "ViT-B/32" and B == 256 and os.path.exists(path):
+    if arch == "ViT-B/32" and B == 256 and os.path.exists(path):
         g = np.load(path)
         if np.array_equal(g["ids"], ids.cpu().numpy()):
             want = g["logits_per_image"]
             top2 = np.sort(want / scale, axis=1)[:, -2:]
             clear = (top2[:, 1] - top2[:, 0]) > 2e-3
             return {"cosine": float(np.abs(lpi / scale - want / scale).max()),
+                    "cosine_rms": float(np.sqrt(((lpi / scale - want / scale) ** 2).mean())),
                     "scaled_logits": float(np.abs(lpi - want).max()),
                     "image_embeds": float(np.abs(got.image_embeds.cpu().numpy() - g["image_embeds"]).max()),
                     "text_embeds": float(np.abs(got.text_embeds.cpu().numpy() - g["text_embeds"]).max()),
                     "argmax_agreement": float((lpi.argmax(1) == want.argmax(1)).mean()),
-                    "argmax_agreement_clear_rows": float((lpi.argmax(1)[clear] == want.argmax(1)[clear]).mean()),
+                    "argmax_agreement_clear_rows": float((lpi.argmax(1)[clear] == want.argmax(1)[clear]).mean()) if clear.any() else None,
                     "clear_rows": int(clear.sum()),
-                    "vs": "HF transformers CLIPModel (CPU fp32) golden logits, tests/golden/vitb32_b256.npz",
+                    "vs": f"HF transformers CLIPModel (CPU fp32) golden logits, tests/golden/{fixture}.npz",
                     "pairs": 256, "logits_compared": int(want.size)}
     from oracle import clip_oracle as O
     n = min(8, B)
@@ -194,6 +199,17 @@ def logits_error_vs_hf_golden(model, cfg, sd, px, ids, mask, B, args):
     return {"cosine": float(np.abs(lpi[:n, :n] / scale - o["logits_per_image"] / scale).max()),
             "vs": "CPU oracle (numpy fp32 restatement of HF CLIPModel, pinned to HF golden vectors); no HF fixture for this config",
             "pairs": n, "logits_compared": n * n}
+
+
+def timed_steps(step, n, dev, warmup=0):
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(n):
+        out = step()
+    torch.cuda.synchronize(dev)
+    return (time.perf_counter() - t0) / n, out
 
 
 def main():
@@ -238,23 +254,31 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    def window():
+        """exactly --steps steps between two fences; max over ranks"""
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            o = step()
+        fence()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, o
+
     for _ in range(args.warmup):
         step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed, out = window()                                    # THE measurement
+    more = [window()[0] for _ in range(2)]                     # two more windows of the same length, reported beside it
     logits = out[0]
     assert logits.shape == (B, B * world) and bool(torch.isfinite(logits).all())
 
-    # ---- roofline of the dominant kernel: HIP events on the launch stream(s), same K steps, same stream
-    # setup as the timed region; then once more single-stream, where no other kernel shares the CUs ----------
+    # ---- roofline of the dominant kernel: HIP events recorded by the library on the launch stream, over --steps steps on ONE
+    # stream -- the kernel owns the GPU, which is what the rocprofv3 kernel trace of the same command measures
+    # (profiles/r03_rocprofv3_*).  With two streams an event bracket also contains the time a kernel spends queued behind the
+    # other tower's workgroups: that measurement is kept as a side field only.
     def profile_pass(overlap):
         """-> (rows merged per kernel symbol, rows per (kernel, role)); the engine tags GEMM launches 'name|role'."""
         raw = []
@@ -270,8 +294,6 @@ def main():
         rows = sorted(merged.values(), key=lambda r: -r["total_ms"])
         return rows, raw
 
-    HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
-
     def roofline_of(rows, name=None):
         dom = next((r for r in rows if r["flops"] > 0 and r["name"].startswith("gemm") and (name is None or r["name"] == name)), None)
         if not dom:
@@ -279,64 +301,62 @@ def main():
         ach = dom["flops"] / (dom["total_ms"] * 1e-3) / 1e12
         peak = PEAK_TFLOPS[args.dtype]
         gem = [r for r in rows if r["name"].startswith("gemm")]
-        return {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                "traffic": None, "kernel": dom["name"], "avg_launch_us": round(dom["total_ms"] * 1e3 / dom["calls"], 2),
-                "flops_per_launch": round(dom["flops"] / dom["calls"]),
-                "all_gemm_tflops": round(sum(r["flops"] for r in gem) / (sum(r["total_ms"] for r in gem) * 1e9), 1)}
+        rf = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+              "traffic": None, "kernel": dom["name"], "avg_launch_us": round(dom["total_ms"] * 1e3 / dom["calls"], 2),
+              "launches_per_step": dom["calls"] / args.steps,
+              "flops_per_launch": round(dom["flops"] / dom["calls"]),
+              "all_gemm_tflops": round(sum(r["flops"] for r in gem) / (sum(r["total_ms"] for r in gem) * 1e9), 1)}
+        tr = load_pmc_traffic(dom["name"])
+        if tr:
+            rf["traffic"] = tr["bytes_per_launch"]
+            rf["traffic_note"] = tr["note"]
+        return rf
 
     def by_role(raw, kernel):
-        """The dominant kernel symbol serves launches with different ceilings (out-proj: 10 B of residual traffic per
-        output element for 2*D FLOP -> HBM-bound; fc2: MFMA-bound).  Split its launches by role and price each against
+        """The dominant kernel symbol serves launches with different ceilings (out-proj: 8 B of residual traffic per
+        output element for 2*D FLOP -> HBM-side; fc2: at the ridge).  Split its launches by role and price each against
         the bound that applies (ridge = peak FLOP/s / peak B/s)."""
         peak = PEAK_TFLOPS[args.dtype]
         ridge = peak * 1e12 / (HBM_PEAK_GBS * 1e9)
-        out = []
+        rows = []
         for r in raw:
             if r["name"].split("|")[0] != kernel or "|" not in r["name"] or not r["total_ms"]:
                 continue
             t = r["total_ms"] * 1e-3
             tf, gbs = r["flops"] / t / 1e12, r["bytes"] / t / 1e9
             intensity = r["flops"] / max(r["bytes"], 1.0)
-            out.append({"role": r["name"].split("|")[1], "calls_per_step": r["calls"] / args.steps,
-                        "avg_launch_us": round(r["total_ms"] * 1e3 / r["calls"], 2), "tflops": round(tf, 1),
-                        "algorithmic_GBps": round(gbs, 1), "flop_per_byte": round(intensity, 1),
-                        "bound": "hbm" if intensity < ridge else "mfma",
-                        "frac": round(gbs / HBM_PEAK_GBS, 4) if intensity < ridge else round(tf / peak, 4),
-                        "frac_mfma": round(tf / peak, 4), "frac_hbm": round(gbs / HBM_PEAK_GBS, 4)})
-        return sorted(out, key=lambda x: -x["calls_per_step"] * x["avg_launch_us"])
+            rows.append({"role": r["name"].split("|")[1], "calls_per_step": r["calls"] / args.steps,
+                         "avg_launch_us": round(r["total_ms"] * 1e3 / r["calls"], 2), "tflops": round(tf, 1),
+                         "algorithmic_GBps": round(gbs, 1), "flop_per_byte": round(intensity, 1),
+                         "bound": "hbm" if intensity < ridge else "mfma",
+                         "frac": round(gbs / HBM_PEAK_GBS, 4) if intensity < ridge else round(tf / peak, 4),
+                         "frac_mfma": round(tf / peak, 4), "frac_hbm": round(gbs / HBM_PEAK_GBS, 4)})
+        return sorted(rows, key=lambda x: -x["calls_per_step"] * x["avg_launch_us"])
 
-    roofline = None
+    roofline = roofline_2s = roles = None
     kernels = []
-    roofline_1s = None
-    roles = None
+    one_stream_ms = None
     if not args.no_profile:
-        rows, raw = profile_pass(bool(args.overlap))
-        total = sum(r["total_ms"] for r in rows) or 1.0
+        rows1, raw1 = profile_pass(False)
+        total = sum(r["total_ms"] for r in rows1) or 1.0
+        one_stream_ms = total / args.steps
         kernels = [{"name": r["name"], "calls_per_step": r["calls"] / args.steps,
                     "ms_per_step": round(r["total_ms"] / args.steps, 4), "share": round(r["total_ms"] / total, 4),
                     "tflops": round(r["flops"] / (r["total_ms"] * 1e9), 1) if r["flops"] else None}
-                   for r in rows[:8]]
-        roofline = roofline_of(rows)
+                   for r in rows1[:8]]
+        roofline = roofline_of(rows1)
         if roofline:
-            roofline["mode"] = "two HIP streams (towers co-scheduled, as in the timed region)" if args.overlap else "one stream"
-            tr = load_pmc_traffic(roofline["kernel"])
-            if tr:
-                roofline["traffic"] = tr["bytes_per_launch"]
-                roofline["traffic_note"] = tr["note"]
-        if roofline and not args.overlap:
-            roles = by_role(raw, roofline["kernel"])
-        if args.overlap and roofline:
-            rows1, raw1 = profile_pass(False)
-            roofline_1s = roofline_of(rows1)
-            if roofline_1s:
-                roles = by_role(raw1, roofline_1s["kernel"])
-            if roofline_1s:
-                tr = load_pmc_traffic(roofline_1s["kernel"])
-                if tr:
-                    roofline_1s["traffic"] = tr["bytes_per_launch"]
-                    roofline_1s["traffic_note"] = tr["note"]
-            if roofline_1s:
-                roofline_1s["mode"] = "one stream: the kernel owns the GPU (kernel quality, not the timed configuration)"
+            roofline["mode"] = ("one HIP stream, HIP events on the launch stream: the kernel owns the GPU, as in the rocprofv3 "
+                                "kernel trace of the same command")
+            roles = by_role(raw1, roofline["kernel"])
+            if args.overlap:
+                rows2, _ = profile_pass(True)
+                roofline_2s = roofline_of(rows2, roofline["kernel"])
+                if roofline_2s:
+                    roofline_2s["mode"] = ("two HIP streams (the timed configuration): an event bracket includes queueing behind the "
+                                           "other tower's workgroups -- not a kernel-quality number")
+                    roofline_2s.pop("traffic", None)
+                    roofline_2s.pop("traffic_note", None)
 
     if rank != 0:
         if world > 1:
@@ -346,25 +366,32 @@ def main():
 
     pairs = B * world * args.steps
     value = pairs / elapsed
+    ex = executed_gflop_per_pair(cfg, args.dtype)
+    win = [elapsed / args.steps * 1e3] + [m / args.steps * 1e3 for m in more]
     res = {
         "metric": "image+text pairs embedded/sec at 224px bs=256",
         "value": round(value, 1), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": args.dtype if args.dtype != "f32" else "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"full dual encoder (image tower + text tower + L2 normalise + logits_per_image), "
                                f"{args.arch}, bs={B} pairs per GPU, {cfg.image_size}px, {cfg.context_length} tokens, "
                                f"{args.dtype} MFMA / fp32 accumulate (BASELINE.json configs[2])",
                    "arch": args.arch, "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
                    "collective": "none" if world == 1 else "RCCL all-gather of [B,512] fp32 image+text embeddings",
                    "streams": 2 if args.overlap else 1, "device": model.engine.device_name},
+        "windows": {"ms_per_step": [round(w, 3) for w in win], "median": round(float(np.median(win)), 3), "min": round(min(win), 3),
+                    "note": "three back-to-back windows of --steps steps each; `value` / `ms_per_step` are the FIRST (the contract's "
+                            "exactly-K-steps measurement), the others show the spread"},
         "algorithmic_tflops": round(value * cfg.pair_flops() / 1e12, 2),
-        "executed_gflop_per_pair": executed_gflop_per_pair(cfg, args),
+        "executed_tflops": round(value * ex["executed"] * 1e9 / 1e12, 2),
+        "executed_gflop_per_pair": ex,
         "roofline": roofline,
-        "roofline_single_stream": roofline_1s,
-        "roofline_by_role": {"note": "launches of the single-stream dominant kernel symbol split by what they compute, each priced "
-                                     "against the bound its arithmetic intensity puts it under (ridge 312 FLOP/B at 2.5 PF / 8 TB/s); "
-                                     "bytes are algorithmic (operands once, fp32 residual stream read + written as two 16-bit planes)",
+        "roofline_two_stream_events": roofline_2s,
+        "roofline_by_role": {"note": "launches of the dominant kernel symbol (one stream) split by what they compute, each priced against "
+                                     "the bound its arithmetic intensity puts it under (ridge 312 FLOP/B at 2.5 PF / 8 TB/s); bytes are "
+                                     "algorithmic (operands once, fp32 residual stream read + written as two 16-bit planes)",
                              "roles": roles} if roles else None,
+        "one_stream_sum_of_kernel_ms": round(one_stream_ms, 3) if one_stream_ms else None,
         "kernels": kernels,
     }
     try:
@@ -372,40 +399,50 @@ def main():
         res["csrc_sha16"] = source_digest()
     except Exception:  # pragma: no cover
         pass
-    if world == 1 and not args.no_fp32_tower and args.dtype != "f32" and res["executed_gflop_per_pair"]["pooled_last_block"]:
+    extras = world == 1 and not args.no_extras and args.dtype != "f32"
+    if world == 1 and not args.no_cpu_baseline:
+        try:
+            res["logits_max_abs_err"] = logits_error_vs_hf_golden(model, cfg, sd, px, ids, mask, B, args.arch)
+        except Exception as e:  # pragma: no cover
+            res["logits_max_abs_err"] = {"error": repr(e)}
+
+    def side_engine(dtype, **kw):
+        return PlipModel(cfg, sd, device=dev, dtype=dtype, max_batch=B, **kw)
+
+    if extras:
+        # the OTHER 16-bit engine on the same step: bf16 is the headline BASELINE.json names; f16 (IEEE half, the reference's
+        # own GPU dtype) has 8x smaller operand rounding at the same matrix-core rate
+        other = "f16" if args.dtype == "bf16" else "bf16"
+        try:
+            mo = side_engine(other)
+            dto, _ = timed_steps(lambda: sharded_pair_logits(mo, px, ids, mask, overlap=bool(args.overlap), equal_shards=True),
+                                 args.steps, dev, args.warmup)
+            res[other] = {"note": f"the same step on the {other} engine (compute_dtype PLIPMI_{other.upper()})",
+                          "pairs_per_s": round(B / dto, 1), "ms_per_step": round(dto * 1e3, 3),
+                          "logits_max_abs_err": logits_error_vs_hf_golden(mo, cfg, sd, px, ids, mask, B, args.arch)}
+            mo.engine.close()
+            del mo
+        except Exception as e:  # pragma: no cover
+            res[other] = {"error": repr(e)}
         # A/B: the same step with the last block computed on EVERY token (as HF does), i.e. the dense 14.777 GFLOP per pair
         try:
-            md = PlipModel(cfg, sd, device=dev, dtype=args.dtype, max_batch=B, pooled_last_block=False)
-            for _ in range(args.warmup):
-                sharded_pair_logits(md, px, ids, mask, overlap=bool(args.overlap), equal_shards=True)
-            torch.cuda.synchronize(dev)
-            t3 = time.perf_counter()
-            for _ in range(args.steps):
-                od = sharded_pair_logits(md, px, ids, mask, overlap=bool(args.overlap), equal_shards=True)
-            torch.cuda.synchronize(dev)
-            dtd = (time.perf_counter() - t3) / args.steps
+            md = side_engine(args.dtype, pooled_last_block=False)
+            dtd, od = timed_steps(lambda: sharded_pair_logits(md, px, ids, mask, overlap=bool(args.overlap), equal_shards=True),
+                                  args.steps, dev, args.warmup)
             res["dense_last_block"] = {
-                "note": "same step, an engine built with PLIPMI_FLAG_DENSE_LAST_BLOCK: the last block's out_proj / fc1 / fc2 on all tokens instead of the "
-                        "pooled row only (identical embeddings up to fp32 summation order)",
+                "note": "same step on an engine built with PLIPMI_FLAG_DENSE_LAST_BLOCK: the last block's out_proj / fc1 / fc2 on all "
+                        "tokens instead of the pooled row only (identical embeddings up to fp32 summation order)",
                 "pairs_per_s": round(B / dtd, 1), "ms_per_step": round(dtd * 1e3, 3),
                 "max_abs_diff_of_logits_vs_pooled_path": float((od[0] - logits).abs().max())}
             md.engine.close()
             del md
         except Exception as e:  # pragma: no cover
             res["dense_last_block"] = {"error": repr(e)}
-    if world == 1 and not args.no_fp32_tower and args.dtype != "f32" and res["executed_gflop_per_pair"]["pooled_last_block"]:
         # A/B, NOT the headline: the same step with the text tower on the captions' live rows only (plipmi_set_text_packing).
         # The headline above executes every padded position of the 77-token context, as the reference does.
         try:
             model.engine.set_text_packing(True)
-            for _ in range(args.warmup):
-                sharded_pair_logits(model, px, ids, mask, overlap=bool(args.overlap), equal_shards=True)
-            torch.cuda.synchronize(dev)
-            t4 = time.perf_counter()
-            for _ in range(args.steps):
-                op = sharded_pair_logits(model, px, ids, mask, overlap=bool(args.overlap), equal_shards=True)
-            torch.cuda.synchronize(dev)
-            dtp = (time.perf_counter() - t4) / args.steps
+            dtp, op = timed_steps(step, args.steps, dev, args.warmup)
             live = float(mask.sum(dim=1).float().mean().item())          # BOS .. EOS inclusive
             res["packed_captions"] = {
                 "note": "same step with plipmi_set_text_packing(1): rows behind each caption's EOS token are not computed (causal "
@@ -418,33 +455,54 @@ def main():
             res["packed_captions"] = {"error": repr(e)}
         finally:
             model.engine.set_text_packing(False)
-    if world == 1 and not args.no_fp32_tower and args.dtype != "f32":
+        # larger per-GPU batches of the same step (the engine's asymptote; inputs generated on the device)
+        try:
+            scal = {}
+            for Bb in (512, 1024):
+                mb = PlipModel(cfg, sd, device=dev, dtype=args.dtype, max_batch=Bb)
+                g = torch.Generator(device=dev).manual_seed(5)
+                pxb = torch.randn((Bb, 3, cfg.image_size, cfg.image_size), generator=g, device=dev)
+                ib, mbk = W.synthetic_ids(cfg, Bb, seed=2000)
+                ib, mbk = torch.from_numpy(ib).to(dev), torch.from_numpy(mbk).to(dev)
+                dtb, _ = timed_steps(lambda: sharded_pair_logits(mb, pxb, ib, mbk, overlap=bool(args.overlap), equal_shards=True),
+                                     max(4, args.steps // 2), dev, 2)
+                scal[f"bs{Bb}"] = {"pairs_per_s": round(Bb / dtb, 1), "ms_per_step": round(dtb * 1e3, 3)}
+                mb.engine.close()
+                del mb, pxb
+            res["batch_scaling"] = scal
+        except Exception as e:  # pragma: no cover
+            res["batch_scaling"] = {"error": repr(e)}
+        # one GPU's share of BASELINE.json configs[4] (ViT-L/14@336, bs=512 over 8 GPUs = 64 pairs per GPU), same dtype
+        try:
+            cl = get_config("ViT-L/14@336px")
+            ml = PlipModel(cl, W.synthetic_state_dict(cl, seed=3), device=dev, dtype=args.dtype, max_batch=64)
+            g = torch.Generator(device=dev).manual_seed(6)
+            pxl = torch.randn((64, 3, cl.image_size, cl.image_size), generator=g, device=dev)
+            il, mk = W.synthetic_ids(cl, 64, seed=42)
+            il, mk = torch.from_numpy(il).to(dev), torch.from_numpy(mk).to(dev)
+            dtl, _ = timed_steps(lambda: sharded_pair_logits(ml, pxl, il, mk, overlap=bool(args.overlap), equal_shards=True), 5, dev, 2)
+            res["vitl14_336_b64"] = {
+                "workload": "ViT-L/14@336 dual encoder, 64 pairs (one GPU's share of configs[4]'s bs=512 on 8 GPUs), same step; parity "
+                            "of this architecture: tests/test_gpu_configs.py against HF (tests/golden/vitl14_336_b2.npz)",
+                "pairs_per_s": round(64 / dtl, 1), "ms_per_step": round(dtl * 1e3, 3),
+                "algorithmic_tflops": round(64 * cl.pair_flops() / dtl / 1e12, 1),
+                "frac_of_mfma_peak": round(64 * cl.pair_flops() / dtl / 1e12 / PEAK_TFLOPS[args.dtype], 4)}
+            ml.engine.close()
+            del ml, pxl
+        except Exception as e:  # pragma: no cover
+            res["vitl14_336_b64"] = {"error": repr(e)}
         # BASELINE.json configs[1]: ViT-B/32 image tower only, bs=256, fp32 (exact-fp32 MFMA engine), same pixels
         try:
-            m32 = PlipModel(cfg, sd, device=dev, dtype="f32", max_batch=B)
-            for _ in range(2):
-                m32.engine.encode_image(px, True)
-            torch.cuda.synchronize(dev)
+            m32 = side_engine("f32")
             n32 = max(3, args.steps // 4)
-            t1 = time.perf_counter()
-            for _ in range(n32):
-                e32 = m32.engine.encode_image(px, True)
-            torch.cuda.synchronize(dev)
-            dt32 = (time.perf_counter() - t1) / n32
+            dt32, e32 = timed_steps(lambda: m32.engine.encode_image(px, True), n32, dev, 2)
             rows32 = []
             with m32.engine.profile(rows32):
                 m32.engine.encode_image(px, True)
             rows32.sort(key=lambda r: -r["total_ms"])
             dom32 = next((r for r in rows32 if r["flops"] > 0), None)
             # the fp32 PAIR rate (both towers + logits on the fp32 engine), same batch
-            for _ in range(1):
-                sharded_pair_logits(m32, px, ids, mask, overlap=bool(args.overlap), equal_shards=True)
-            torch.cuda.synchronize(dev)
-            t2 = time.perf_counter()
-            for _ in range(n32):
-                sharded_pair_logits(m32, px, ids, mask, overlap=bool(args.overlap), equal_shards=True)
-            torch.cuda.synchronize(dev)
-            dtp = (time.perf_counter() - t2) / n32
+            dtp, _ = timed_steps(lambda: sharded_pair_logits(m32, px, ids, mask, overlap=bool(args.overlap), equal_shards=True), n32, dev, 1)
             e16 = model.engine.encode_image(px, True)
             res["fp32_pairs"] = {"workload": "full dual encoder bs=256 on the exact-fp32 MFMA engine (v_mfma_f32_32x32x2_f32)",
                                  "pairs_per_s": round(B / dtp, 1), "ms_per_step": round(dtp * 1e3, 3),
@@ -458,20 +516,12 @@ def main():
                     "bound": "mfma", "kernel": dom32["name"], "peak": PEAK_TFLOPS["f32"], "unit": "TFLOP/s",
                     "achieved": round(dom32["flops"] / (dom32["total_ms"] * 1e9), 2),
                     "frac": round(dom32["flops"] / (dom32["total_ms"] * 1e9) / PEAK_TFLOPS["f32"], 4)},
-                "bf16_vs_fp32_embedding_max_abs_diff": float((e16 - e32).abs().max())}
+                f"{args.dtype}_vs_fp32_embedding_max_abs_diff": float((e16 - e32).abs().max())}
             m32.engine.close()
             del m32
         except Exception as e:  # pragma: no cover
             res["config1_fp32_image_tower"] = {"error": repr(e)}
-    if world == 1 and not args.no_cpu_baseline:
-        # parity on a small sample, then the timed CPU baseline (rank 0, N=1 only)
-        try:
-            res["logits_max_abs_err"] = logits_error_vs_hf_golden(model, cfg, sd, px, ids, mask, B, args)
-        except Exception as e:  # pragma: no cover
-            res["logits_max_abs_err"] = {"error": repr(e)}
-        res["cpu_baseline"] = cpu_baseline(cfg, sd, args.cpu_seconds)
-    else:
-        res["cpu_baseline"] = None
+    res["cpu_baseline"] = cpu_baseline(cfg, sd, args.cpu_seconds) if (world == 1 and not args.no_cpu_baseline) else None
     print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

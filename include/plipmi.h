@@ -248,11 +248,6 @@ int plipmi_gemm_variant_built(int dtype, int variant);
 void plipmi_set_gemm_variant(int variant);
 /* TEST / A-B HOOK, process-wide: epilogue stores of every GEMM write through the XCD's L2 (1) or not (0) */
 void plipmi_set_gemm_store_wt(int on);
-/* Tile policy of ONE handle's own choice (per-handle state, like everything else behind a handle):
- * 0 = wave-quantisation cost model (its kernels own the GPU one at a time; the default),
- * 1..3 = the caller runs the handle's two towers on two streams (idle CUs are filled by the other tower, so the tile
- *        is fixed per epilogue instead: 3 = 256x256 for q/k/v, 320x256 for fc1, 192x256 for the residual epilogues) */
-int plipmi_set_gemm_policy(plipmi_handle h, int policy);
 /* same call with explicit leading dimensions (in elements) for A [M,K] and W [N,K]: rows may be padded */
 int plipmi_gemm_nt_ld(int dtype, int epilogue, int variant, int M, int N, int K, const void* A, int lda, const void* W,
                       int ldw, const float* bias, float alpha, void* C, void* stream);

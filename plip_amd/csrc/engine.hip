@@ -107,7 +107,6 @@ struct plipmi_engine {
   // only -- causal attention and EOS pooling mean the rows behind EOS cannot reach the embedding.  Off by default: the
   // default engine executes every padded position, like the reference does.
   bool text_pack = false;
-  int gemm_policy = 0;  // tile policy of this handle's GEMMs (plipmi_set_gemm_policy)
   // small-batch hipGraph replay (plipmi_config.graph_batch, plipmi_set_graph_batch): batches of at most this many samples
   int graph_batch = 0;
   std::map<std::tuple<int, int, int, int, int>, GraphEntry> graphs;
@@ -301,7 +300,7 @@ int run_gemm(plipmi_engine* e, int epi, const void* A, const void* W, void* C, c
   Scope sc(e, s, name, 2.0 * M * N * (double)K, ((double)M * K + (double)N * K) * e->esz + out_bytes);
   const int rc = (skinny && e->half() && gemm_skinny_supports(epi, M, N, K))
                      ? gemm_launch_skinny(e->dtype, epi, p, s, &name)
-                     : gemm_launch(e->dtype, epi, -1, p, s, &name, e->gemm_policy);
+                     : gemm_launch(e->dtype, epi, -1, p, s, &name);
   if (e->prof) sc.rename(name_with_role(name, role));
   if (rc != 0) return fail(PLIPMI_ERR_HIP, "gemm launch (%s, M=%d N=%d K=%d) failed: %s", name, M, N, K,
                            hipGetErrorString((hipError_t)rc));
@@ -889,16 +888,6 @@ int plipmi_gemm_nt_ld(int dtype, int epilogue, int variant, int M, int N, int K,
 
 void plipmi_set_gemm_variant(int variant) { gemm_set_default_override(variant); }
 void plipmi_set_gemm_store_wt(int on) { gemm_set_store_wt(on); }
-int plipmi_set_gemm_policy(plipmi_handle h, int policy) {
-  if (!h) return fail(PLIPMI_ERR_INVALID, "null handle");
-  if (policy < 0 || policy > 5) return fail(PLIPMI_ERR_INVALID, "policy must be 0..5");
-  if (policy != h->gemm_policy) {   // captured forwards hold the other policy's tiles
-    for (auto& kv : h->graphs) if (kv.second.exec) hipGraphExecDestroy(kv.second.exec);
-    h->graphs.clear();
-  }
-  h->gemm_policy = policy;
-  return PLIPMI_OK;
-}
 int plipmi_check_async(plipmi_handle h) {
   if (!h) return fail(PLIPMI_ERR_INVALID, "null handle");
   return check_async(h);

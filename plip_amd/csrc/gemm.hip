@@ -9,11 +9,8 @@ namespace plipmi {
 int gemm_num_cus();
 
 static const GemmVariant kVariants[kNumVariants] = {
-    {"128x128_w2x2_glds64", 128, 128, 256},       {"128x128_w2x2_bufdma", 128, 128, 256},
-    {"256x256_w4x2_bufdma", 256, 256, 512},       {"320x256_w2x4_bufdma", 320, 256, 512},
-    {"192x256_w2x4_bufdma", 192, 256, 512},       {"160x256_w2x4_ring3", 160, 256, 512},
-    {"160x256_w2x4_ring3_stagger", 160, 256, 512}, {"160x256_w2x4_2stage", 160, 256, 512},
-    {"192x256_w2x4_fill2", 192, 256, 512},
+    {"128x128_w2x2_glds64", 128, 128, 256}, {"128x128_w2x2_bufdma", 128, 128, 256}, {"256x256_w4x2_bufdma", 256, 256, 512},
+    {"320x256_w2x4_bufdma", 320, 256, 512}, {"192x256_w2x4_bufdma", 192, 256, 512}, {"160x256_w2x4_bufdma", 160, 256, 512},
 };
 
 int gemm_num_cus() {
@@ -35,13 +32,13 @@ const GemmVariant& gemm_variant(int v) { return kVariants[v]; }
 // The product path never writes it; the tile POLICY is a per-call argument owned by the handle.
 static int g_override = -100;  // -100 = not yet read
 void gemm_set_default_override(int variant) { g_override = variant; }
-static int g_store_wt = -1;   // -1 = not yet read (PLIPMI_GEMM_STORE_WT)
+static int g_store_wt = -1;   // -1 = not yet read (PLIPMI_GEMM_STORE_WT; default on)
 void gemm_set_store_wt(int on) { g_store_wt = on ? 1 : 0; }
 bool gemm_variant_is_built(int dtype, int variant) {
   return dtype == 1 ? gemm_built_bf16(variant) : dtype == 2 ? gemm_built_f16(variant) : gemm_built_f32(variant);
 }
 
-int gemm_default_variant(int dtype, int M, int N, int K, int epi, int policy) {
+int gemm_default_variant(int dtype, int M, int N, int K) {
   if (g_override == -100) {
     const char* e = getenv("PLIPMI_GEMM_VARIANT");
     g_override = e ? atoi(e) : -1;
@@ -50,31 +47,21 @@ int gemm_default_variant(int dtype, int M, int N, int K, int epi, int policy) {
     if (g_override >= 0 && (N % kVariants[g_override].bn != 0 || !gemm_variant_is_built(dtype, g_override))) return 0;
     return g_override;
   }
-  // Tile choice = wave quantisation.  One 256-wide tile family runs one workgroup per CU (LDS-bound), so a GEMM
-  // takes ceil(tiles / CUs) rounds of roughly tile-area-proportional time; the 128x128 tile runs two workgroups per CU at
-  // ~1.2x the per-output cost, its last partial round cheaper.  Pick the candidate with the smallest rounds x tile-time.
+  // Tile choice = wave quantisation.  The 256-wide tiles run one workgroup per CU (LDS-bound), so a GEMM takes
+  // ceil(tiles / CUs) rounds of roughly tile-area-proportional time; `rel` is a tile's measured cost per output against
+  // 256x256 / 320x256 (K loop cycles per MFMA, prologue + epilogue share: profiles/r03_gemm_tiles.txt); the 128x128 tile runs
+  // two workgroups per CU, its last partial round cheaper.  Smallest rounds x tile-time wins.  At bs=256 that is 256x256 for
+  // q/k/v, 320x256 for fc1 and 160x256 (240 / 248 tiles = one round on 256 CUs) for out-proj / fc2 / the patch GEMM -- the
+  // measured best on all eight shapes, on one stream and on two.
   (void)K;
   if (M <= 1024) return 0;
-  const bool half = dtype != 0;
-  // Policy 1..3 = the two towers are co-scheduled on two streams: CUs a partial round would leave idle are taken by the
-  // other tower's kernels, so quantisation matters less and a fixed tile per epilogue wins (in-process A/B,
-  // profiles/r01_gemm_policy_ab.txt).  3 (the engine's choice): residual / patch epilogues on the 192x256 tile, whose
-  // register budget lets it request the residual rows one block ahead; q/k/v on 256x256; fc1 on 320x256.
-  if (policy == 1 && half && N % 256 == 0) return 3;
-  if (policy == 2 && half && N % 256 == 0) return (epi_is_resid(epi) || epi == EPI_PATCH) ? 4 : 3;
-  if (policy == 3 && half && N % 256 == 0)
-    return (epi_is_resid(epi) || epi == EPI_PATCH) ? 4 : ((epi == EPI_BIAS || epi == EPI_BIAS_LN) ? 2 : 3);
-  // Policy 4: as 3, residual / patch epilogues on the 160x256 ring-of-three tile.  Policy 5: every 256-wide GEMM on it.
-  if (policy == 4 && half && N % 256 == 0)
-    return (epi_is_resid(epi) || epi == EPI_PATCH) ? 5 : ((epi == EPI_BIAS || epi == EPI_BIAS_LN) ? 2 : 3);
-  if (policy == 5 && half && N % 256 == 0) return 5;
   const int cus = gemm_num_cus();
   struct Cand { int variant, bm, bn, per_cu; double rel; };
-  const Cand cands[] = {{2, 256, 256, 1, 1.00}, {3, 320, 256, 1, 1.00}, {4, 192, 256, 1, 1.05}, {1, 128, 128, 2, 1.21}};
+  const Cand cands[] = {{2, 256, 256, 1, 1.00}, {3, 320, 256, 1, 1.00}, {4, 192, 256, 1, 1.05}, {5, 160, 256, 1, 1.10},
+                        {1, 128, 128, 2, 1.21}};
   int best = 1;
   double best_cost = 1e300;
-  for (int i = 0; i < 4; ++i) {
-    const Cand& c = cands[i];
+  for (const Cand& c : cands) {
     if (N % c.bn) continue;
     const long tiles = (long)((M + c.bm - 1) / c.bm) * (N / c.bn);
     const long slots = (long)cus * c.per_cu;
@@ -90,9 +77,8 @@ int gemm_default_variant(int dtype, int M, int N, int K, int epi, int policy) {
 static const char* kEpiNames[EPI_COUNT] = {"bias", "bias_qgelu", "bias_resid", "scale", "patch", "ln_bias", "ln_qgelu",
                                            "resid_emit", "resid_split"};
 
-int gemm_launch(int dtype, int epi, int variant, const GemmParams& p, hipStream_t stream, const char** kernel_name,
-                int policy) {
-  if (variant == -1) variant = gemm_default_variant(dtype, p.M, p.N, p.K, epi, policy);
+int gemm_launch(int dtype, int epi, int variant, const GemmParams& p, hipStream_t stream, const char** kernel_name) {
+  if (variant == -1) variant = gemm_default_variant(dtype, p.M, p.N, p.K);
   // the buffer-addressed kernels (1..) carry 32-bit byte offsets: operands or outputs of 4 GiB and more take the
   // 64-bit-address tile (variant 0, global_load_lds with per-lane 64-bit addresses)
   if (variant >= 1) {
@@ -114,7 +100,7 @@ int gemm_launch(int dtype, int epi, int variant, const GemmParams& p, hipStream_
   GemmLaunchFn fn = dtype == 1 ? gemm_get_bf16(variant, epi) : dtype == 2 ? gemm_get_f16(variant, epi) : gemm_get_f32(variant, epi);
   if (!fn) return (int)hipErrorInvalidValue;
   GemmParams pr = p;
-  if (g_store_wt < 0) { const char* e = getenv("PLIPMI_GEMM_STORE_WT"); g_store_wt = e ? atoi(e) : 0; }
+  if (g_store_wt < 0) { const char* e = getenv("PLIPMI_GEMM_STORE_WT"); g_store_wt = e ? atoi(e) : 1; }
   pr.store_wt = g_store_wt;
   if (variant >= 0) {
     // column-group raster: minimise A*xn + W*(8/xn) fabric bytes subject to an XCD's W share fitting its L2

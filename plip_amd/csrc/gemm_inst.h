@@ -7,12 +7,12 @@ namespace plipmi {
 
 typedef int (*GemmLaunchFn)(const GemmParams&, hipStream_t);
 
-template <typename T, int BM, int BN, int WM, int WN, int EPI, int SCHED = 0, int NSTAGE = 2, int ADDR = 0>
+template <typename T, int BM, int BN, int WM, int WN, int EPI, int SCHED = 0, int ADDR = 0>
 int launch_tiled(const GemmParams& p, hipStream_t stream) {
   constexpr int NT = WM * WN * 64;
   // + rstd per tile row for the LayerNorm-folded epilogues
-  constexpr int LDS = NSTAGE * (BM + BN) * 128 + (epi_is_ln(EPI) ? BM * 4 : 0);
-  auto kern = gemm_nt_kernel<T, BM, BN, WM, WN, EPI, SCHED, NSTAGE, ADDR>;
+  constexpr int LDS = 2 * (BM + BN) * 128 + (epi_is_ln(EPI) ? BM * 4 : 0);
+  auto kern = gemm_nt_kernel<T, BM, BN, WM, WN, EPI, SCHED, ADDR>;
   static bool attr_set = false;  // one handle per process; set once per instantiation
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -33,24 +33,18 @@ int launch_naive(const GemmParams& p, hipStream_t stream) {
   return (int)hipGetLastError();
 }
 
-// The tile variants.  Every one is built for every dtype unless noted; numbers are what plipmi_gemm_nt(variant=...) and
-// PLIPMI_GEMM_VARIANT take, names come from gemm.hip.
+// The tile variants, each built for every dtype; numbers are what plipmi_gemm_nt(variant=...) and PLIPMI_GEMM_VARIANT
+// take, names come from gemm.hip.
 //   0  128x128, 2x2 waves, two workgroups per CU, 64-bit lane addresses (operands of 4 GiB and more; small problems)
 //   1  128x128, 2x2 waves, buffer-form LDS-DMA
-//   2  256x256, 4x2 waves, two LDS stages
-//   3  320x256, 2x4 waves, two LDS stages
-//   4  192x256, 2x4 waves, two LDS stages
-//   5  160x256, 2x4 waves (3 + 2 row blocks), ring of three LDS stages (two tiles of lookahead)
-//   6  160x256, as 5 with the fill of the second wave half one K step later       [16-bit types, experiment]
-//   7  160x256, two LDS stages                                                    [16-bit types, experiment]
-//   8  192x256, fill packed into 2 K steps                                        [16-bit types, experiment]
-constexpr int kNumVariants = 9;
+//   2  256x256, 4x2 waves
+//   3  320x256, 2x4 waves
+//   4  192x256, 2x4 waves
+//   5  160x256, 2x4 waves with 3 + 2 row blocks per wave row: 240 / 248 tiles on the bs=256 residual GEMMs (256 CUs)
+constexpr int kNumVariants = 6;
 
 template <typename T>
-constexpr bool gemm_variant_built(int v) {
-  if (v == -2 || (v >= 0 && v <= 5)) return true;
-  return sizeof(T) == 2 && v >= 6 && v < kNumVariants;
-}
+constexpr bool gemm_variant_built(int v) { return v == -2 || (v >= 0 && v < kNumVariants); }
 
 // table[variant][epilogue]
 template <typename T>
@@ -64,15 +58,12 @@ struct GemmTable {
       return nullptr;
     } else {
       switch (variant) {
-        case 0: return launch_tiled<T, 128, 128, 2, 2, EPI, 0, 2, 0>;
-        case 1: return launch_tiled<T, 128, 128, 2, 2, EPI, 1, 2, 1>;
-        case 2: return launch_tiled<T, 256, 256, 4, 2, EPI, kH ? 5 : 1, 2, 1>;
-        case 3: return launch_tiled<T, 320, 256, 2, 4, EPI, kH ? 6 : 0, 2, 1>;
-        case 4: return launch_tiled<T, 192, 256, 2, 4, EPI, kH ? 6 : 1, 2, 1>;
-        case 5: return launch_tiled<T, 160, 256, 2, 4, EPI, kH ? 6 : 1, 3, 1>;
-        case 6: if constexpr (kH) return launch_tiled<T, 160, 256, 2, 4, EPI, 7, 3, 1>; else return nullptr;
-        case 7: if constexpr (kH) return launch_tiled<T, 160, 256, 2, 4, EPI, 6, 2, 1>; else return nullptr;
-        case 8: if constexpr (kH) return launch_tiled<T, 192, 256, 2, 4, EPI, 5, 2, 1>; else return nullptr;
+        case 0: return launch_tiled<T, 128, 128, 2, 2, EPI, 0, 0>;
+        case 1: return launch_tiled<T, 128, 128, 2, 2, EPI, 1, 1>;
+        case 2: return launch_tiled<T, 256, 256, 4, 2, EPI, kH ? 5 : 1, 1>;
+        case 3: return launch_tiled<T, 320, 256, 2, 4, EPI, kH ? 6 : 0, 1>;
+        case 4: return launch_tiled<T, 192, 256, 2, 4, EPI, kH ? 6 : 1, 1>;
+        case 5: return launch_tiled<T, 160, 256, 2, 4, EPI, kH ? 6 : 1, 1>;
         case -2: if constexpr (!kLn) return launch_naive<T, EPI>; else return nullptr;
         default: return nullptr;
       }

@@ -181,18 +181,8 @@ class Engine:
         the towers are independent (separate workspaces), so the tail of one tower's GEMM grid -- 150..600
         workgroups over 256 CUs -- is filled by the other tower's kernels instead of idling."""
         if not overlap:
-            self._set_policy(getattr(self, "single_policy", 0))
-            try:
-                return self.encode_image(pixels, normalize), self.encode_text(input_ids, attention_mask, normalize)
-            finally:
-                self._set_policy(0)
-        # co-scheduled towers: tile choice per epilogue instead of by wave quantisation -- a field of THIS handle, set
-        # for the duration of the call (handles are not thread-safe, include/plipmi.h), never process-wide state
-        self._set_policy(getattr(self, "pair_policy", 3))
-        try:
-            return self._encode_pair_two_streams(pixels, input_ids, attention_mask, normalize)
-        finally:
-            self._set_policy(0)
+            return self.encode_image(pixels, normalize), self.encode_text(input_ids, attention_mask, normalize)
+        return self._encode_pair_two_streams(pixels, input_ids, attention_mask, normalize)
 
     def check_async(self, synchronize: bool = True) -> None:
         """Raise IndexError if an earlier ``encode_text`` was given a token id outside the vocabulary -- the reference's
@@ -210,9 +200,6 @@ class Engine:
         """Captions packed to their live rows (0 .. EOS): bit-identical text_embeds, cost proportional to the caption
         lengths instead of the padded 77 (include/plipmi.h plipmi_set_text_packing).  Off by default."""
         _lib.check(self.lib.plipmi_set_text_packing(self._h, int(bool(on))), "plipmi_set_text_packing")
-
-    def _set_policy(self, policy: int):
-        _lib.check(self.lib.plipmi_set_gemm_policy(self._h, int(policy)), "plipmi_set_gemm_policy")
 
     def _encode_pair_two_streams(self, pixels, input_ids, attention_mask, normalize):
         main = torch.cuda.current_stream(self.device)
@@ -430,6 +417,11 @@ def gemm_nt_ln(mode: int, a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, 
         return out, xb, st
 
 
+def _pow2(k: torch.Tensor) -> torch.Tensor:
+    """2^k as float64, built from the bit pattern (torch.pow / torch.ldexp are not exact on the GPU)"""
+    return ((k.to(torch.int64) + 1023) << 52).view(torch.float64)
+
+
 def split_planes(x: torch.Tensor, dtype=torch.bfloat16):
     """fp32 -> the engine's two-plane residual form (csrc/common.h split_f32<H>), on the host in torch integer / float64
     arithmetic; ``join_planes`` is the exact inverse.
@@ -447,7 +439,7 @@ def split_planes(x: torch.Tensor, dtype=torch.bfloat16):
     hi = xc.clamp(-65504.0, 65504.0).to(torch.float16)
     hf = hi.float()
     eb = ((hf.view(torch.int32) >> 23) & 0xFF).clamp(min=113)
-    lo = torch.ldexp(xc.double() - hf.double(), 151 - eb)           # exact scaling by a power of two
+    lo = (xc.double() - hf.double()) * _pow2(151 - eb)              # exact scaling by a power of two
     return hi, lo.clamp(-32768, 32767).trunc().to(torch.int16)
 
 
@@ -455,7 +447,7 @@ def join_planes(hi: torch.Tensor, lo: torch.Tensor) -> torch.Tensor:
     if hi.dtype == torch.float16:
         hf = hi.float()
         eb = ((hf.view(torch.int32) >> 23) & 0xFF).clamp(min=113)
-        return (hf.double() + torch.ldexp(lo.double(), eb - 151)).float()
+        return (hf.double() + lo.double() * _pow2(eb - 151)).float()
     h = hi.view(torch.int16).to(torch.int64) & 0xFFFF
     u = ((h << 16) + lo.to(torch.int64)) & 0xFFFFFFFF
     u = torch.where(u >= 2 ** 31, u - 2 ** 32, u)

@@ -25,10 +25,9 @@ def _ref(a, w, bias, epi, alpha, c0):
 
 
 # Tile variants (csrc/gemm_inst.h): 0 / 1 = 128x128 (64-bit addresses / buffer LDS-DMA), 2 = 256x256, 3 = 320x256,
-# 4 = 192x256, 5 = 160x256 on a ring of three LDS stages (uneven wave rows: 3 + 2 row blocks); 6..8 = schedule experiments
-# of the 16-bit types; -2 = the naive checker kernel.
+# 4 = 192x256, 5 = 160x256 (uneven wave rows: 3 + 2 row blocks); -2 = the naive checker kernel.
 HALF = {"bf16": torch.bfloat16, "f16": torch.float16}
-NVAR = 9
+NVAR = 6
 
 
 def _built(dtype):
@@ -39,8 +38,7 @@ def _built(dtype):
 def test_every_listed_variant_is_built():
     from plip_amd.engine import gemm_variants
     assert len(gemm_variants()) == NVAR
-    assert _built(torch.float32) == [0, 1, 2, 3, 4, 5, -2]
-    for dt in HALF.values():
+    for dt in (torch.float32, *HALF.values()):
         assert _built(dt) == list(range(NVAR)) + [-2]
 
 
@@ -56,8 +54,7 @@ def _half_tol(y, ref):
 @pytest.mark.parametrize("epi", [0, 1, 2, 3])
 def test_gemm_variants(dtype, variant, epi):
     from plip_amd.engine import gemm_nt, gemm_variant_built
-    if not gemm_variant_built(dtype, variant):
-        pytest.skip("schedule experiments exist for the 16-bit types only")
+    assert gemm_variant_built(dtype, variant)
     dev = torch.device("cuda:0")
     g = torch.Generator(device="cpu").manual_seed(1234 + 10 * epi + variant)
     for (M, N, K) in SHAPES:
@@ -96,7 +93,7 @@ def test_write_through_epilogue_stores_change_no_bit(variant):
             torch.cuda.synchronize()
             outs.append((y, hi, lo, st))
     finally:
-        lib.plipmi_set_gemm_store_wt(0)
+        lib.plipmi_set_gemm_store_wt(1)            # the library's default
     for u, v in zip(*outs):
         assert torch.equal(u, v)
 
@@ -161,7 +158,7 @@ def _slice_stats(x):
 
 
 @pytest.mark.parametrize("hdt", list(HALF.values()), ids=list(HALF))
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 8, -1, -3])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, -1, -3])
 @pytest.mark.parametrize("mode", [0, 1])
 def test_layernorm_folded_consumer_epilogue(variant, mode, hdt):
     """y = [quickgelu](Linear(LayerNorm(x))) computed as rstd * (bf16(x) @ W'^T) + c2 with W' = bf16(W * g, rows centred)
@@ -207,7 +204,7 @@ def test_layernorm_folded_consumer_epilogue(variant, mode, hdt):
 
 
 @pytest.mark.parametrize("hdt", list(HALF.values()), ids=list(HALF))
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 8, -1, -3])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, -1, -3])
 def test_layernorm_folded_producer_epilogue(variant, hdt):
     """x += A @ W^T + bias in place (fp32), plus the bf16 copy and the per-slice {sum, centred M2} of the updated rows,
     the latter against fp64 statistics of the kernel's OWN fp32 output (so the check is exact to fp32 round-off)."""
@@ -234,7 +231,7 @@ def test_layernorm_folded_producer_epilogue(variant, hdt):
 
 
 @pytest.mark.parametrize("hdt", list(HALF.values()), ids=list(HALF))
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 8, -1])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, -1])
 def test_split_plane_residual_epilogue(variant, hdt):
     """The engine's residual update: the fp32 stream lives as two 16-bit planes, hi = the value rounded to bf16 (the next
     GEMM's A operand), lo = the signed remainder of its bit pattern, hi + lo == the fp32 value EXACTLY.  The kernel must

@@ -409,35 +409,33 @@ def _step_inputs(B=256):
 
 
 def sec_policy():
-    """In-process interleaved A/B of the step under tile policies / forced tiles / write-through stores, one and two
-    streams, bf16 and f16.  arguments: list of 'dtype:policy:variant:wt' (variant -1 = the policy's own choice)."""
+    """In-process interleaved A/B of the step under forced tiles / write-through stores, one and two streams, per engine
+    dtype.  arguments: list of 'dtype:variant:wt' (variant -1 = the cost model's own choice)."""
     from plip_amd import _lib
     from plip_amd.dist import sharded_pair_logits
     lib = _lib.load()
     B = 256
     cfg, sd, px, ids, mask = _step_inputs(B)
-    arms = sys.argv[2:] or ["bf16:3:-1:0", "bf16:3:-1:1", "bf16:4:-1:0", "bf16:4:-1:1", "bf16:5:-1:0", "f16:3:-1:0", "f16:4:-1:0"]
+    arms = sys.argv[2:] or ["bf16:-1:1", "bf16:-1:0", "bf16:4:1", "f16:-1:1", "f16:-1:0"]
     models = {}
     res = {(a, ov): [] for a in arms for ov in (False, True)}
     for rep in range(4):
         for arm in arms:
-            dt, pol, var, wt = arm.split(":")
+            dt, var, wt = arm.split(":")
             if dt not in models:
                 models[dt] = PlipModel(cfg, sd, dtype=dt, max_batch=B)
             model = models[dt]
             lib.plipmi_set_gemm_variant(int(var))
             lib.plipmi_set_gemm_store_wt(int(wt))
-            model.engine.pair_policy = int(pol)
-            model.engine.single_policy = 0 if int(pol) == 3 else int(pol)
             for ov in (False, True):
                 ms = _time(lambda: sharded_pair_logits(model, px, ids, mask, overlap=ov), iters=10, warm=2)
                 if rep:                      # rep 0 = warm-up of clocks / caches
                     res[(arm, ov)].append(ms)
     lib.plipmi_set_gemm_variant(-1)
-    lib.plipmi_set_gemm_store_wt(0)
+    lib.plipmi_set_gemm_store_wt(1)
     for arm in arms:
         a, b = res[(arm, False)], res[(arm, True)]
-        print(f"dtype:policy:variant:write-through {arm:16s} one stream {np.median(a):6.3f} ms (min {min(a):6.3f})   "
+        print(f"dtype:variant:write-through {arm:12s} one stream {np.median(a):6.3f} ms (min {min(a):6.3f})   "
               f"two streams {np.median(b):6.3f} ms (min {min(b):6.3f})  -> {B / np.median(b) * 1e3:7.0f} pairs/s")
 
 
@@ -453,7 +451,7 @@ def sec_tiles():
     shapes = [("v.qkv", 12800, 2304, 768, 0), ("v.fc1", 12800, 3072, 768, 1), ("v.out", 12800, 768, 768, 3),
               ("v.fc2", 12800, 768, 3072, 3), ("t.qkv", 19712, 1536, 512, 0), ("t.fc1", 19712, 2048, 512, 1),
               ("t.out", 19712, 512, 512, 3), ("t.fc2", 19712, 512, 2048, 3)]
-    variants = [2, 3, 4, 5, 6, 7, 8]
+    variants = [2, 3, 4, 5]
     names = gemm_variants()
     print("variants:", {v: names[v] for v in variants}, "dtype", hdt)
     g = torch.Generator().manual_seed(0)
@@ -477,7 +475,7 @@ def sec_tiles():
                 for v in variants:
                     us = _time(lambda: run(v), iters=20, warm=3) * 1e3
                     best[(v, wt)] = min(best.get((v, wt), 1e9), us)
-        lib.plipmi_set_gemm_store_wt(0)
+        lib.plipmi_set_gemm_store_wt(1)
         lib_us = _time(lambda: F.linear(a, w, bias.to(hdt)), iters=20, warm=3) * 1e3
         row = "  ".join(f"v{v}: {best[(v, 0)]:6.1f}/{best[(v, 1)]:6.1f}" for v in variants)
         bv = min(best, key=best.get)

@@ -16,30 +16,18 @@ EPI = {"0": "bias", "1": "bias_qgelu", "2": "bias_resid", "3": "scale", "4": "pa
        "7": "resid_emit", "8": "resid_split"}
 
 
-def pretty(sym, variants):
-    m = re.search(r"gemm_nt_kernelI(DF16b|f)Li(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELb([01])(?:ELi(\d+))?(?:ELi(\d+))?(?:ELi(\d+))?(?:ELi(\d+))?", sym)
+def pretty(sym, variants=None):
+    """gemm_nt_kernel<T, BM, BN, WM, WN, EPI, SCHED, ADDR> (mangled) -> the engine's profile name gemm_nt<dtype,tile,epilogue>"""
+    m = re.search(r"gemm_nt_kernelI(DF16b|DF16_|Dh|f)Li(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E", sym)
     if not m:
         return sym
-    dt = "bf16" if m.group(1) == "DF16b" else "f32"
-    bm, bn, wm, wn, epi, glds = m.group(2), m.group(3), m.group(4), m.group(5), m.group(6), m.group(7)
-    sched, l2pf, nst = m.group(8) or "0", m.group(9) or "0", m.group(10) or "2"
-    addr = m.group(11) or "0"
-    key = (bm, bn, glds, sched, l2pf, nst)
-    tile = variants.get(key, f"{bm}x{bn}_w{wm}x{wn}_g{glds}s{sched}p{l2pf}n{nst}")
-    if addr == "1":
-        tile = tile.replace("_glds", "_bufdma")
+    dt = {"DF16b": "bf16", "DF16_": "f16", "Dh": "f16", "f": "f32"}[m.group(1)]
+    bm, bn, wm, wn, epi, addr = m.group(2), m.group(3), m.group(4), m.group(5), m.group(6), m.group(8)
+    tile = f"{bm}x{bn}_w{wm}x{wn}_" + ("bufdma" if addr == "1" else "glds64")
     return f"gemm_nt<{dt},{tile},{EPI.get(epi, epi)}>"
 
 
-VARIANTS = {("128", "128", "0", "0", "0", "2"): "128x128_w2x2_regstage", ("128", "128", "1", "0", "0", "2"): "128x128_w2x2_glds",
-            ("256", "256", "1", "0", "0", "2"): "256x256_w4x2_glds", ("256", "256", "1", "1", "0", "2"): "256x256_w4x2_glds_fragpipe",
-            ("128", "128", "1", "1", "0", "2"): "128x128_w2x2_glds_fragpipe", ("256", "128", "1", "1", "0", "2"): "256x128_w4x2_glds_fragpipe",
-            ("256", "256", "1", "3", "0", "2"): "256x256_w4x2_glds_spreadfill", ("128", "128", "1", "3", "0", "2"): "128x128_w2x2_glds_spreadfill",
-            ("192", "256", "1", "3", "0", "2"): "192x256_w2x4_glds_spreadfill", ("192", "256", "1", "1", "0", "2"): "192x256_w2x4_glds_fragpipe",
-            ("320", "256", "1", "3", "0", "2"): "320x256_w2x4_glds_spreadfill", ("320", "256", "1", "0", "0", "2"): "320x256_w2x4_glds",
-            ("256", "256", "1", "5", "0", "2"): "256x256_w4x2_glds_fill2", ("320", "256", "1", "5", "0", "2"): "320x256_w2x4_glds_fill2",
-            ("192", "256", "1", "5", "0", "2"): "192x256_w2x4_glds_fill2", ("256", "256", "1", "6", "0", "2"): "256x256_w4x2_glds_fill3",
-            ("320", "256", "1", "6", "0", "2"): "320x256_w2x4_glds_fill3", ("192", "256", "1", "6", "0", "2"): "192x256_w2x4_glds_fill3"}
+VARIANTS = None   # (the tile name follows from the template arguments since round 3)
 
 
 def main():

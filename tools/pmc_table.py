@@ -28,7 +28,7 @@ def short(sym):
         if key in sym:
             tail = sym.split(key, 1)[1]
             arg = tail[1:tail.index("E")] if tail.startswith("I") and "E" in tail else ""
-            arg = arg.replace("DF16b", "bf16,").replace("Li", "").replace("E", ",").strip(",")
+            arg = arg.replace("DF16b", "bf16,").replace("DF16_", "f16,").replace("Li", "").replace("E", ",").strip(",")
             return key.replace("_kernel", "") + (f"<{arg}>" if arg else "")
     return None
 
@@ -67,8 +67,11 @@ def main():
             print(f"   => wave time: WAIT_ANY {100 * c.get('SQ_WAIT_ANY', 0) / w:.0f} %, WAIT_INST_ANY {100 * c.get('SQ_WAIT_INST_ANY', 0) / w:.0f} %, "
                   f"ACTIVE {100 * c.get('SQ_ACTIVE_INST_ANY', 0) / w:.0f} %; LDS bank-conflict cycles {c.get('SQ_LDS_BANK_CONFLICT', 0):.0f}")
         if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "GRBM_GUI_ACTIVE" in c and c["GRBM_GUI_ACTIVE"] > 0:
+            # GRBM_GUI_ACTIVE spans more than the kernel's own timestamps (the round-2 table derived an "effective clock" of
+            # 2.4-2.7 GHz from it, above the chip's maximum): it is used as the matrix pipes' time base only; the shader
+            # clock under load comes from the in-kernel s_memtime / s_memrealtime stamps (profiles/r03_gemm_kloop.txt)
             clk = c["GRBM_GUI_ACTIVE"] / 8.0
-            print(f"   => effective clock {clk / t_ns:.2f} GHz; MFMA pipe busy {100 * c['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024 * clk):.1f} % of the matrix pipes' time")
+            print(f"   => MFMA pipe busy {100 * c['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024 * clk):.1f} % of the matrix pipes' time (GRBM_GUI_ACTIVE / 8 as the time base)")
         print()
 
 
