@@ -19,9 +19,10 @@
 //     16-byte slots of the 256-byte bank row: conflict-free fragment reads.
 //   * global -> LDS staging through LDS-DMA (`buffer_load_dwordx4 ... lds`, or `global_load_lds_dwordx4` for
 //     operands of 4 GiB and more): the LDS image is lane-linear, so the swizzle is applied to the per-lane SOURCE address.
-//   * two LDS stages (one tile of lookahead), one barrier per K tile.  (A ring of three stages -- two tiles of
-//     lookahead, counted vmcnt -- was built for the 160x256 tile and measured equal: the loop does not wait for fills,
-//     profiles/r03_gemm_kloop.txt.)
+//   * two LDS stages (one tile of lookahead) or, where three fit in the 160 KB (the 160x256 tile), a ring of three
+//     (two tiles of lookahead, counted vmcnt); one barrier per K tile either way.  With operands resident in the
+//     Infinity Cache the two are equal; with operands coming from HBM -- how the engine's kernels find the activations
+//     the previous kernel wrote -- the second tile of lookahead is what covers the longer fill (profiles/r03_gemm_cold.txt).
 //   * blockIdx -> tile map is XCD-aware: hardware round-robins blocks over the 8
 //     XCDs, so block b is given logical tile (b%8)*ceil(n/8)+b/8 (bijective form)
 //     and each XCD's private L2 sees a contiguous strip of M tiles sweeping N.
@@ -257,10 +258,12 @@ struct EpilogueOp {
 //       1: reads of K-step ks+1 pinned in front of the MFMAs of step ks (register double buffering), fill at the top;
 //       5 / 6: as 1, and the next fill's LDS-DMA requests are packed into the first 2 / 3 K steps of the iteration, one batch
 //          in front of each step's MFMA group, instead of queueing all of them on the texture-address unit at once.
-// Two LDS stages: the fill runs ONE K tile ahead, the end-of-iteration wait is vmcnt(0).
+// NSTAGE 2: the fill runs ONE K tile ahead, the end-of-iteration wait is vmcnt(0);
+//        3: three LDS stages, the fill runs TWO K tiles ahead and the wait is a counted vmcnt (in-order retirement: the
+//           older tile has landed, the newest may still fly).  Needs 3 * (BM + BN) * 128 B of the 160 KB.
 // ADDR 0: 64-bit per-lane global addresses (any operand size); 1: buffer resource + 32-bit lane offset (< 4 GiB).
 // waves per SIMD the kernel is built for: 2 (LDS caps residency there, so let the allocator use 256 VGPRs)
-template <typename T, int BM, int BN, int WM, int WN, int EPI, int SCHED = 0, int ADDR = 0>
+template <typename T, int BM, int BN, int WM, int WN, int EPI, int SCHED = 0, int ADDR = 0, int NSTAGE = 2>
 __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void gemm_nt_kernel(const GemmParams p) {
   constexpr int NT = WM * WN * 64;
@@ -273,7 +276,7 @@ void gemm_nt_kernel(const GemmParams p) {
   using OutT = std::conditional_t<sizeof(T) == 4, float, T>;
   static_assert(!(epi_is_ln(EPI) || epi_emits_stats(EPI)) || sizeof(T) == 2, "LayerNorm folding is a 16-bit-engine form");
   static_assert(SCHED == 0 || SCHED == 1 || SCHED == 5 || SCHED == 6, "schedules: 0, 1, 5 (fill2), 6 (fill3)");
-  constexpr int NSTAGE = 2;
+  static_assert(NSTAGE == 2 || NSTAGE == 3, "two LDS stages or a ring of three");
   constexpr bool kSpread = SCHED == 5 || SCHED == 6;
   static_assert(!kSpread || ADDR == 1, "the spread fill batches buffer-form requests");
   constexpr int BK = 8 * ELEMS16;          // 128-byte rows
@@ -282,7 +285,7 @@ void gemm_nt_kernel(const GemmParams p) {
   // 16-byte chunks per thread per tile.  A piece = one wave instruction = 8 rows; when BM * 8 is not a multiple of the
   // thread count the last A piece exists for the first waves only (wave-uniform test a_piece(i))
   constexpr int PA = (BM * 8 + NT - 1) / NT, PW = BN * 8 / NT;
-  constexpr int PA_MIN = BM * 8 / NT;      // pieces every wave issues
+  constexpr int PA_MIN = BM * 8 / NT;      // pieces every wave issues (counted vmcnt of the three-stage ring)
   static_assert(BM % 32 == 0 && TN % 32 == 0, "wave tile must be a multiple of the 32x32 MFMA tile");
   static_assert((BM * 8) % 64 == 0 && (BN * 8) % NT == 0, "staging passes must be whole wave pieces");
   static_assert((NT / 8) % 16 == 0, "swizzle term must not depend on the staging pass");
@@ -524,7 +527,7 @@ void gemm_nt_kernel(const GemmParams p) {
     }
   };
 
-  // ---- main loop: tile kt+1 streams in while tile kt is multiplied; one barrier per tile.
+  // ---- main loop: tiles kt+1 (and kt+2) stream in while tile kt is multiplied; one barrier per tile.
   const int KT = p.K / BK;
   unsigned long long* trace = p.trace ? p.trace + (size_t)bid * 8 : nullptr;
   unsigned long long trace_real0 = 0;
@@ -536,7 +539,36 @@ void gemm_nt_kernel(const GemmParams p) {
                ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20 /* XCC_ID [3:0] */) << 32);
     trace[6] = KT;
   }
-  {
+  if constexpr (NSTAGE == 3) {
+    // ring of three: at the top of iteration kt tile kt is visible, tile kt+1 is landing or landed, and the fill of tile
+    // kt+2 goes into the stage every wave left at the last barrier.  The wait at the end of the iteration leaves one
+    // tile's requests of this wave outstanding (vmcnt retires in order): tile kt+1 has landed, tile kt+2 may still fly.
+    constexpr int kLeave = PA_MIN + PW;
+    stage_issue(0);
+    if (KT > 1) stage_issue(1);
+    stage_ln_rows();
+    if (KT > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kLeave) : "memory");  // tile 0 landed, tile 1 may be in flight
+    else wait_vm0();
+    __syncthreads();
+    if (trace && tid == 0) trace[1] = __builtin_amdgcn_s_memtime();
+    int cur = 0, nxt2 = 2;  // stage of tile kt, stage of tile kt+2
+    for (int kt = 0; kt < KT - 1; ++kt) {
+      const bool fetch = kt + 2 < KT && !(p.ablate & 1);
+      if constexpr (!kSpread) { if (fetch) stage_issue(nxt2); }
+      if (!(p.ablate & 2)) compute(cur, fetch ? nxt2 : -1);
+      if (fetch) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kLeave) : "memory");
+      else wait_vm0();
+      if (!(p.ablate & 8)) __syncthreads();  // tile kt+1 visible to all waves; stage `cur` free for tile kt+3
+      cur = cur == 2 ? 0 : cur + 1;
+      nxt2 = nxt2 == 2 ? 0 : nxt2 + 1;
+    }
+    if constexpr (kRowOperand) {  // the residual / position rows of the first 32-row block travel during the last K tile
+      load_block(0, add[0]);
+      add_ready = true;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (!(p.ablate & 2)) compute(cur, -1);
+  } else {
     stage_issue(0);
     stage_ln_rows();
     wait_vm0();

@@ -1,4 +1,5 @@
 // gemm.hip -- variant registry and dispatch for the NT GEMM (kernels live in gemm.h).
+#include <stdio.h>
 #include <stdlib.h>
 
 #include <algorithm>
@@ -11,6 +12,7 @@ int gemm_num_cus();
 static const GemmVariant kVariants[kNumVariants] = {
     {"128x128_w2x2_glds64", 128, 128, 256}, {"128x128_w2x2_bufdma", 128, 128, 256}, {"256x256_w4x2_bufdma", 256, 256, 512},
     {"320x256_w2x4_bufdma", 320, 256, 512}, {"192x256_w2x4_bufdma", 192, 256, 512}, {"160x256_w2x4_bufdma", 160, 256, 512},
+    {"160x256_w2x4_ring3", 160, 256, 512},
 };
 
 int gemm_num_cus() {
@@ -51,14 +53,28 @@ int gemm_default_variant(int dtype, int M, int N, int K) {
   // ceil(tiles / CUs) rounds of roughly tile-area-proportional time; `rel` is a tile's measured cost per output against
   // 256x256 / 320x256 (K loop cycles per MFMA, prologue + epilogue share: profiles/r03_gemm_tiles.txt); the 128x128 tile runs
   // two workgroups per CU, its last partial round cheaper.  Smallest rounds x tile-time wins.  At bs=256 that is 256x256 for
-  // q/k/v, 320x256 for fc1 and 160x256 (240 / 248 tiles = one round on 256 CUs) for out-proj / fc2 / the patch GEMM -- the
-  // measured best on all eight shapes, on one stream and on two.
+  // q/k/v, 320x256 for fc1 and 160x256 on its three-stage ring (240 / 248 tiles = one round on 256 CUs) for out-proj / fc2 /
+  // the patch GEMM -- the measured best on all eight shapes, kernel by kernel and in the step, on one stream and on two
+  // (profiles/r03_gemm_tiles.txt).
   (void)K;
   if (M <= 1024) return 0;
   const int cus = gemm_num_cus();
   struct Cand { int variant, bm, bn, per_cu; double rel; };
-  const Cand cands[] = {{2, 256, 256, 1, 1.00}, {3, 320, 256, 1, 1.00}, {4, 192, 256, 1, 1.05}, {5, 160, 256, 1, 1.10},
-                        {1, 128, 128, 2, 1.21}};
+  // (6 = 160x256 on three LDS stages: as 5 with operands in the Infinity Cache, 6-9 % faster with operands from HBM)
+  static Cand cands[] = {{2, 256, 256, 1, 1.00}, {3, 320, 256, 1, 1.00}, {4, 192, 256, 1, 1.05}, {6, 160, 256, 1, 1.08},
+                         {5, 160, 256, 1, 1.10}, {1, 128, 128, 2, 1.21}};
+  static bool rel_read = false;
+  if (!rel_read) {   // A/B hook: PLIPMI_GEMM_REL="variant:rel,variant:rel" overrides the relative tile costs (not a product knob)
+    rel_read = true;
+    if (const char* e = getenv("PLIPMI_GEMM_REL")) {
+      int v; double r; int n = 0;
+      while (sscanf(e, "%d:%lf%n", &v, &r, &n) == 2) {
+        for (Cand& c : cands) if (c.variant == v) c.rel = r;
+        e += n;
+        if (*e == ',') ++e; else break;
+      }
+    }
+  }
   int best = 1;
   double best_cost = 1e300;
   for (const Cand& c : cands) {

@@ -7,12 +7,12 @@ namespace plipmi {
 
 typedef int (*GemmLaunchFn)(const GemmParams&, hipStream_t);
 
-template <typename T, int BM, int BN, int WM, int WN, int EPI, int SCHED = 0, int ADDR = 0>
+template <typename T, int BM, int BN, int WM, int WN, int EPI, int SCHED = 0, int ADDR = 0, int NSTAGE = 2>
 int launch_tiled(const GemmParams& p, hipStream_t stream) {
   constexpr int NT = WM * WN * 64;
   // + rstd per tile row for the LayerNorm-folded epilogues
-  constexpr int LDS = 2 * (BM + BN) * 128 + (epi_is_ln(EPI) ? BM * 4 : 0);
-  auto kern = gemm_nt_kernel<T, BM, BN, WM, WN, EPI, SCHED, ADDR>;
+  constexpr int LDS = NSTAGE * (BM + BN) * 128 + (epi_is_ln(EPI) ? BM * 4 : 0);
+  auto kern = gemm_nt_kernel<T, BM, BN, WM, WN, EPI, SCHED, ADDR, NSTAGE>;
   static bool attr_set = false;  // one handle per process; set once per instantiation
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -41,7 +41,8 @@ int launch_naive(const GemmParams& p, hipStream_t stream) {
 //   3  320x256, 2x4 waves
 //   4  192x256, 2x4 waves
 //   5  160x256, 2x4 waves with 3 + 2 row blocks per wave row: 240 / 248 tiles on the bs=256 residual GEMMs (256 CUs)
-constexpr int kNumVariants = 6;
+//   6  160x256 on a ring of three LDS stages (two K tiles of lookahead)
+constexpr int kNumVariants = 7;
 
 template <typename T>
 constexpr bool gemm_variant_built(int v) { return v == -2 || (v >= 0 && v < kNumVariants); }
@@ -64,6 +65,7 @@ struct GemmTable {
         case 3: return launch_tiled<T, 320, 256, 2, 4, EPI, kH ? 6 : 0, 1>;
         case 4: return launch_tiled<T, 192, 256, 2, 4, EPI, kH ? 6 : 1, 1>;
         case 5: return launch_tiled<T, 160, 256, 2, 4, EPI, kH ? 6 : 1, 1>;
+        case 6: return launch_tiled<T, 160, 256, 2, 4, EPI, kH ? 6 : 1, 1, 3>;
         case -2: if constexpr (!kLn) return launch_naive<T, EPI>; else return nullptr;
         default: return nullptr;
       }

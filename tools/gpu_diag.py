@@ -483,6 +483,79 @@ def sec_tiles():
               f"| best v{bv[0]} wt{bv[1]} {fl / best[bv]:7.1f} TF/s | vendor F.linear+bias {lib_us:6.1f} us {fl / lib_us:7.1f} TF/s")
 
 
+def sec_cold():
+    """The production GEMMs with operands that are NOT resident in the 256 MiB Infinity Cache: every launch takes its A
+    operand and its residual planes / output from the next of a ring of buffers (> 600 MB in total), as the engine's
+    kernels find them -- written by the previous kernel, read once.  Same launches with ONE buffer set (warm) beside it."""
+    from plip_amd.engine import gemm_nt_ln, split_planes
+    shapes = [("v.qkv", 12800, 2304, 768, 0), ("v.fc1", 12800, 3072, 768, 1), ("v.out", 12800, 768, 768, 3),
+              ("v.fc2", 12800, 768, 3072, 3), ("t.fc2", 19712, 512, 2048, 3)]
+    variants = [int(x) for x in sys.argv[2:]] or [2, 3, 4, 5]
+    g = torch.Generator().manual_seed(0)
+    for name, M, N, K, mode in shapes:
+        per = M * K * 2 + M * N * 4
+        nb = max(2, int(700e6 // per) + 1)
+        A = [torch.randn(M, K, generator=g).to(dev).bfloat16() for _ in range(nb)]
+        w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev).bfloat16()
+        bias = torch.randn(N, generator=g).to(dev)
+        if mode == 3:
+            planes = [split_planes(torch.randn(M, N, generator=g).to(dev)) for _ in range(nb)]
+            def run(v, i):
+                gemm_nt_ln(3, A[i], w, bias, variant=v, out=planes[i])
+        else:
+            outs = [torch.zeros(M, N, device=dev, dtype=torch.bfloat16) for _ in range(nb)]
+            xs = torch.randn(M, K, generator=g).to(dev).reshape(M, K // 64, 64)
+            st = torch.stack((xs.sum(-1), ((xs - xs.mean(-1, keepdim=True)) ** 2).sum(-1)), dim=-1).contiguous()
+            def run(v, i):
+                gemm_nt_ln(mode, A[i], w, bias, st, variant=v, out=outs[i])
+        row = []
+        for v in variants:
+            res = {}
+            for cold in (0, 1):
+                state = {"i": 0}
+                def once():
+                    run(v, state["i"] % nb if cold else 0)
+                    state["i"] += 1
+                res[cold] = min(_time(once, iters=3 * nb if cold else 30, warm=nb) for _ in range(2)) * 1e3
+            row.append(f"v{v}: warm {res[0]:6.1f} cold {res[1]:6.1f}")
+        print(f"{name:6s} {M}x{N}x{K} ({nb} buffer sets): " + "   ".join(row) + " us")
+        del A
+
+
+def sec_sustain():
+    """Burst vs sustained: the same GEMM timed over 20 launches after an idle gap, and over ~3000 back-to-back launches
+    (~0.2 s of continuous MFMA load) -- does the chip hold its burst clock?"""
+    from plip_amd.engine import gemm_nt_ln, split_planes
+    g = torch.Generator().manual_seed(0)
+    for name, M, N, K, mode, variants in (("v.fc2", 12800, 768, 3072, 3, (4, 5)), ("v.fc1", 12800, 3072, 768, 1, (3, 5))):
+        a = torch.randn(M, K, generator=g).to(dev).bfloat16()
+        w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev).bfloat16()
+        bias = torch.randn(N, generator=g).to(dev)
+        if mode == 3:
+            hi, lo = split_planes(torch.randn(M, N, generator=g).to(dev))
+            run = lambda v: gemm_nt_ln(3, a, w, bias, variant=v, out=(hi, lo))
+        else:
+            out = torch.zeros(M, N, device=dev, dtype=torch.bfloat16)
+            xs = torch.randn(M, K, generator=g).to(dev).reshape(M, K // 64, 64)
+            st = torch.stack((xs.sum(-1), ((xs - xs.mean(-1, keepdim=True)) ** 2).sum(-1)), dim=-1).contiguous()
+            run = lambda v: gemm_nt_ln(mode, a, w, bias, st, variant=v, out=out)
+        for v in variants:
+            torch.cuda.synchronize(); time.sleep(0.5)
+            burst = _time(lambda: run(v), iters=20, warm=3) * 1e3
+            torch.cuda.synchronize(); time.sleep(0.5)
+            rows = []
+            for chunk in range(6):                    # 6 x 500 launches, timed chunk by chunk without idling in between
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(500):
+                    run(v)
+                e1.record()
+                rows.append((e0, e1))
+            torch.cuda.synchronize()
+            sus = [e0.elapsed_time(e1) / 500 * 1e3 for e0, e1 in rows]
+            print(f"{name} variant {v}: burst of 20 launches {burst:6.1f} us; sustained chunks of 500 launches: " + " ".join(f"{x:6.1f}" for x in sus) + " us")
+
+
 def sec_parity():
     """Where the cosine error of the 16-bit engines comes from at the benchmark size: vitb32_b256 against its HF golden,
     per engine form (dtype x LayerNorm fold x pooled last block)."""
@@ -555,6 +628,6 @@ def sec_e2e():
 
 if __name__ == "__main__":
     t0 = time.time()
-    {"gemm": sec_gemm, "attn": sec_attn, "tiny": sec_tiny, "vitb32": sec_vitb32, "gemmbench": sec_gemmbench, "lnbench": sec_lnbench, "latency": sec_latency, "libgemm": sec_libgemm, "tiles": sec_tiles, "parity": sec_parity, "towerswap": sec_towerswap, "e2e": sec_e2e, "gemmone": sec_gemmone, "policy": sec_policy, "ldpad": sec_ldpad, "gemmtrace": sec_gemmtrace,
+    {"gemm": sec_gemm, "attn": sec_attn, "tiny": sec_tiny, "vitb32": sec_vitb32, "gemmbench": sec_gemmbench, "lnbench": sec_lnbench, "latency": sec_latency, "libgemm": sec_libgemm, "tiles": sec_tiles, "parity": sec_parity, "sustain": sec_sustain, "cold": sec_cold, "towerswap": sec_towerswap, "e2e": sec_e2e, "gemmone": sec_gemmone, "policy": sec_policy, "ldpad": sec_ldpad, "gemmtrace": sec_gemmtrace,
      "overlap": sec_overlap}[sys.argv[1]]()
     print(f"[{sys.argv[1]} done in {time.time() - t0:.1f} s]")

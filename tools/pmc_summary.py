@@ -17,13 +17,13 @@ EPI = {"0": "bias", "1": "bias_qgelu", "2": "bias_resid", "3": "scale", "4": "pa
 
 
 def pretty(sym, variants=None):
-    """gemm_nt_kernel<T, BM, BN, WM, WN, EPI, SCHED, ADDR> (mangled) -> the engine's profile name gemm_nt<dtype,tile,epilogue>"""
-    m = re.search(r"gemm_nt_kernelI(DF16b|DF16_|Dh|f)Li(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E", sym)
+    """gemm_nt_kernel<T, BM, BN, WM, WN, EPI, SCHED, ADDR, NSTAGE> (mangled) -> the engine's profile name gemm_nt<dtype,tile,epilogue>"""
+    m = re.search(r"gemm_nt_kernelI(DF16b|DF16_|Dh|f)Li(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E", sym)
     if not m:
         return sym
     dt = {"DF16b": "bf16", "DF16_": "f16", "Dh": "f16", "f": "f32"}[m.group(1)]
     bm, bn, wm, wn, epi, addr = m.group(2), m.group(3), m.group(4), m.group(5), m.group(6), m.group(8)
-    tile = f"{bm}x{bn}_w{wm}x{wn}_" + ("bufdma" if addr == "1" else "glds64")
+    tile = f"{bm}x{bn}_w{wm}x{wn}_" + ("ring3" if m.group(9) == "3" else "bufdma" if addr == "1" else "glds64")
     return f"gemm_nt<{dt},{tile},{EPI.get(epi, epi)}>"
 
 
