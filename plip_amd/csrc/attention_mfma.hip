@@ -41,17 +41,11 @@ __device__ __forceinline__ typename half_traits<H>::x8 vtr_fragment(const char* 
   return __builtin_bit_cast(typename half_traits<H>::x8, v);
 }
 
-// PAIRS (sample, head) problems per workgroup, one after the other, the K / V rows of problem p+1 requested (into
-// registers) right after problem p's rows have been handed to LDS.  MEASURED AND NOT SHIPPED (profiles/r02_attention.txt):
-// at bs=256 two problems per workgroup make the grid resident in one round, but the loop form costs registers (132 / 155
-// VGPRs vs 64 / 80: three waves per SIMD instead of six to eight) and the launch got slower, 18.4 -> 19.6 us (S = 50) and
-// 21.0 -> 29.2 us (S = 77): the many small independent workgroups already overlap each other's load -> compute -> store
-// chains better than a prefetching loop does.  The launcher instantiates PAIRS = 1; the template keeps the experiment.
-template <typename HT, int KT, int PAIRS>  // 32-key tiles: S <= 32*KT
-__global__ __launch_bounds__(64 * KT) void attention_mfma_kernel(const HT* __restrict__ qkv,
-                                                                 HT* __restrict__ out, int S, int H, int causal,
-                                                                 const int64_t* __restrict__ key_mask, int n_problems,
-                                                                 int pairs /* == PAIRS; a run-time value so the loop stays a loop */,
+// One (sample, head) problem per workgroup.  (Two problems per workgroup with a register prefetch of the next K / V rows
+// was measured slower in round 2 -- registers: three waves per SIMD instead of six to eight -- and is gone.)
+template <typename HT, int KT>  // 32-key tiles: S <= 32*KT
+__global__ __launch_bounds__(64 * KT) void attention_mfma_kernel(const HT* __restrict__ qkv, HT* __restrict__ out, int S, int H,
+                                                                 int causal, const int64_t* __restrict__ key_mask,
                                                                  const int* __restrict__ cu /* packed rows: sample b owns rows
                                                                  cu[b] .. cu[b+1]-1 of qkv / out (nullptr: b*S .. b*S+S-1) */) {
   using X8 = typename half_traits<HT>::x8;
@@ -75,35 +69,13 @@ __global__ __launch_bounds__(64 * KT) void attention_mfma_kernel(const HT* __res
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int q0 = wave * 32;
-  const int lrow = lane & 31, hi_c = lane >> 5;
-  const int qidx_c = q0 + lrow;
+  const int lrow = lane & 31, hi = lane >> 5;
+  const int qidx = q0 + lrow;
   const int lsw = (lrow >> 1) & 7;
+  const int bh = blockIdx.x;
 
   u32x4 kreg[NP], vreg[NP];
-  auto fetch = [&](int bh) {   // this thread's pieces of problem bh's K and V rows -> registers
-    const int b = bh / H, h = bh - b * H;
-    const int row0 = cu ? cu[b] : b * S, Sb = cu ? cu[b + 1] - row0 : S;
-    const HT* base = qkv + (size_t)row0 * ld + h * 64;
-#pragma unroll
-    for (int i = 0; i < NP; ++i) {
-      const int e = tid + i * NT, row = e >> 3, c = e & 7;
-      const HT* src = base + (size_t)(row < Sb ? row : Sb - 1) * ld + c * 8;
-      kreg[i] = *reinterpret_cast<const u32x4*>(src + D);
-      vreg[i] = *reinterpret_cast<const u32x4*>(src + 2 * D);
-    }
-  };
-  const int bh0 = blockIdx.x * PAIRS;
-  fetch(bh0);
-  const int npairs = PAIRS == 1 ? 1 : pairs;   // PAIRS == 1: a compile-time single trip, the loop folds away (64 / 80 VGPRs)
-#pragma unroll 1
-  for (int pp = 0; pp < npairs; ++pp) {
-    const int bh = bh0 + pp;
-    if (bh >= n_problems) break;                    // uniform
-    // Everything below that depends only on the lane (query index, key slots) is loop-invariant; hoisted out of the loop
-    // the 16 x KT mask predicates alone stay live as SGPR pairs / VGPRs across the whole body (187-241 VGPRs instead of
-    // 64-80: one wave per SIMD).  An empty asm makes the two lane values opaque per iteration, so they are recomputed.
-    int qidx = qidx_c, hi = hi_c;
-    asm volatile("" : "+v"(qidx), "+v"(hi));
+  {
     const int b = bh / H, h = bh - b * H;
     // packed captions: this problem's rows start at cu[b] and there are cu[b+1] - cu[b] of them (queries AND keys); the
     // tokenizer mask keeps its [B, S] layout.  Keys past the caption's last row are masked like sequence padding, so a
@@ -112,6 +84,13 @@ __global__ __launch_bounds__(64 * KT) void attention_mfma_kernel(const HT* __res
     const int Sb = __builtin_amdgcn_readfirstlane(cu ? cu[b + 1] - row0 : S);
     const bool active = q0 < Sb;
     const HT* base = qkv + (size_t)row0 * ld + h * 64;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {   // this thread's 16-byte pieces of the problem's K and V rows -> registers
+      const int e = tid + i * NT, row = e >> 3, c = e & 7;
+      const HT* src = base + (size_t)(row < Sb ? row : Sb - 1) * ld + c * 8;
+      kreg[i] = *reinterpret_cast<const u32x4*>(src + D);
+      vreg[i] = *reinterpret_cast<const u32x4*>(src + 2 * D);
+    }
     // key validity bits (sequence padding and the tokenizer's attention_mask): key = tid
     {
       const bool ok = tid < Sb && (key_mask == nullptr || key_mask[(size_t)b * S + tid] != 0);
@@ -134,7 +113,6 @@ __global__ __launch_bounds__(64 * KT) void attention_mfma_kernel(const HT* __res
       for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const u32x4*>(qrow + (ks * 2 + hi) * 8);
     }
     __syncthreads();
-    if (pp + 1 < npairs && bh + 1 < n_problems) fetch(bh + 1);   // in flight during this problem's arithmetic
 
     // scores^T tiles
     f32x16 sc[KT];
@@ -223,7 +201,6 @@ __global__ __launch_bounds__(64 * KT) void attention_mfma_kernel(const HT* __res
         if (r < Sb) *reinterpret_cast<u32x4*>(out + ((size_t)row0 + r) * D + h * 64 + c * 8) = v;
       }
     }
-    if (pp + 1 < npairs) __syncthreads();   // the next problem overwrites Ks / Vs / mk
   }
 }
 
@@ -408,11 +385,9 @@ static hipError_t launch_attention_mfma_t(const void* qkv, void* out, int B, int
     return hipGetLastError();
   }
   const int KT = (S + 31) / 32;
-  constexpr int kPairs = 1;                   // (sample, head) problems per workgroup, see the kernel's header
-  const dim3 grid((B * H + kPairs - 1) / kPairs), block(64 * KT);
+  const dim3 grid(B * H), block(64 * KT);
 #define PLIPMI_ATT(K) \
-  hipLaunchKernelGGL((attention_mfma_kernel<HT, K, kPairs>), grid, block, 0, s, (const HT*)qkv, (HT*)out, S, H, causal, \
-                     key_mask, B * H, kPairs, cu)
+  hipLaunchKernelGGL((attention_mfma_kernel<HT, K>), grid, block, 0, s, (const HT*)qkv, (HT*)out, S, H, causal, key_mask, cu)
   switch (KT) {
     case 1: PLIPMI_ATT(1); break;
     case 2: PLIPMI_ATT(2); break;

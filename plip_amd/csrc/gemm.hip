@@ -61,20 +61,8 @@ int gemm_default_variant(int dtype, int M, int N, int K) {
   const int cus = gemm_num_cus();
   struct Cand { int variant, bm, bn, per_cu; double rel; };
   // (6 = 160x256 on three LDS stages: as 5 with operands in the Infinity Cache, 6-9 % faster with operands from HBM)
-  static Cand cands[] = {{2, 256, 256, 1, 1.00}, {3, 320, 256, 1, 1.00}, {4, 192, 256, 1, 1.05}, {6, 160, 256, 1, 1.08},
-                         {5, 160, 256, 1, 1.10}, {1, 128, 128, 2, 1.21}};
-  static bool rel_read = false;
-  if (!rel_read) {   // A/B hook: PLIPMI_GEMM_REL="variant:rel,variant:rel" overrides the relative tile costs (not a product knob)
-    rel_read = true;
-    if (const char* e = getenv("PLIPMI_GEMM_REL")) {
-      int v; double r; int n = 0;
-      while (sscanf(e, "%d:%lf%n", &v, &r, &n) == 2) {
-        for (Cand& c : cands) if (c.variant == v) c.rel = r;
-        e += n;
-        if (*e == ',') ++e; else break;
-      }
-    }
-  }
+  const Cand cands[] = {{2, 256, 256, 1, 1.00}, {3, 320, 256, 1, 1.00}, {4, 192, 256, 1, 1.05}, {6, 160, 256, 1, 1.08},
+                        {5, 160, 256, 1, 1.10}, {1, 128, 128, 2, 1.21}};
   int best = 1;
   double best_cost = 1e300;
   for (const Cand& c : cands) {

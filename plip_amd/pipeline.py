@@ -58,9 +58,12 @@ def run_batches(items: Sequence, batch_size: int, prepare_item: Optional[Callabl
             staging = [None, None]
             copied = [torch.cuda.Event(), torch.cuda.Event()]
             consumed = [None, None]
+            pinned_src = [False, False]
         for k, (lo, hi) in enumerate(bounds):
             prepared = fut.result()
             host = arr(prepared)
+            if use_gpu and k >= 1 and pinned_src[(k - 1) & 1]:
+                copied[(k - 1) & 1].synchronize()       # batch k-1 has left its producer-owned pinned buffer: it may be refilled
             if k + 1 < len(bounds):
                 nlo, nhi = bounds[k + 1]
                 fut = ahead.submit(prep, items[nlo:nhi])
@@ -71,13 +74,17 @@ def run_batches(items: Sequence, batch_size: int, prepare_item: Optional[Callabl
             if consumed[slot] is not None:
                 consumed[slot].synchronize()            # the tower that read this slot's device copy has finished
             if torch.is_tensor(host) and host.is_pinned():
-                src = host                              # the producer already wrote into page-locked memory: no staging copy
+                # the producer already wrote into page-locked memory: no staging copy.  The producer may refill that very
+                # buffer while preparing batch k+2 (the usual double-buffer pattern), so the copy of batch k out of it must be
+                # complete before `prepare` runs again on this slot: waited for below, before the next submit
+                src = host
             else:
                 ht = host if torch.is_tensor(host) else torch.from_numpy(host)
                 if staging[slot] is None or staging[slot].shape != ht.shape or staging[slot].dtype != ht.dtype:
                     staging[slot] = torch.empty(ht.shape, dtype=ht.dtype).pin_memory()
                 staging[slot].copy_(ht)
                 src = staging[slot]
+            pinned_src[slot] = src is host
             main = torch.cuda.current_stream(device)
             with torch.cuda.stream(copy_stream):
                 dev = src.to(device, non_blocking=True)

@@ -203,8 +203,10 @@ class PLIP:
     def _nearest_neighbours(self, k, key_vectors, space_vectors, normalize=True, debug=False):
         eng = self.model.engine
         key_vectors, space_vectors = np.asarray(key_vectors), np.asarray(space_vectors)
-        # argsort()[:, -k:] hands back every column when k exceeds the corpus (plip.py:84): clamp instead of failing
-        k = max(0, min(int(k), space_vectors.shape[0]))
+        # argsort()[:, -k:] hands back every column when k exceeds the corpus -- and for k = 0, since [-0:] is [0:]
+        # (plip.py:84): the same here instead of failing
+        n_space = space_vectors.shape[0]
+        k = n_space if int(k) <= 0 else min(int(k), n_space)
         if k == 0 or key_vectors.shape[0] == 0:
             return np.zeros((key_vectors.shape[0], k), np.int64)
         kv = torch.as_tensor(np.ascontiguousarray(key_vectors, dtype=np.float32)).to(eng.device)

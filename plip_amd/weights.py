@@ -386,9 +386,12 @@ def load_checkpoint(path: str, arch: str | None = None, trust_pickle: bool = Fal
         from safetensors.numpy import load_file
         sd = load_file(path)
     else:
+        import pickle
         try:
             sd = torch.load(path, map_location="cpu", weights_only=True)
-        except Exception as e:
+        except (OSError, TypeError):
+            raise                                     # missing / unreadable file, or a torch without weights_only: not a pickle question
+        except (pickle.UnpicklingError, RuntimeError) as e:   # what weights_only=True raises on a code-carrying pickle
             if not (trust_pickle or os.environ.get("PLIPMI_TRUST_PICKLE") == "1"):
                 raise RuntimeError(
                     f"{path} is not a plain tensor state dict ({type(e).__name__}: {str(e)[:200]}). Loading it needs full "

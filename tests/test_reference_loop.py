@@ -106,6 +106,8 @@ def test_reference_host_loops_on_the_drop_in_model_cpu(tmp_path):
     np.testing.assert_array_equal(ours.retrieval(CAPTIONS, top_k=3), ref.retrieval(CAPTIONS, top_k=3))
     # k beyond the corpus: the reference's argsort()[:, -k:] hands back every column
     assert ours.retrieval(CAPTIONS, top_k=10).shape == ref.retrieval(CAPTIONS, top_k=10).shape == (4, 5)
+    # ... and for k = 0 too ([:, -0:] is [:, 0:]): ADVICE r2
+    np.testing.assert_array_equal(ours.retrieval(CAPTIONS, top_k=0), ref.retrieval(CAPTIONS, top_k=0))
 
     # --- the restatement the GPU box runs (no /root/reference there) IS the reference's loop: identical arrays -------------
     restated = Hh.ReferenceHostLoops(model, processor, "cpu")

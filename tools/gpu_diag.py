@@ -522,6 +522,26 @@ def sec_cold():
         del A
 
 
+def sec_power():
+    """Is the step limited by the chip's power budget?  The same step (same kernels, same launches, same bytes) on inputs
+    that make every sample identical -- all-zero pixels, one repeated caption: the operands of every GEMM then repeat row
+    after row and toggle far fewer bits -- against the random batch.  (MI355X_MICROARCH.md, DVFS: the 8-phase GEMM runs
+    15-21 % faster on zero-filled operands.)"""
+    from plip_amd.dist import sharded_pair_logits
+    B = 256
+    cfg, sd, px, ids, mask = _step_inputs(B)
+    model = PlipModel(cfg, sd, dtype="bf16", max_batch=B)
+    px0 = torch.zeros_like(px)
+    ids0 = ids[:1].repeat(B, 1).contiguous()
+    mask0 = mask[:1].repeat(B, 1).contiguous()
+    for rep in range(3):
+        for name, a, b, c in (("random batch", px, ids, mask), ("identical samples", px0, ids0, mask0)):
+            for ov in (True, False):
+                ms = _time(lambda: sharded_pair_logits(model, a, b, c, overlap=ov), iters=20, warm=3)
+                if rep:
+                    print(f"{name:18s} {'two streams' if ov else 'one stream '}: {ms:6.3f} ms/step")
+
+
 def sec_sustain():
     """Burst vs sustained: the same GEMM timed over 20 launches after an idle gap, and over ~3000 back-to-back launches
     (~0.2 s of continuous MFMA load) -- does the chip hold its burst clock?"""
@@ -628,6 +648,6 @@ def sec_e2e():
 
 if __name__ == "__main__":
     t0 = time.time()
-    {"gemm": sec_gemm, "attn": sec_attn, "tiny": sec_tiny, "vitb32": sec_vitb32, "gemmbench": sec_gemmbench, "lnbench": sec_lnbench, "latency": sec_latency, "libgemm": sec_libgemm, "tiles": sec_tiles, "parity": sec_parity, "sustain": sec_sustain, "cold": sec_cold, "towerswap": sec_towerswap, "e2e": sec_e2e, "gemmone": sec_gemmone, "policy": sec_policy, "ldpad": sec_ldpad, "gemmtrace": sec_gemmtrace,
+    {"gemm": sec_gemm, "attn": sec_attn, "tiny": sec_tiny, "vitb32": sec_vitb32, "gemmbench": sec_gemmbench, "lnbench": sec_lnbench, "latency": sec_latency, "libgemm": sec_libgemm, "tiles": sec_tiles, "parity": sec_parity, "sustain": sec_sustain, "power": sec_power, "cold": sec_cold, "towerswap": sec_towerswap, "e2e": sec_e2e, "gemmone": sec_gemmone, "policy": sec_policy, "ldpad": sec_ldpad, "gemmtrace": sec_gemmtrace,
      "overlap": sec_overlap}[sys.argv[1]]()
     print(f"[{sys.argv[1]} done in {time.time() - t0:.1f} s]")
