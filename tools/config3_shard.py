@@ -7,10 +7,12 @@ replicated.  Three numbers (the scaling risk of this confi
   resident   tiles already in HBM (a pool of distinct uint8 batches, cycled)           -> the GPU-side rate
   h2d        tiles start in pinned host memory and cross PCIe through the double-buffer pipeline (plip_amd/pipeline.py),
              copy stream overlapped with the towers                                    -> the H2D-inclusive rate
-  agreement  top-1 of the bf16 engine vs the reference arithmetic (HF CLIPModel on the host cores; numpy oracle when
-             transformers is missing) on a 512-image sample
+  agreement  scores, top-1 and class ordering of the engine vs HF CLIPModel on the 512-tile sample of
+             tests/golden/config3_zero_shot.npz (oracle/make_config3_fixture.py): structured synthetic tiles and ten class
+             prompts CHOSEN so that the classes are populated (nine of ten hold >= 4 % of the sample) -- on pure-noise tiles
+             and arbitrary prompts every image lands in one class and "top-1 agreement" says nothing
 
-    python tools/config3_shard.py [--images 125000] [--pool 8] > gpurun_out/config3_shard.json
+    python tools/config3_shard.py [--images 125000] [--pool 8] [--dtype bf16|f16] > gpurun_out/config3_shard.json
 """
 import argparse
 import json
@@ -27,7 +29,6 @@ from plip_amd import weights as W  # noqa: E402
 from plip_amd.config import get_config  # noqa: E402
 from plip_amd.model import PlipModel  # noqa: E402
 from plip_amd.pipeline import run_batches  # noqa: E402
-from plip_amd.preprocess import CLIP_MEAN, CLIP_STD  # noqa: E402
 
 
 def main():
@@ -36,18 +37,21 @@ def main():
     ap.add_argument("--classes", type=int, default=10)
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--pool", type=int, default=8, help="distinct synthetic batches (cycled)")
-    ap.add_argument("--sample", type=int, default=512)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16"])
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     cfg = get_config("ViT-B/32")
     sd = W.synthetic_state_dict(cfg, 0)
-    model = PlipModel(cfg, sd, device=dev, dtype="bf16", max_batch=args.batch)
+    model = PlipModel(cfg, sd, device=dev, dtype=args.dtype, max_batch=args.batch)
     eng = model.engine
-    prompts, pmask = W.synthetic_ids(cfg, args.classes, seed=7)          # stand-ins for "An H&E image patch of <class>."
+    gold = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "config3_zero_shot.npz"))
+    tile_seed, prompt_seed, weight_seed, n_sample, n_pool = (int(v) for v in gold["seeds"])
+    assert weight_seed == 0 and args.classes == gold["prompts"].shape[0]
+    prompts = gold["prompts"]                                            # stand-ins for "An H&E image patch of <class>."
     class_emb = eng.encode_text(torch.from_numpy(prompts), None, normalize=True)
     B, n_px = args.batch, cfg.image_size
-    g = torch.Generator().manual_seed(1000)                              # rank 0's seed
-    host_pool = [torch.randint(0, 256, (B, n_px, n_px, 3), dtype=torch.uint8, generator=g).pin_memory() for _ in range(args.pool)]
+    tiles = W.synthetic_tiles(cfg, args.pool * B, tile_seed)             # rank 0's seed; first 512 = the fixture's sample
+    host_pool = [torch.from_numpy(tiles[k * B:(k + 1) * B]).pin_memory() for k in range(args.pool)]
     dev_pool = [t.to(dev) for t in host_pool]
     nb = (args.images + B - 1) // B
     sizes = [min(B, args.images - k * B) for k in range(nb)]
@@ -78,40 +82,20 @@ def main():
     dt_h2d = time.perf_counter() - t0
     pred_h2d = torch.cat(outs).cpu().numpy()
     assert np.array_equal(pred_res, pred_h2d), "resident and H2D paths disagree"
-    # ---- agreement with the reference arithmetic on a sample ---------------------------------------------------------------
-    ns = min(args.sample, args.pool * B, args.images)
-    u8 = torch.cat(host_pool)[:ns].numpy()
-    px = ((u8.astype(np.float32) / np.float32(255.0) - np.asarray(CLIP_MEAN, np.float32)) / np.asarray(CLIP_STD, np.float32))
-    px = np.ascontiguousarray(px.transpose(0, 3, 1, 2))
-    t1 = time.perf_counter()
-    try:
-        from oracle import hf_reference as H
-        hf = H.build_model(cfg, sd, "sdpa")
-        with torch.no_grad():
-            fi = np.concatenate([H._tensor(hf.get_image_features(pixel_values=torch.from_numpy(px[s:s + 64]))).numpy()
-                                 for s in range(0, ns, 64)])
-            ft = H._tensor(hf.get_text_features(input_ids=torch.from_numpy(prompts))).numpy()
-        ref_kind = "HF transformers CLIPModel (CPU fp32)"
-    except Exception as e:  # pragma: no cover
-        from oracle import clip_oracle as O
-        ns = min(ns, 64)
-        fi, ft = O.vision_tower(px[:ns], sd, cfg), O.text_tower(prompts, sd, cfg, None)
-        ref_kind = f"numpy oracle ({type(e).__name__}: transformers unavailable)"
-    fi = fi / np.linalg.norm(fi, axis=1, keepdims=True)
-    ft = ft / np.linalg.norm(ft, axis=1, keepdims=True)
-    sim = fi @ ft.T
-    ref_pred = sim.argmax(1)
-    top2 = np.sort(sim, axis=1)[:, -2:]
-    clear = (top2[:, 1] - top2[:, 0]) > 2e-3                              # winner ahead by 2x the bf16 cosine tolerance
+    # ---- agreement with the reference's head on the fixture's sample (HF scores stored in the fixture) ---------------------------
+    ns = min(n_sample, args.pool * B, args.images)
+    sim = gold["scores"][:ns]
+    ref_pred = gold["argmax"][:ns]
+    tol = 1e-3 if args.dtype == "bf16" else 2.5e-4
+    gaps_all = np.diff(np.sort(sim, axis=1), axis=1)
+    clear = gaps_all[:, -1] > 2 * tol                                     # winner ahead by 2x the engine's cosine tolerance
     got = pred_res[:ns]
-    # random-init weights map every synthetic tile to nearly the same direction, so the arg-max is the same class for the
-    # whole corpus (see class_histogram): the informative comparison is the full [sample, classes] score matrix and the
-    # ordering of all classes per image, not top-1 alone
     sim_gpu = torch.cat([scores(dev_pool[k][:min(B, ns - k * B)]) for k in range((ns + B - 1) // B)]).cpu().numpy()
     order_ok = (np.argsort(-sim_gpu, axis=1, kind="stable") == np.argsort(-sim, axis=1, kind="stable")).all(axis=1)
-    gaps = np.diff(np.sort(sim, axis=1), axis=1).min(axis=1)
+    gaps = gaps_all.min(axis=1)
+    ref_kind = "HF transformers CLIPModel (CPU fp32), tests/golden/config3_zero_shot.npz"
     res = {
-        "config": "BASELINE.json configs[3], one rank's shard on one MI355X: ViT-B/32 bf16, uint8 224x224 tiles, "
+        "config": f"BASELINE.json configs[3], one rank's shard on one MI355X: ViT-B/32 {args.dtype}, structured synthetic uint8 224x224 tiles, "
                   f"{args.images} images = {nb} batches of {B}, {args.classes} class prompts replicated, arg-max head",
         "device": eng.device_name,
         "resident": {"images_per_s": round(args.images / dt_res, 1), "seconds": round(dt_res, 3),
@@ -125,9 +109,11 @@ def main():
                            "clear_rows": float((got[clear] == ref_pred[clear]).mean()) if clear.any() else None,
                            "n_clear_rows": int(clear.sum()), "scores_max_abs_err": float(np.abs(sim_gpu - sim).max()),
                            "full_class_ordering_agreement": float(order_ok.mean()),
-                           "full_class_ordering_agreement_where_gaps_exceed_2e-3": float(order_ok[gaps > 2e-3].mean()) if (gaps > 2e-3).any() else None,
-                           "vs": ref_kind, "reference_seconds": round(time.perf_counter() - t1, 1)},
-        "class_histogram": np.bincount(pred_res, minlength=args.classes).tolist(),
+                           "full_class_ordering_agreement_where_all_gaps_exceed_2tol": float(order_ok[gaps > 2 * tol].mean()) if (gaps > 2 * tol).any() else None,
+                           "rows_with_all_gaps_above_2tol": int((gaps > 2 * tol).sum()), "tolerance": tol, "vs": ref_kind},
+        "class_histogram_of_the_sample": {"engine": np.bincount(got, minlength=args.classes).tolist(),
+                                          "hf": np.bincount(ref_pred, minlength=args.classes).tolist()},
+        "class_histogram_of_the_shard": np.bincount(pred_res, minlength=args.classes).tolist(),
     }
     print(json.dumps(res, indent=1))
 

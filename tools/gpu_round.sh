@@ -12,23 +12,26 @@ for s in $SECTIONS; do
     pytest)  timeout 1200 python -m pytest tests -m gpu -q -x > gpurun_out/pytest_gpu.log 2>&1 ;;
     pytestall) timeout 1500 python -m pytest tests -m gpu -q > gpurun_out/pytest_gpu.log 2>&1 ;;
     bench)   timeout 600 python bench.py --steps 20 --warmup 3 > gpurun_out/bench.json 2> gpurun_out/bench.err ;;
-    rocprof) (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/gpurun_out/prof" -o plip -- python "$OLDPWD/bench.py" --steps 10 --warmup 2 --no-cpu-baseline --no-profile --no-fp32-tower > "$OLDPWD/gpurun_out/rocprof_bench.json" 2> "$OLDPWD/gpurun_out/rocprof.err")
-             (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/gpurun_out/prof1s" -o plip -- python "$OLDPWD/bench.py" --steps 10 --warmup 2 --no-cpu-baseline --no-profile --no-fp32-tower --overlap 0 > "$OLDPWD/gpurun_out/rocprof_bench_1stream.json" 2>> "$OLDPWD/gpurun_out/rocprof.err") ;;
+    rocprof) (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/gpurun_out/prof" -o plip -- python "$OLDPWD/bench.py" --steps 10 --warmup 2 --no-cpu-baseline --no-profile --no-extras > "$OLDPWD/gpurun_out/rocprof_bench.json" 2> "$OLDPWD/gpurun_out/rocprof.err")
+             (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/gpurun_out/prof1s" -o plip -- python "$OLDPWD/bench.py" --steps 10 --warmup 2 --no-cpu-baseline --no-profile --no-extras --overlap 0 > "$OLDPWD/gpurun_out/rocprof_bench_1stream.json" 2>> "$OLDPWD/gpurun_out/rocprof.err") ;;
     libprof) (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/gpurun_out/proflib" -o lib -- python "$OLDPWD/tools/gpu_diag.py" libgemm > "$OLDPWD/gpurun_out/libprof.log" 2>&1) ;;
-    bench1s) timeout 600 python bench.py --steps 20 --warmup 3 --overlap 0 --no-cpu-baseline > gpurun_out/bench_1stream.json 2>> gpurun_out/bench.err ;;
+    bench1s) timeout 600 python bench.py --steps 20 --warmup 3 --overlap 0 --no-cpu-baseline --no-extras > gpurun_out/bench_1stream.json 2>> gpurun_out/bench.err ;;
+    benchf16) timeout 600 python bench.py --steps 20 --warmup 3 --dtype f16 --no-cpu-baseline --no-extras > gpurun_out/bench_f16.json 2>> gpurun_out/bench.err ;;
+    config3f16) timeout 900 python tools/config3_shard.py --dtype f16 > gpurun_out/config3_shard_f16.json 2> gpurun_out/config3_shard_f16.err ;;
+    cold)    timeout 400 python tools/gpu_diag.py cold 2 3 4 5 6 > gpurun_out/diag_cold.log 2>&1 ;;
     pmc)     # hardware counters of the dominant GEMM (own passes, kernel-trace only -- see MI355X_MICROARCH rocprofv3 notes)
              for pass in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_VALU_MFMA_BUSY_CYCLES" \
                          "GRBM_GUI_ACTIVE FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SALU SQ_INSTS_VALU SQ_LDS_IDX_ACTIVE SQ_LDS_UNALIGNED_STALL SQ_WAVES"; do
                tag=$(echo $pass | cut -d' ' -f1)
-               (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d "$OLDPWD/gpurun_out/pmc_$tag" -o pmc -- python "$OLDPWD/tools/gpu_diag.py" gemmone ${PMC_ARGS:-5 12800 768 3072 2} >> "$OLDPWD/gpurun_out/pmc.log" 2>&1)
+               (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d "$OLDPWD/gpurun_out/pmc_$tag" -o pmc -- python "$OLDPWD/tools/gpu_diag.py" gemmone ${PMC_ARGS:-6 12800 768 3072 2} >> "$OLDPWD/gpurun_out/pmc.log" 2>&1)
              done ;;
-    trace)   echo "${TRACE_ARGS:-4 12800 768 3072 2;5 12800 768 3072 2;7 12800 768 3072 2;4 12800 768 768 2;5 12800 768 768 2;5 19712 512 2048 2;2 12800 2304 768 0;5 12800 2304 768 0;3 12800 3072 768 1;5 12800 3072 768 1}" | tr ';' '\n' | while read a; do
+    trace)   echo "${TRACE_ARGS:-6 12800 768 3072 2;5 12800 768 3072 2;4 12800 768 3072 2;6 12800 768 768 2;6 19712 512 2048 2;6 19712 512 512 2;2 12800 2304 768 0;3 12800 3072 768 1;2 19712 1536 512 0;3 19712 2048 512 1}" | tr ';' '\n' | while read a; do
                timeout 120 python tools/gpu_diag.py gemmtrace $a >> gpurun_out/diag_gemmtrace.log 2>&1; done ;;
-    ablate)  for ab in 0 1 2 3 4 6; do echo "=== PLIPMI_GEMM_ABLATE=$ab (1: no K-loop fills, 2: no MFMA, 4: no epilogue)" >> gpurun_out/diag_ablate.log
-               PLIPMI_GEMM_ABLATE=$ab timeout 120 python tools/gpu_diag.py gemmtrace ${ABLATE_ARGS:-5 12800 768 3072 2} 2>&1 | grep -E "variant|prologue|main loop|epilogue|lifetime" >> gpurun_out/diag_ablate.log; done ;;
+    ablate)  for ab in 0 1 8 16 9 17 24 25 4; do echo "=== PLIPMI_GEMM_ABLATE=$ab (1: no K-loop fills, 8: no K-loop barriers, 16: no LDS fragment reads, 4: no epilogue)" >> gpurun_out/diag_ablate.log
+               PLIPMI_GEMM_ABLATE=$ab timeout 120 python tools/gpu_diag.py gemmtrace ${ABLATE_ARGS:-6 12800 768 3072 2} 2>&1 | grep -E "variant|prologue|main loop|epilogue|lifetime" >> gpurun_out/diag_ablate.log; done ;;
     pmcbench) rm -rf gpurun_out/pmc_bench_*
              for ov in 0 1; do for pass in "FETCH_SIZE" "WRITE_SIZE"; do
-               (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d "$OLDPWD/gpurun_out/pmc_bench_${pass}_ov$ov" -o pmc -- python "$OLDPWD/bench.py" --steps 3 --warmup 1 --overlap $ov --no-cpu-baseline --no-profile --no-fp32-tower >> "$OLDPWD/gpurun_out/pmcbench.log" 2>&1)
+               (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d "$OLDPWD/gpurun_out/pmc_bench_${pass}_ov$ov" -o pmc -- python "$OLDPWD/bench.py" --steps 3 --warmup 1 --overlap $ov --no-cpu-baseline --no-profile --no-extras >> "$OLDPWD/gpurun_out/pmcbench.log" 2>&1)
              done; done
              python tools/pmc_summary.py gpurun_out/pmc_bench_FETCH_SIZE_ov0 gpurun_out/pmc_bench_WRITE_SIZE_ov0 gpurun_out/pmc_bench_FETCH_SIZE_ov1 gpurun_out/pmc_bench_WRITE_SIZE_ov1 > gpurun_out/pmc_traffic.json 2>> gpurun_out/pmcbench.log ;;
     torchrun1) timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline --no-fp32-tower > gpurun_out/bench_torchrun1.json 2> gpurun_out/bench_torchrun1.err ;;
@@ -38,10 +41,10 @@ for s in $SECTIONS; do
              for pass in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAVES" \
                          "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_LDS SQ_INSTS_VALU SQ_LDS_IDX_ACTIVE"; do
                i=$((i+1))
-               (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d "$OLDPWD/gpurun_out/pmcstep_$i" -o pmc -- python "$OLDPWD/bench.py" --steps 3 --warmup 1 --overlap 0 --no-cpu-baseline --no-profile --no-fp32-tower >> "$OLDPWD/gpurun_out/pmcstep.log" 2>&1)
+               (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d "$OLDPWD/gpurun_out/pmcstep_$i" -o pmc -- python "$OLDPWD/bench.py" --steps 3 --warmup 1 --overlap 0 --no-cpu-baseline --no-profile --no-extras >> "$OLDPWD/gpurun_out/pmcstep.log" 2>&1)
              done
              for ov in 0 1; do for pass in "FETCH_SIZE" "WRITE_SIZE"; do
-               (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d "$OLDPWD/gpurun_out/pmc_bench_${pass}_ov$ov" -o pmc -- python "$OLDPWD/bench.py" --steps 3 --warmup 1 --overlap $ov --no-cpu-baseline --no-profile --no-fp32-tower >> "$OLDPWD/gpurun_out/pmcstep.log" 2>&1)
+               (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d "$OLDPWD/gpurun_out/pmc_bench_${pass}_ov$ov" -o pmc -- python "$OLDPWD/bench.py" --steps 3 --warmup 1 --overlap $ov --no-cpu-baseline --no-profile --no-extras >> "$OLDPWD/gpurun_out/pmcstep.log" 2>&1)
              done; done
              python tools/pmc_table.py gpurun_out/pmcstep_1 gpurun_out/pmcstep_2 gpurun_out/pmc_bench_FETCH_SIZE_ov0 gpurun_out/pmc_bench_WRITE_SIZE_ov0 > gpurun_out/pmc_step_counters.txt 2>> gpurun_out/pmcstep.log
              python tools/pmc_summary.py gpurun_out/pmc_bench_FETCH_SIZE_ov0 gpurun_out/pmc_bench_WRITE_SIZE_ov0 gpurun_out/pmc_bench_FETCH_SIZE_ov1 gpurun_out/pmc_bench_WRITE_SIZE_ov1 > gpurun_out/pmc_traffic.json 2>> gpurun_out/pmcstep.log ;;
