@@ -424,6 +424,21 @@ def main():
             del mo
         except Exception as e:  # pragma: no cover
             res[other] = {"error": repr(e)}
+        # the bf16 engine with its text tower on IEEE-half operands (PLIPMI_FLAG_TEXT_TOWER_F16): the text side carries most of
+        # the bf16 engine's cosine error and 40 % of its time
+        if args.dtype == "bf16":
+            try:
+                mm = side_engine("bf16", text_f16=True)
+                dtm, _ = timed_steps(lambda: sharded_pair_logits(mm, px, ids, mask, overlap=bool(args.overlap), equal_shards=True),
+                                     args.steps, dev, args.warmup)
+                res["bf16_image_f16_text"] = {
+                    "note": "the same step on a bf16 engine created with PLIPMI_FLAG_TEXT_TOWER_F16 (image tower bf16, text tower f16)",
+                    "pairs_per_s": round(B / dtm, 1), "ms_per_step": round(dtm * 1e3, 3),
+                    "logits_max_abs_err": logits_error_vs_hf_golden(mm, cfg, sd, px, ids, mask, B, args.arch)}
+                mm.engine.close()
+                del mm
+            except Exception as e:  # pragma: no cover
+                res["bf16_image_f16_text"] = {"error": repr(e)}
         # A/B: the same step with the last block computed on EVERY token (as HF does), i.e. the dense 14.777 GFLOP per pair
         try:
             md = side_engine(args.dtype, pooled_last_block=False)

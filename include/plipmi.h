@@ -62,7 +62,13 @@ enum {
   PLIPMI_FLAG_DENSE_LAST_BLOCK = 2,    /* compute the last block's out_proj / fc1 / fc2 on every token, as the reference
                                         * does, instead of on the pooled row of each sample only */
   PLIPMI_FLAG_PACK_CAPTIONS = 4,       /* start with caption packing on (plipmi_set_text_packing) */
-  PLIPMI_FLAG_VALU_ATTENTION = 8       /* exact-fp32 VALU attention kernel instead of the MFMA kernels (A/B measurements) */
+  PLIPMI_FLAG_VALU_ATTENTION = 8,      /* exact-fp32 VALU attention kernel instead of the MFMA kernels (A/B measurements) */
+  PLIPMI_FLAG_TEXT_TOWER_F16 = 16      /* bf16 engine only: the TEXT tower's operands (weights, activations, its plane of
+                                        * the residual stream) are IEEE half instead of bf16.  The text side carries
+                                        * 3.2x the image side's embedding error in bf16 (operand rounding of the weights,
+                                        * coherent over a caption's tokens) and 40 % of the step's time:
+                                        * half precision there buys most of the f16 engine's accuracy for a third of
+                                        * its cost.  The image tower stays bf16. */
 };
 
 /* towers, for plipmi_debug_hidden */

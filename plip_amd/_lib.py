@@ -10,7 +10,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libplipmi.so")
 
 F32, BF16, F16 = 0, 1, 2
 # plipmi_config.flags
-FLAG_SEPARATE_LAYERNORM, FLAG_DENSE_LAST_BLOCK, FLAG_PACK_CAPTIONS, FLAG_VALU_ATTENTION = 1, 2, 4, 8
+FLAG_SEPARATE_LAYERNORM, FLAG_DENSE_LAST_BLOCK, FLAG_PACK_CAPTIONS, FLAG_VALU_ATTENTION, FLAG_TEXT_TOWER_F16 = 1, 2, 4, 8, 16
 VISION, TEXT = 0, 1
 
 

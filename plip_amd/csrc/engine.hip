@@ -55,6 +55,7 @@ struct LayerW {
 };
 struct Tower {
   int D = 0, F = 0, L = 0, H = 0, S = 0;
+  int dtype = 0;   // operand type of this tower's GEMMs / attention (the engine's, or f16 for the text tower under PLIPMI_FLAG_TEXT_TOWER_F16)
   std::vector<LayerW> layers;
   // workspace
   float* x = nullptr;
@@ -235,7 +236,7 @@ void carve(plipmi_engine* e, Carver& c) {
 }
 
 int pack_tower(plipmi_engine* e, Tower& t, const plipmi_layer_weights* src, hipStream_t s) {
-  const int D = t.D, F = t.F, dt = e->dtype;
+  const int D = t.D, F = t.F, dt = t.dtype;
   const float qscale = 0.125f;  // head_dim 64 -> 64^-0.5, a power of two: folding it into Wq/bq is exact
   for (int l = 0; l < t.L; ++l) {
     const plipmi_layer_weights& w = src[l];
@@ -281,7 +282,7 @@ const char* name_with_role(const char* name, const char* role) {
   return v.c_str();
 }
 
-int run_gemm(plipmi_engine* e, int epi, const void* A, const void* W, void* C, const float* bias, int M, int N, int K,
+int run_gemm(plipmi_engine* e, const Tower& t, int epi, const void* A, const void* W, void* C, const float* bias, int M, int N, int K,
              int ldc, int np, hipStream_t s, const char* role, const LnArgs* ln = nullptr, const int* m_dev = nullptr) {
   GemmParams p;
   p.A = A; p.W = W; p.C = C; p.bias = bias; p.m_dev = m_dev;
@@ -299,8 +300,8 @@ int run_gemm(plipmi_engine* e, int epi, const void* A, const void* W, void* C, c
                            : (double)M * N * (epi_is_resid(epi) ? 8.0 : 4.0) + (epi == EPI_RESID_EMIT ? (double)M * N * 2.0 : 0.0);
   Scope sc(e, s, name, 2.0 * M * N * (double)K, ((double)M * K + (double)N * K) * e->esz + out_bytes);
   const int rc = (skinny && e->half() && gemm_skinny_supports(epi, M, N, K))
-                     ? gemm_launch_skinny(e->dtype, epi, p, s, &name)
-                     : gemm_launch(e->dtype, epi, -1, p, s, &name);
+                     ? gemm_launch_skinny(t.dtype, epi, p, s, &name)
+                     : gemm_launch(t.dtype, epi, -1, p, s, &name);
   if (e->prof) sc.rename(name_with_role(name, role));
   if (rc != 0) return fail(PLIPMI_ERR_HIP, "gemm launch (%s, M=%d N=%d K=%d) failed: %s", name, M, N, K,
                            hipGetErrorString((hipError_t)rc));
@@ -319,7 +320,7 @@ int run_layers(plipmi_engine* e, Tower& t, int B, int n_layers, int causal, cons
   const int* md = t.packed ? t.mdev : nullptr;
   auto attention = [&]() -> int {
     Scope sc(e, s, impl ? "attention_mfma" : "attention_valu", 4.0 * B * t.H * (double)t.S * t.S * 64, (double)M * 4 * D * e->esz);
-    HIP_TRY(launch_attention(t.qkv, t.att, e->dtype, B, t.S, t.H, causal, key_mask, impl, s, cu));
+    HIP_TRY(launch_attention(t.qkv, t.att, t.dtype, B, t.S, t.H, causal, key_mask, impl, s, cu));
     return PLIPMI_OK;
   };
   if (e->ln_fold) {
@@ -332,30 +333,30 @@ int run_layers(plipmi_engine* e, Tower& t, int B, int n_layers, int causal, cons
     LnArgs emit; emit.xb_out = t.h; emit.st_out = t.st; emit.lo_io = t.lo;
     for (int l = 0; l < n_layers; ++l) {
       const LayerW& w = t.layers[l];
-      RUN(run_gemm(e, EPI_BIAS_LN, t.h, w.wqkv, t.qkv, w.bqkv, M, 3 * D, D, 3 * D, 0, s, "qkv", &use, md));
+      RUN(run_gemm(e, t, EPI_BIAS_LN, t.h, w.wqkv, t.qkv, w.bqkv, M, 3 * D, D, 3 * D, 0, s, "qkv", &use, md));
       RUN(attention());
-      RUN(run_gemm(e, EPI_RESID_SPLIT, t.att, w.wo, nullptr, w.bo, M, D, D, D, 0, s, "out_proj", &emit, md));
-      RUN(run_gemm(e, EPI_QGELU_LN, t.h, w.w1, t.mlp, w.b1, M, F, D, F, 0, s, "fc1", &use, md));
-      RUN(run_gemm(e, EPI_RESID_SPLIT, t.mlp, w.w2, nullptr, w.b2, M, D, F, D, 0, s, "fc2", &emit, md));
+      RUN(run_gemm(e, t, EPI_RESID_SPLIT, t.att, w.wo, nullptr, w.bo, M, D, D, D, 0, s, "out_proj", &emit, md));
+      RUN(run_gemm(e, t, EPI_QGELU_LN, t.h, w.w1, t.mlp, w.b1, M, F, D, F, 0, s, "fc1", &use, md));
+      RUN(run_gemm(e, t, EPI_RESID_SPLIT, t.mlp, w.w2, nullptr, w.b2, M, D, F, D, 0, s, "fc2", &emit, md));
     }
     if (!more_follow) {
       if (t.packed) return fail(PLIPMI_ERR_INVALID, "packed rows have no every-token form");   // a consumer of plain fp32 rows follows (the every-token head, plipmi_debug_hidden)
       Scope sc(e, s, "join_planes", 0, (double)M * D * 8);
-      HIP_TRY(launch_join_planes(t.h, t.lo, t.x, (size_t)M * D, e->dtype, s));
+      HIP_TRY(launch_join_planes(t.h, t.lo, t.x, (size_t)M * D, t.dtype, s));
     }
     return PLIPMI_OK;
   }
   for (int l = 0; l < n_layers; ++l) {
     const LayerW& w = t.layers[l];
     { Scope sc(e, s, "layernorm", 0, (double)M * D * (4 + e->esz));
-      HIP_TRY(launch_layernorm(t.x, D, w.ln1w, w.ln1b, t.h, e->dtype, M, D, eps, s)); }
-    RUN(run_gemm(e, EPI_BIAS, t.h, w.wqkv, t.qkv, w.bqkv, M, 3 * D, D, 3 * D, 0, s, "qkv"));
+      HIP_TRY(launch_layernorm(t.x, D, w.ln1w, w.ln1b, t.h, t.dtype, M, D, eps, s)); }
+    RUN(run_gemm(e, t, EPI_BIAS, t.h, w.wqkv, t.qkv, w.bqkv, M, 3 * D, D, 3 * D, 0, s, "qkv"));
     RUN(attention());
-    RUN(run_gemm(e, EPI_BIAS_RESID, t.att, w.wo, t.x, w.bo, M, D, D, D, 0, s, "out_proj"));
+    RUN(run_gemm(e, t, EPI_BIAS_RESID, t.att, w.wo, t.x, w.bo, M, D, D, D, 0, s, "out_proj"));
     { Scope sc(e, s, "layernorm", 0, (double)M * D * (4 + e->esz));
-      HIP_TRY(launch_layernorm(t.x, D, w.ln2w, w.ln2b, t.h, e->dtype, M, D, eps, s)); }
-    RUN(run_gemm(e, EPI_BIAS_QGELU, t.h, w.w1, t.mlp, w.b1, M, F, D, F, 0, s, "fc1"));
-    RUN(run_gemm(e, EPI_BIAS_RESID, t.mlp, w.w2, t.x, w.b2, M, D, F, D, 0, s, "fc2"));
+      HIP_TRY(launch_layernorm(t.x, D, w.ln2w, w.ln2b, t.h, t.dtype, M, D, eps, s)); }
+    RUN(run_gemm(e, t, EPI_BIAS_QGELU, t.h, w.w1, t.mlp, w.b1, M, F, D, F, 0, s, "fc1"));
+    RUN(run_gemm(e, t, EPI_BIAS_RESID, t.mlp, w.w2, t.x, w.b2, M, D, F, D, 0, s, "fc2"));
   }
   return PLIPMI_OK;
 }
@@ -373,16 +374,16 @@ int run_last_block_pooled(plipmi_engine* e, Tower& t, int B, int causal, const i
   const int impl = (&t == &e->vis) ? e->attn_impl_vis : e->attn_impl_txt;
   LnArgs use; use.stats = t.st; use.ns = D / kLnSlice; use.inv_d = 1.0f / (float)D; use.eps = e->cfg.layer_norm_eps;
   const int* cu = t.packed ? t.cu : nullptr;
-  RUN(run_gemm(e, EPI_BIAS_LN, t.h, w.wqkv, t.qkv, w.bqkv, M, 3 * D, D, 3 * D, 0, s, "qkv", &use, t.packed ? t.mdev : nullptr));
+  RUN(run_gemm(e, t, EPI_BIAS_LN, t.h, w.wqkv, t.qkv, w.bqkv, M, 3 * D, D, 3 * D, 0, s, "qkv", &use, t.packed ? t.mdev : nullptr));
   { Scope sc(e, s, impl ? "attention_mfma" : "attention_valu", 4.0 * B * t.H * (double)t.S * t.S * 64, (double)M * 4 * D * e->esz);
-    HIP_TRY(launch_attention(t.qkv, t.att, e->dtype, B, t.S, t.H, causal, key_mask, impl, s, cu)); }
+    HIP_TRY(launch_attention(t.qkv, t.att, t.dtype, B, t.S, t.H, causal, key_mask, impl, s, cu)); }
   { Scope sc(e, s, "pool_gather", 0, (double)B * D * (2 * e->esz + 8));
-    HIP_TRY(launch_pool_gather(t.att, t.h, t.lo, t.S, D, ids, eos_id, t.attp, t.xp, B, e->dtype, s, cu)); }
+    HIP_TRY(launch_pool_gather(t.att, t.h, t.lo, t.S, D, ids, eos_id, t.attp, t.xp, B, t.dtype, s, cu)); }
   LnArgs emit; emit.xb_out = t.hp; emit.st_out = t.stp;
-  RUN(run_gemm(e, EPI_RESID_EMIT, t.attp, w.wo, t.xp, w.bo, B, D, D, D, 0, s, "~out_proj_pooled", &emit));
+  RUN(run_gemm(e, t, EPI_RESID_EMIT, t.attp, w.wo, t.xp, w.bo, B, D, D, D, 0, s, "~out_proj_pooled", &emit));
   use.stats = t.stp;
-  RUN(run_gemm(e, EPI_QGELU_LN, t.hp, w.w1, t.mlpp, w.b1, B, F, D, F, 0, s, "~fc1_pooled", &use));
-  RUN(run_gemm(e, EPI_BIAS_RESID, t.mlpp, w.w2, t.xp, w.b2, B, D, F, D, 0, s, "~fc2_pooled"));
+  RUN(run_gemm(e, t, EPI_QGELU_LN, t.hp, w.w1, t.mlpp, w.b1, B, F, D, F, 0, s, "~fc1_pooled", &use));
+  RUN(run_gemm(e, t, EPI_BIAS_RESID, t.mlpp, w.w2, t.xp, w.b2, B, D, F, D, 0, s, "~fc2_pooled"));
   return PLIPMI_OK;
 }
 
@@ -392,16 +393,16 @@ int vision_embed(plipmi_engine* e, const float* pixels, const uint8_t* tiles_u8,
   Tower& t = e->vis;
   if (tiles_u8) {
     Scope sc(e, s, "unfold_patches_u8", 0, (double)B * 3 * g.image_size * g.image_size + (double)B * e->np * e->kpad * e->esz);
-    HIP_TRY(launch_unfold_patches_u8(tiles_u8, e->patches, e->dtype, B, g.image_size, g.patch_size, e->kpad, s));
+    HIP_TRY(launch_unfold_patches_u8(tiles_u8, e->patches, t.dtype, B, g.image_size, g.patch_size, e->kpad, s));
   } else {
     Scope sc(e, s, "unfold_patches", 0, (double)B * 3 * g.image_size * g.image_size * 4 + (double)B * e->np * e->kpad * e->esz);
-    HIP_TRY(launch_unfold_patches(pixels, e->patches, e->dtype, B, g.image_size, g.patch_size, e->kpad, s)); }
+    HIP_TRY(launch_unfold_patches(pixels, e->patches, t.dtype, B, g.image_size, g.patch_size, e->kpad, s)); }
   { Scope sc(e, s, "cls_rows", 0, (double)B * t.D * 4);
     HIP_TRY(launch_cls_rows(e->cls, e->vpos, t.x, B, t.S, t.D, s)); }
-  RUN(run_gemm(e, EPI_PATCH, e->patches, e->patch_w, t.x, e->vpos, B * e->np, t.D, e->kpad, t.D, e->np, s, "patch_embed"));
+  RUN(run_gemm(e, t, EPI_PATCH, e->patches, e->patch_w, t.x, e->vpos, B * e->np, t.D, e->kpad, t.D, e->np, s, "patch_embed"));
   if (e->ln_fold) {   // the tower's one LayerNorm pass: fp32 embedding rows in, the split residual stream + row statistics out
     Scope sc(e, s, "layernorm", 0, (double)B * t.S * t.D * 8.2);
-    HIP_TRY(launch_layernorm_emit(t.x, e->pre_w, e->pre_b, t.h, t.lo, t.st, B * t.S, t.D, g.layer_norm_eps, e->dtype, s));
+    HIP_TRY(launch_layernorm_emit(t.x, e->pre_w, e->pre_b, t.h, t.lo, t.st, B * t.S, t.D, g.layer_norm_eps, t.dtype, s));
     return PLIPMI_OK;
   }
   { Scope sc(e, s, "layernorm", 0, (double)B * t.S * t.D * 8);
@@ -416,11 +417,11 @@ int text_embed(plipmi_engine* e, const int64_t* ids, int B, hipStream_t s, int e
       HIP_TRY(launch_text_pack(ids, B, t.S, eos_id, t.cu, t.rowmap, t.mdev, s)); }
     Scope sc(e, s, "text_embed", 0, (double)B * t.S * t.D * 8.2);
     HIP_TRY(launch_text_embed_emit_packed(ids, e->tok, e->tpos, t.h, t.lo, t.st, t.rowmap, t.mdev, B * t.S, t.S, t.D,
-                                          e->cfg.vocab_size, e->bad_id, e->dtype, s));
+                                          e->cfg.vocab_size, e->bad_id, t.dtype, s));
     return PLIPMI_OK;
   }
   Scope sc(e, s, "text_embed", 0, (double)B * t.S * t.D * (e->ln_fold ? 8.2 : 8.0));
-  if (e->ln_fold) HIP_TRY(launch_text_embed_emit(ids, e->tok, e->tpos, t.h, t.lo, t.st, B, t.S, t.D, e->cfg.vocab_size, e->bad_id, e->dtype, s));
+  if (e->ln_fold) HIP_TRY(launch_text_embed_emit(ids, e->tok, e->tpos, t.h, t.lo, t.st, B, t.S, t.D, e->cfg.vocab_size, e->bad_id, t.dtype, s));
   else HIP_TRY(launch_text_embed(ids, e->tok, e->tpos, t.x, B, t.S, t.D, e->cfg.vocab_size, e->bad_id, s));
   return PLIPMI_OK;
 }
@@ -533,8 +534,11 @@ int plipmi_create(const plipmi_config* cfg, const plipmi_weights* w, void* strea
   const plipmi_config& g = *cfg;
   if (g.compute_dtype != PLIPMI_F32 && g.compute_dtype != PLIPMI_BF16 && g.compute_dtype != PLIPMI_F16)
     return fail(PLIPMI_ERR_INVALID, "compute_dtype must be PLIPMI_F32, PLIPMI_BF16 or PLIPMI_F16");
-  if (g.flags & ~(PLIPMI_FLAG_SEPARATE_LAYERNORM | PLIPMI_FLAG_DENSE_LAST_BLOCK | PLIPMI_FLAG_PACK_CAPTIONS | PLIPMI_FLAG_VALU_ATTENTION))
+  if (g.flags & ~(PLIPMI_FLAG_SEPARATE_LAYERNORM | PLIPMI_FLAG_DENSE_LAST_BLOCK | PLIPMI_FLAG_PACK_CAPTIONS | PLIPMI_FLAG_VALU_ATTENTION |
+                  PLIPMI_FLAG_TEXT_TOWER_F16))
     return fail(PLIPMI_ERR_INVALID, "unknown bits in plipmi_config.flags (0x%x)", (unsigned)g.flags);
+  if ((g.flags & PLIPMI_FLAG_TEXT_TOWER_F16) && g.compute_dtype != PLIPMI_BF16)
+    return fail(PLIPMI_ERR_INVALID, "PLIPMI_FLAG_TEXT_TOWER_F16 is a mode of the bf16 engine (compute_dtype PLIPMI_BF16)");
   if (g.v_heads <= 0 || g.t_heads <= 0 || g.v_width != g.v_heads * 64 || g.t_width != g.t_heads * 64)
     return fail(PLIPMI_ERR_INVALID, "head_dim must be 64 (v_width=%d/%d heads, t_width=%d/%d heads)", g.v_width,
                 g.v_heads, g.t_width, g.t_heads);
@@ -559,6 +563,8 @@ int plipmi_create(const plipmi_config* cfg, const plipmi_weights* w, void* strea
   e->cfg = g;
   e->dtype = g.compute_dtype;
   e->esz = e->half() ? 2 : 4;
+  e->vis.dtype = e->dtype;
+  e->txt.dtype = (g.flags & PLIPMI_FLAG_TEXT_TOWER_F16) ? PLIPMI_F16 : e->dtype;
   e->ln_fold = e->half() && !(g.flags & PLIPMI_FLAG_SEPARATE_LAYERNORM);
   e->pooled_last = e->ln_fold && !(g.flags & PLIPMI_FLAG_DENSE_LAST_BLOCK);
   e->text_pack = e->pooled_last && (g.flags & PLIPMI_FLAG_PACK_CAPTIONS);
@@ -595,7 +601,7 @@ int plipmi_create(const plipmi_config* cfg, const plipmi_weights* w, void* strea
   int rc = PLIPMI_OK;
   auto body = [&]() -> int {
     const int Dv = g.v_width, Dt = g.t_width, P = g.projection_dim;
-    HIP_TRY(launch_convert(w->v_patch_weight, e->patch_w, e->dtype, Dv, 3 * g.patch_size * g.patch_size, e->kpad, 1.f, s));
+    HIP_TRY(launch_convert(w->v_patch_weight, e->patch_w, e->vis.dtype, Dv, 3 * g.patch_size * g.patch_size, e->kpad, 1.f, s));
     HIP_TRY(launch_scale_copy(w->v_class_embedding, e->cls, Dv, 1.f, s));
     HIP_TRY(launch_scale_copy(w->v_pos_embedding, e->vpos, tokens * Dv, 1.f, s));
     HIP_TRY(launch_scale_copy(w->v_pre_ln_w, e->pre_w, Dv, 1.f, s));

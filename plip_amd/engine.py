@@ -33,9 +33,11 @@ class Engine:
 
     def __init__(self, cfg: PlipConfig, state_dict: Mapping[str, object], device="cuda:0", dtype="bf16",
                  max_batch: int = 256, *, ln_fold: bool = True, pooled_last_block: bool = True,
-                 pack_captions: bool = False, mfma_attention: bool = True, graph_batch: Optional[int] = None):
+                 pack_captions: bool = False, mfma_attention: bool = True, graph_batch: Optional[int] = None,
+                 text_f16: bool = False):
         """``ln_fold`` / ``pooled_last_block`` / ``mfma_attention`` = False select the A/B forms of the 16-bit engines
         (separate LayerNorm kernels, the last block on every token, the exact VALU attention kernel);
+        ``text_f16`` (bf16 engine only): the text tower runs on IEEE-half operands, the image tower stays bf16;
         ``graph_batch``: None = default small-batch hipGraph replay (<= 32 samples), 0 = never, n = up to n samples.
         All of it is per-handle configuration (include/plipmi.h plipmi_config.flags): no environment variables."""
         cfg.validate()
@@ -51,7 +53,8 @@ class Engine:
         self.dtype_code = _DTYPES[dtype]
         self.dtype_name = {_lib.BF16: "bf16", _lib.F32: "f32", _lib.F16: "f16"}[self.dtype_code]
         self.flags = ((0 if ln_fold else _lib.FLAG_SEPARATE_LAYERNORM) | (0 if pooled_last_block else _lib.FLAG_DENSE_LAST_BLOCK) |
-                      (_lib.FLAG_PACK_CAPTIONS if pack_captions else 0) | (0 if mfma_attention else _lib.FLAG_VALU_ATTENTION))
+                      (_lib.FLAG_PACK_CAPTIONS if pack_captions else 0) | (0 if mfma_attention else _lib.FLAG_VALU_ATTENTION) |
+                      (_lib.FLAG_TEXT_TOWER_F16 if text_f16 else 0))
         gb = 0 if graph_batch is None else (-1 if int(graph_batch) <= 0 else int(graph_batch))
         self.max_batch = int(max_batch)
         self.lib = _lib.load()

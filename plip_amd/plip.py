@@ -67,13 +67,14 @@ def _uniform_u8_images(chunk, n_px):
 class PLIP:
     def __init__(self, model_name: str = None, auth_token=None, *, model: Optional[PlipModel] = None,
                  tokenizer: Optional[Callable] = None, tokenizer_dir: Optional[str] = None, dtype: str = "bf16",
-                 max_batch: int = 256, device: str = "cuda:0", pack_captions: bool = False):
+                 max_batch: int = 256, device: str = "cuda:0", pack_captions: bool = False, text_f16: bool = False):
         """``model_name``: local HF directory (what ``CLIPModel/CLIPProcessor.from_pretrained`` take, plip.py:26-27)
         or an OpenAI-clip ``.pt`` state dict.  The tokenizer comes from ``tokenizer`` (a callable), else from
         ``tokenizer_dir`` / the model directory when it holds ``vocab.json`` + ``merges.txt``; with neither,
         ``encode_text`` still takes token ids.  ``pack_captions`` (extension, bf16 engine): the text tower computes only
         the positions up to each caption's EOS token -- bit-identical embeddings, cost proportional to the caption lengths
-        instead of the padded 77 (include/plipmi.h ``plipmi_set_text_packing``)."""
+        instead of the padded 77 (include/plipmi.h ``plipmi_set_text_packing``).  ``dtype``: "bf16" | "f16" | "f32";
+        ``text_f16`` (bf16 engine): the text tower on IEEE-half operands (PLIPMI_FLAG_TEXT_TOWER_F16)."""
         if not torch.cuda.is_available():
             raise RuntimeError("plip_amd.PLIP needs an MI355X (ROCm) GPU; there is no CPU path")
         self.device = device
@@ -88,7 +89,7 @@ class PLIP:
             if cand and os.path.exists(os.path.join(cand, "vocab.json")) and os.path.exists(os.path.join(cand, "merges.txt")):
                 tokenizer = load_tokenizer(cand)
         if model is None:
-            model = PlipModel.from_pretrained(model_name, device=device, dtype=dtype, max_batch=max_batch)
+            model = PlipModel.from_pretrained(model_name, device=device, dtype=dtype, max_batch=max_batch, text_f16=text_f16)
         self.model = model.to(self.device)
         if pack_captions:
             self.model.engine.set_text_packing(True)

@@ -63,6 +63,45 @@ def test_full_matrix_parity_bs256_vs_hf_golden(dtype, engines, golden):
         assert (got.argmax(1) == want.argmax(1)).mean() > 0.99
 
 
+def test_text_tower_f16_flag_bs256(engines, golden):
+    """PLIPMI_FLAG_TEXT_TOWER_F16: a bf16 engine whose text tower runs on IEEE-half operands.  Its image side is the bf16
+    engine's bit for bit, its text side the f16 engine's bit for bit, and the cosine logits land well inside the bar."""
+    from plip_amd.model import PlipModel
+    g = golden("vitb32_b256")
+    mb, cfg, sd, *_ = engines("vitb32_b4", "bf16", 256)
+    mh, *_ = engines("vitb32_b4", "f16", 256)
+    _, _, px, ids, mask = case_inputs("vitb32_b256")
+    px, ids, mask = torch.from_numpy(px), torch.from_numpy(ids), torch.from_numpy(mask)
+    mm = PlipModel(cfg, sd, dtype="bf16", max_batch=256, text_f16=True)
+    try:
+        out = mm(input_ids=ids, pixel_values=px, attention_mask=mask)
+        ob = mb(input_ids=ids, pixel_values=px, attention_mask=mask)
+        oh = mh(input_ids=ids, pixel_values=px, attention_mask=mask)
+        assert torch.equal(out.image_embeds, ob.image_embeds)
+        assert torch.equal(out.text_embeds, oh.text_embeds)
+        scale = np.exp(np.float64(sd["logit_scale"]))
+        err = np.abs(out.logits_per_image.cpu().numpy() - g["logits_per_image"]).max() / scale
+        e_txt = np.abs(out.text_embeds.cpu().numpy() - g["text_embeds"]).max()
+        e_img = np.abs(out.image_embeds.cpu().numpy() - g["image_embeds"]).max()
+        print(f"bs=256 bf16 image tower + f16 text tower: max |cos err| = {err:.2e}, image_embeds {e_img:.2e}, text_embeds {e_txt:.2e}")
+        assert err < 5e-4 and e_txt < TOL["f16"]["emb"] and e_img < 1e-3
+        # hidden states of the text tower come back through the f16 planes
+        assert torch.equal(mm.engine.hidden("text", cfg.t_layers, ids[:4]), mh.engine.hidden("text", cfg.t_layers, ids[:4]))
+        assert torch.equal(mm.engine.hidden("vision", cfg.v_layers, px[:4]), mb.engine.hidden("vision", cfg.v_layers, px[:4]))
+    finally:
+        mm.engine.close()
+
+
+def test_text_tower_f16_flag_needs_the_bf16_engine():
+    from plip_amd import weights as W
+    from plip_amd.config import get_config
+    from plip_amd.model import PlipModel
+    cfg = get_config("tiny")
+    for dt in ("f32", "f16"):
+        with pytest.raises(RuntimeError, match="TEXT_TOWER_F16"):
+            PlipModel(cfg, W.synthetic_state_dict(cfg, 0), dtype=dt, max_batch=4, text_f16=True)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("name", FULL_CASES)
 def test_golden_features_and_logits(name, dtype, engines, golden):

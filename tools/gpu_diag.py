@@ -594,8 +594,8 @@ def sec_parity():
     assert np.array_equal(gold["ids"], ids.cpu().numpy())
     scale = float(np.exp(np.float64(sd["logit_scale"])))
     for dt in ("f32", "bf16", "f16"):
-        for kw in ({}, {"ln_fold": False}, {"pooled_last_block": False}):
-            if dt == "f32" and kw:
+        for kw in ({}, {"ln_fold": False}, {"pooled_last_block": False}, {"text_f16": True}):
+            if (dt == "f32" and kw) or ("text_f16" in kw and dt != "bf16"):
                 continue
             model = PlipModel(cfg, sd, dtype=dt, max_batch=256, **kw)
             out = model(input_ids=ids, pixel_values=px, attention_mask=mask)
