@@ -94,7 +94,7 @@ struct GemmParams {
   // test hook (plipmi_gemm_nt_traced): per workgroup 8 x u64 {start, prologue done, main loop done, epilogue
   // done, logical tile id, HW_ID, k tiles, 0}, s_memtime ticks.  nullptr on the product path.
   unsigned long long* trace = nullptr;
-  // test hook (PLIPMI_GEMM_ABLATE, timeline runs only; results are wrong by construction):
+  // test hook (plipmi_set_gemm_trace_ablate, traced launches only; results are wrong by construction):
   // bit 0 = skip the global->LDS fills of the K loop, bit 1 = skip the MFMA block, bit 2 = skip the epilogue,
   // bit 3 = skip the K loop's barriers, bit 4 = skip the K loop's LDS fragment reads
   int ablate = 0;
@@ -803,7 +803,7 @@ void gemm_nt_kernel(const GemmParams p) {
 }
 
 // One thread per output element; the on-device checker for the MFMA kernels
-// (tests and PLIPMI_NAIVE_GEMM=1), never used on the product path by default.
+// (tests: variant -2), never used on the product path.
 template <typename T, int EPI>
 __global__ void gemm_nt_naive_kernel(const GemmParams p) {
   const int n4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
@@ -836,7 +836,8 @@ bool gemm_variant_is_built(int dtype, int variant);
 // small-M kernel of the 16-bit engines (gemm_skinny.hip): 32 x 64 output tile per workgroup, K split over its waves
 bool gemm_skinny_supports(int epi, int M, int N, int K);
 int gemm_launch_skinny(int dtype, int epi, const GemmParams& p, hipStream_t stream, const char** kernel_name);
-void gemm_set_default_override(int variant);  // PLIPMI_GEMM_VARIANT / tests (process-wide A/B hook, not a product knob)
+void gemm_set_default_override(int variant);  // tests / A-B runs (process-wide hook, not a product knob)
 void gemm_set_store_wt(int on);               // experiment hook: write-through epilogue stores (process-wide)
+void gemm_set_trace_ablate(int bits);         // experiment hook: GemmParams::ablate of traced launches (process-wide)
 
 }  // namespace plipmi

@@ -30,21 +30,19 @@ int gemm_num_cus() {
 int gemm_num_variants() { return kNumVariants; }
 const GemmVariant& gemm_variant(int v) { return kVariants[v]; }
 
-// Process-wide override of the tile choice: a TEST / A-B hook only (PLIPMI_GEMM_VARIANT, plipmi_set_gemm_variant).
-// The product path never writes it; the tile POLICY is a per-call argument owned by the handle.
-static int g_override = -100;  // -100 = not yet read
+// Process-wide overrides for TESTS and A/B measurements (plipmi_set_gemm_variant, plipmi_set_gemm_store_wt): the product
+// path never writes them, and nothing here is read from the environment.
+static int g_override = -1;    // -1 = the cost model below chooses
 void gemm_set_default_override(int variant) { g_override = variant; }
-static int g_store_wt = -1;   // -1 = not yet read (PLIPMI_GEMM_STORE_WT; default on)
+static int g_store_wt = 1;     // write-through epilogue stores (default on)
 void gemm_set_store_wt(int on) { g_store_wt = on ? 1 : 0; }
+static int g_trace_ablate = 0;  // parts of the kernel left out in TRACED launches (GemmParams::ablate; timeline experiments)
+void gemm_set_trace_ablate(int bits) { g_trace_ablate = bits; }
 bool gemm_variant_is_built(int dtype, int variant) {
   return dtype == 1 ? gemm_built_bf16(variant) : dtype == 2 ? gemm_built_f16(variant) : gemm_built_f32(variant);
 }
 
 int gemm_default_variant(int dtype, int M, int N, int K) {
-  if (g_override == -100) {
-    const char* e = getenv("PLIPMI_GEMM_VARIANT");
-    g_override = e ? atoi(e) : -1;
-  }
   if (g_override >= 0 || g_override == -2) {
     if (g_override >= 0 && (N % kVariants[g_override].bn != 0 || !gemm_variant_is_built(dtype, g_override))) return 0;
     return g_override;
@@ -104,15 +102,12 @@ int gemm_launch(int dtype, int epi, int variant, const GemmParams& p, hipStream_
   GemmLaunchFn fn = dtype == 1 ? gemm_get_bf16(variant, epi) : dtype == 2 ? gemm_get_f16(variant, epi) : gemm_get_f32(variant, epi);
   if (!fn) return (int)hipErrorInvalidValue;
   GemmParams pr = p;
-  if (g_store_wt < 0) { const char* e = getenv("PLIPMI_GEMM_STORE_WT"); g_store_wt = e ? atoi(e) : 1; }
   pr.store_wt = g_store_wt;
   if (variant >= 0) {
     // column-group raster: minimise A*xn + W*(8/xn) fabric bytes subject to an XCD's W share fitting its L2
     const double esz = dtype == 0 ? 4.0 : 2.0;
     const int nbn = p.N / kVariants[variant].bn;
     const double a_bytes = (double)p.M * p.K * esz, w_bytes = (double)p.N * p.K * esz;
-    static int force = -2;
-    if (force == -2) { const char* e = getenv("PLIPMI_GEMM_XN"); force = e ? atoi(e) : -1; }
     int best_xn = 1;
     double best = 1e300;
     for (int xn = 1; xn <= 8; xn *= 2) {
@@ -122,13 +117,10 @@ int gemm_launch(int dtype, int epi, int variant, const GemmParams& p, hipStream_
       if (share > 2.5e6) cost += 4.0 * w_bytes * 8.0;  // W share thrashes the L2: every M row re-fetches it
       if (cost < best) { best = cost; best_xn = xn; }
     }
-    if (force > 0 && nbn % force == 0) best_xn = force;
     pr.gw = nbn / best_xn;
   }
   if (p.trace) {  // timeline runs may ablate parts of the kernel (never on the product path: trace is null there)
-    static int ablate = -1;
-    if (ablate < 0) { const char* e = getenv("PLIPMI_GEMM_ABLATE"); ablate = e ? atoi(e) : 0; }
-    if (ablate) { pr.ablate = ablate; return fn(pr, stream); }
+    if (g_trace_ablate) { pr.ablate = g_trace_ablate; return fn(pr, stream); }
   }
   if (kernel_name) {
     // static table of names: "gemm_nt<dtype,tile,epi>"

@@ -33,8 +33,8 @@ int launch_naive(const GemmParams& p, hipStream_t stream) {
   return (int)hipGetLastError();
 }
 
-// The tile variants, each built for every dtype; numbers are what plipmi_gemm_nt(variant=...) and PLIPMI_GEMM_VARIANT
-// take, names come from gemm.hip.
+// The tile variants, each built for every dtype; numbers are what plipmi_gemm_nt(variant=...) and
+// plipmi_set_gemm_variant take, names come from gemm.hip.
 //   0  128x128, 2x2 waves, two workgroups per CU, 64-bit lane addresses (operands of 4 GiB and more; small problems)
 //   1  128x128, 2x2 waves, buffer-form LDS-DMA
 //   2  256x256, 4x2 waves

@@ -32,6 +32,19 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 2 and lib.plipmi_gemm_variant_name(-1) is None
 
 
+def test_library_reads_no_environment_variables():
+    """Every switch of the library is an argument (plipmi_config.flags, per-handle setters, the test hooks): the shared
+    object does not even import getenv."""
+    import subprocess
+    from plip_amd.build import LIB as LIB_PATH, build
+    build(verbose=False)
+    syms = subprocess.run(["nm", "-D", "--undefined-only", LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in syms
+    for f in os.listdir(os.path.join(ROOT, "plip_amd", "csrc")):
+        if f.endswith((".hip", ".h")):
+            assert "getenv" not in open(os.path.join(ROOT, "plip_amd", "csrc", f)).read(), f
+
+
 def test_struct_layouts_match_header():
     """ctypes mirrors of the C structs: field order/sizes as in include/plipmi.h."""
     import ctypes as C

@@ -357,6 +357,9 @@ def sec_gemmtrace():
     """In-kernel timeline of one GEMM launch: where a workgroup's lifetime goes.
     usage: gpu_diag.py gemmtrace <variant> <M> <N> <K> <epi>"""
     v, M, N, K, epi = (int(x) for x in sys.argv[2:7]) if len(sys.argv) > 6 else (5, 12800, 3072, 768, 1)
+    # this TOOL's switch (the library itself reads no environment): parts of the kernel to leave out of the traced launch
+    from plip_amd import _lib
+    _lib.load().plipmi_set_gemm_trace_ablate(int(os.environ.get("PLIPMI_GEMM_ABLATE", "0")))
     g = torch.Generator().manual_seed(0)
     dtype = torch.bfloat16
     a = torch.randn(M, K, generator=g).to(dev).to(dtype)
