@@ -475,7 +475,8 @@ void gemm_nt_kernel(const GemmParams p) {
   auto compute = [&](int buf, int fill_buf) {
     const char* sb = smem + buf * STAGE;
     // fragments of K-step ks+1 are fetched from LDS before the MFMAs of step ks issue.  (Rows past an uneven wave row's
-    // last block are read too -- in-bounds LDS bytes nobody multiplies -- so the reads stay branch-free.)
+    // last block are read too -- in-bounds LDS bytes nobody multiplies -- so the reads stay branch-free: skipping them behind a
+    // wave-uniform branch measured 47.2 vs 44.6 us per launch of the residual GEMMs in the step.)
     u32x4 xf[2][MI], wf[2][NI];
     const bool rd = !(p.ablate & 16);
     if (rd) {
