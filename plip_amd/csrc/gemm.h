@@ -95,7 +95,7 @@ struct GemmParams {
   // done, logical tile id, HW_ID, k tiles, 0}, s_memtime ticks.  nullptr on the product path.
   unsigned long long* trace = nullptr;
   // test hook (plipmi_set_gemm_trace_ablate, traced launches only; results are wrong by construction):
-  // bit 0 = skip the global->LDS fills of the K loop, bit 1 = skip the MFMA block, bit 2 = skip the epilogue,
+  // bit 0 = skip the global->LDS fills of the K loop, bit 1 = skip the MFMA block (two-stage tiles), bit 2 = skip the epilogue,
   // bit 3 = skip the K loop's barriers, bit 4 = skip the K loop's LDS fragment reads
   int ablate = 0;
   // output stores write through the XCD's L2 (sc0 sc1) instead of leaving dirty lines for the end-of-kernel write-back
@@ -260,7 +260,12 @@ struct EpilogueOp {
 //          in front of each step's MFMA group, instead of queueing all of them on the texture-address unit at once.
 // NSTAGE 2: the fill runs ONE K tile ahead, the end-of-iteration wait is vmcnt(0);
 //        3: three LDS stages, the fill runs TWO K tiles ahead and the wait is a counted vmcnt (in-order retirement: the
-//           older tile has landed, the newest may still fly).  Needs 3 * (BM + BN) * 128 B of the 160 KB.
+//           older tile has landed, the newest may still fly).  Needs 3 * (BM + BN) * 128 B of the 160 KB.  The iteration's
+//           barrier sits IN FRONT of its last K step's MFMAs: behind it a wave first requests the next tile's first
+//           fragments, then issues the MFMA group it still holds in registers -- the LDS round trip every wave starts a tile
+//           with runs under matrix work instead of in front of it (2105 -> 1793 cycles per K tile, profiles/r03_gemm_kloop.txt).
+//           (With two stages the same move buys 0-2 % per kernel and nothing on the step: there the iteration waits for the fill --
+//           profiles/r02_experiments_not_shipped.txt item 6, re-measured in round 3.)
 // ADDR 0: 64-bit per-lane global addresses (any operand size); 1: buffer resource + 32-bit lane offset (< 4 GiB).
 // waves per SIMD the kernel is built for: 2 (LDS caps residency there, so let the allocator use 256 VGPRs)
 template <typename T, int BM, int BN, int WM, int WN, int EPI, int SCHED = 0, int ADDR = 0, int NSTAGE = 2>
@@ -541,10 +546,38 @@ void gemm_nt_kernel(const GemmParams p) {
     trace[6] = KT;
   }
   if constexpr (NSTAGE == 3) {
-    // ring of three: at the top of iteration kt tile kt is visible, tile kt+1 is landing or landed, and the fill of tile
-    // kt+2 goes into the stage every wave left at the last barrier.  The wait at the end of the iteration leaves one
-    // tile's requests of this wave outstanding (vmcnt retires in order): tile kt+1 has landed, tile kt+2 may still fly.
+    // Ring of three.  Invariants at the top of iteration kt: tile kt is visible and its K-step-0 fragments are in registers;
+    // tile kt+1 is landing or landed; the stage of tile kt-1 is free (every wave's reads of it had returned before the
+    // barrier of iteration kt-1), so the fill of tile kt+2 goes there.  The wait in front of the barrier leaves one tile's
+    // requests of this wave outstanding (vmcnt retires in order): tile kt+1 has landed, tile kt+2 may still fly.
     constexpr int kLeave = PA_MIN + PW;
+    u32x4 xf[2][MI], wf[2][NI];
+    const bool rd = !(p.ablate & 16);
+    auto read_frags = [&](int stage, int ks, int b) {
+      if (!rd) return;
+      const char* sb = smem + stage * STAGE;
+#pragma unroll
+      for (int i = 0; i < MI; ++i) xf[b][i] = *reinterpret_cast<const u32x4*>(sb + a_tile + i * 32 * 128 + foff[ks]);
+#pragma unroll
+      for (int j = 0; j < NI; ++j) wf[b][j] = *reinterpret_cast<const u32x4*>(sb + w_tile + j * 32 * 128 + foff[ks]);
+    };
+    auto mma_step = [&](int b) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        if (kUneven && i >= mi_w) break;   // wave-uniform
+#pragma unroll
+        for (int j = 0; j < NI; ++j) mma16<T>(acc[i][j], wf[b][j], xf[b][i]);
+      }
+    };
+    if (!rd) {
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) xf[b][i] = u32x4{1u, 2u, 3u, 4u};
+#pragma unroll
+        for (int j = 0; j < NI; ++j) wf[b][j] = u32x4{1u, 2u, 3u, 4u};
+      }
+    }
     stage_issue(0);
     if (KT > 1) stage_issue(1);
     stage_ln_rows();
@@ -552,23 +585,43 @@ void gemm_nt_kernel(const GemmParams p) {
     else wait_vm0();
     __syncthreads();
     if (trace && tid == 0) trace[1] = __builtin_amdgcn_s_memtime();
-    int cur = 0, nxt2 = 2;  // stage of tile kt, stage of tile kt+2
+    read_frags(0, 0, 0);
+    int cur = 0, nxt = 1, nxt2 = 2;  // stages of tiles kt, kt+1, kt+2
     for (int kt = 0; kt < KT - 1; ++kt) {
       const bool fetch = kt + 2 < KT && !(p.ablate & 1);
       if constexpr (!kSpread) { if (fetch) stage_issue(nxt2); }
-      if (!(p.ablate & 2)) compute(cur, fetch ? nxt2 : -1);
-      if (fetch) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kLeave) : "memory");
-      else wait_vm0();
-      if (!(p.ablate & 8)) __syncthreads();  // tile kt+1 visible to all waves; stage `cur` free for tile kt+3
-      cur = cur == 2 ? 0 : cur + 1;
-      nxt2 = nxt2 == 2 ? 0 : nxt2 + 1;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        if (ks < 3) {
+          read_frags(cur, ks + 1, (ks + 1) & 1);
+          if constexpr (kSpread) { if (fetch && ks < kFillParts) stage_issue_part(nxt2, ks); }
+        } else {
+          // this wave's pieces of tile kt+1 have landed and its last reads of tile kt have returned: publish, then fetch
+          // the next tile's first fragments while the MFMAs below run
+          if (fetch) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kLeave) : "memory");
+          else wait_vm0();
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          if (!(p.ablate & 8)) __syncthreads();
+          read_frags(nxt, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mma_step(ks & 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      cur = nxt; nxt = nxt2; nxt2 = 3 - cur - nxt;   // rotate: the stage tile kt leaves becomes tile kt+3's
     }
     if constexpr (kRowOperand) {  // the residual / position rows of the first 32-row block travel during the last K tile
       load_block(0, add[0]);
       add_ready = true;
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (!(p.ablate & 2)) compute(cur, -1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      if (ks < 3) read_frags(cur, ks + 1, (ks + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_step(ks & 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
   } else {
     stage_issue(0);
     stage_ln_rows();

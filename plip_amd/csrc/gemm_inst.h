@@ -41,7 +41,7 @@ int launch_naive(const GemmParams& p, hipStream_t stream) {
 //   3  320x256, 2x4 waves
 //   4  192x256, 2x4 waves
 //   5  160x256, 2x4 waves with 3 + 2 row blocks per wave row: 240 / 248 tiles on the bs=256 residual GEMMs (256 CUs)
-//   6  160x256 on a ring of three LDS stages (two K tiles of lookahead)
+//   6  160x256 on a ring of three LDS stages (two K tiles of lookahead, barrier in front of the last K step's MFMAs)
 constexpr int kNumVariants = 7;
 
 template <typename T>
