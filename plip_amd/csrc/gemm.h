@@ -30,6 +30,10 @@
 #include <type_traits>
 #include "common.h"
 
+#ifndef PLIPMI_ABLATE_HOOKS
+#define PLIPMI_ABLATE_HOOKS 2
+#endif
+
 namespace plipmi {
 
 // first-class vector (HIP's uint4 struct keeps staging arrays in scratch)
@@ -297,6 +301,8 @@ void gemm_nt_kernel(const GemmParams p) {
   static_assert(PA == PA_MIN || (NT / 8) % 8 == 0, "partial last A pass: whole waves in or out");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  // timing-experiment hooks (GemmParams::ablate): compiled into the kernels the macro selects
+  const int ablate_bits = (PLIPMI_ABLATE_HOOKS == 2 || (PLIPMI_ABLATE_HOOKS == 1 && NSTAGE == 2)) ? p.ablate : 0;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -483,7 +489,7 @@ void gemm_nt_kernel(const GemmParams p) {
     // last block are read too -- in-bounds LDS bytes nobody multiplies -- so the reads stay branch-free: skipping them behind a
     // wave-uniform branch measured 47.2 vs 44.6 us per launch of the residual GEMMs in the step.)
     u32x4 xf[2][MI], wf[2][NI];
-    const bool rd = !(p.ablate & 16);
+    const bool rd = !(ablate_bits & 16);
     if (rd) {
 #pragma unroll
       for (int i = 0; i < MI; ++i) xf[0][i] = *reinterpret_cast<const u32x4*>(sb + a_tile + i * 32 * 128 + foff[0]);
@@ -552,7 +558,7 @@ void gemm_nt_kernel(const GemmParams p) {
     // requests of this wave outstanding (vmcnt retires in order): tile kt+1 has landed, tile kt+2 may still fly.
     constexpr int kLeave = PA_MIN + PW;
     u32x4 xf[2][MI], wf[2][NI];
-    const bool rd = !(p.ablate & 16);
+    const bool rd = !(ablate_bits & 16);
     auto read_frags = [&](int stage, int ks, int b) {
       if (!rd) return;
       const char* sb = smem + stage * STAGE;
@@ -588,7 +594,7 @@ void gemm_nt_kernel(const GemmParams p) {
     read_frags(0, 0, 0);
     int cur = 0, nxt = 1, nxt2 = 2;  // stages of tiles kt, kt+1, kt+2
     for (int kt = 0; kt < KT - 1; ++kt) {
-      const bool fetch = kt + 2 < KT && !(p.ablate & 1);
+      const bool fetch = kt + 2 < KT && !(ablate_bits & 1);
       if constexpr (!kSpread) { if (fetch) stage_issue(nxt2); }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
@@ -601,7 +607,7 @@ void gemm_nt_kernel(const GemmParams p) {
           if (fetch) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kLeave) : "memory");
           else wait_vm0();
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          if (!(p.ablate & 8)) __syncthreads();
+          if (!(ablate_bits & 8)) __syncthreads();
           read_frags(nxt, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -631,18 +637,18 @@ void gemm_nt_kernel(const GemmParams p) {
     for (int kt = 0; kt < KT - 1; ++kt) {
       const int cur = kt & 1;
       if constexpr (!kSpread) {
-        if (!(p.ablate & 1)) stage_issue(cur ^ 1);
+        if (!(ablate_bits & 1)) stage_issue(cur ^ 1);
       }
-      if (!(p.ablate & 2)) compute(cur, (p.ablate & 1) ? -1 : (cur ^ 1));
+      if (!(ablate_bits & 2)) compute(cur, (ablate_bits & 1) ? -1 : (cur ^ 1));
       wait_vm0();
-      if (!(p.ablate & 8)) __syncthreads();
+      if (!(ablate_bits & 8)) __syncthreads();
     }
     if constexpr (kRowOperand) {  // the residual / position rows of the first 32-row block travel during the last K step
       load_block(0, add[0]);
       add_ready = true;
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (!(p.ablate & 2)) compute((KT - 1) & 1, -1);
+    if (!(ablate_bits & 2)) compute((KT - 1) & 1, -1);
   }
   if (trace && tid == 0) trace[2] = __builtin_amdgcn_s_memtime();
 
@@ -658,7 +664,7 @@ void gemm_nt_kernel(const GemmParams p) {
   static_assert(WM * WN * SLAB_BYTES <= NSTAGE * STAGE, "epilogue slabs must fit in the staging buffers");
   static_assert(NI % 2 == 0, "epilogue handles two 32-column MFMA tiles per slab");
   __syncthreads();  // every wave is done reading the last K tile: the staging LDS can be reused
-  if (p.ablate & 4) return;
+  if (ablate_bits & 4) return;
   const bool wt = p.store_wt != 0;
   char* slab = smem + wave * SLAB_BYTES;
   if constexpr (sizeof(T) == 2 && epi_is_colwise(EPI)) {
@@ -719,7 +725,7 @@ void gemm_nt_kernel(const GemmParams p) {
         for (int it = 0; it < 4; ++it) {
           int m = m0 + wm * TM + i * 32 + it * 8 + hr_row;
           const bool in_range = m < Mrt;
-          if (p.ablate & 32) m &= 255;  // timeline experiment: every tile stores to the same 256 rows (L2-resident)
+          if (ablate_bits & 32) m &= 255;  // timeline experiment: every tile stores to the same 256 rows (L2-resident)
           if (in_range)
             store16(reinterpret_cast<OutT*>(p.C) + (size_t)m * p.ldc + n0 + wn * TN + jp * 64 + hr_chunk * 8, o[it], wt);
         }
@@ -821,7 +827,7 @@ void gemm_nt_kernel(const GemmParams p) {
       for (int it = 0; it < 8; ++it) {
         int m = m0 + wm * TM + i * 32 + it * 4 + rd_row;
         const bool in_range = m < Mrt;
-        if (p.ablate & 32) m &= 255;  // timeline experiment: every tile stores to the same 256 rows (L2-resident)
+        if (ablate_bits & 32) m &= 255;  // timeline experiment: every tile stores to the same 256 rows (L2-resident)
         if constexpr (EPI == EPI_RESID_EMIT) {
           // the updated residual row piece (4 columns per lane, 16 lanes = one 64-column slice of one row): fp32 in
           // place, its 16-bit copy for the next GEMM's A operand, and the slice's LayerNorm partials {sum, centred M2}

@@ -11,6 +11,7 @@ for s in $SECTIONS; do
   case $s in
     pytest)  timeout 1200 python -m pytest tests -m gpu -q -x > gpurun_out/pytest_gpu.log 2>&1 ;;
     pytestall) timeout 1500 python -m pytest tests -m gpu -q > gpurun_out/pytest_gpu.log 2>&1 ;;
+    pytestprints) timeout 900 python -m pytest tests/test_gpu_configs.py tests/test_gpu_parity.py -m gpu -q -s -k "vitl14 or heavy_tailed or config3 or full_matrix or text_tower_f16" 2>&1 | grep -E "cos|err|passed|failed" > gpurun_out/pytest_prints.log ;;
     bench)   timeout 600 python bench.py --steps 20 --warmup 3 > gpurun_out/bench.json 2> gpurun_out/bench.err ;;
     rocprof) (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/gpurun_out/prof" -o plip -- python "$OLDPWD/bench.py" --steps 10 --warmup 2 --no-cpu-baseline --no-profile --no-extras > "$OLDPWD/gpurun_out/rocprof_bench.json" 2> "$OLDPWD/gpurun_out/rocprof.err")
              (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/gpurun_out/prof1s" -o plip -- python "$OLDPWD/bench.py" --steps 10 --warmup 2 --no-cpu-baseline --no-profile --no-extras --overlap 0 > "$OLDPWD/gpurun_out/rocprof_bench_1stream.json" 2>> "$OLDPWD/gpurun_out/rocprof.err") ;;
