@@ -252,12 +252,6 @@ int plipmi_gemm_variant_built(int dtype, int variant);
 /* TEST / A-B HOOK, process-wide, not used by the product path: force every GEMM onto one tile variant (>= 0), or back
  * to the engine's own choice (-1).  (The library reads no environment variables.) */
 void plipmi_set_gemm_variant(int variant);
-/* TEST / A-B HOOK, process-wide: epilogue stores of every GEMM write through the XCD's L2 (1) or not (0) */
-void plipmi_set_gemm_store_wt(int on);
-/* TEST HOOK, process-wide: parts of the GEMM kernel left out in plipmi_gemm_nt_traced launches (timing experiments;
- * results are wrong by construction): 1 K-loop fills, 2 MFMA block, 4 epilogue, 8 K-loop barriers, 16 LDS fragment
- * reads, 32 stores confined to 256 rows.  Untraced launches -- the product path -- ignore it. */
-void plipmi_set_gemm_trace_ablate(int bits);
 /* same call with explicit leading dimensions (in elements) for A [M,K] and W [N,K]: rows may be padded */
 int plipmi_gemm_nt_ld(int dtype, int epilogue, int variant, int M, int N, int K, const void* A, int lda, const void* W,
                       int ldw, const float* bias, float alpha, void* C, void* stream);

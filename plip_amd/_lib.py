@@ -67,8 +67,6 @@ SYMBOLS = {
     "plipmi_gemm_nt": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _f, _vp, _vp]),
     "plipmi_gemm_variant_name": (C.c_char_p, [_i]),
     "plipmi_set_gemm_variant": (None, [_i]),
-    "plipmi_set_gemm_store_wt": (None, [_i]),
-    "plipmi_set_gemm_trace_ablate": (None, [_i]),
     "plipmi_gemm_variant_built": (_i, [_i, _i]),
     "plipmi_set_text_packing": (_i, [_vp, _i]),
     "plipmi_gemm_nt_ln": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp]),

@@ -893,8 +893,6 @@ int plipmi_gemm_nt_ld(int dtype, int epilogue, int variant, int M, int N, int K,
 }
 
 void plipmi_set_gemm_variant(int variant) { gemm_set_default_override(variant); }
-void plipmi_set_gemm_store_wt(int on) { gemm_set_store_wt(on); }
-void plipmi_set_gemm_trace_ablate(int bits) { gemm_set_trace_ablate(bits); }
 int plipmi_check_async(plipmi_handle h) {
   if (!h) return fail(PLIPMI_ERR_INVALID, "null handle");
   return check_async(h);

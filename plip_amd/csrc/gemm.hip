@@ -30,14 +30,10 @@ int gemm_num_cus() {
 int gemm_num_variants() { return kNumVariants; }
 const GemmVariant& gemm_variant(int v) { return kVariants[v]; }
 
-// Process-wide overrides for TESTS and A/B measurements (plipmi_set_gemm_variant, plipmi_set_gemm_store_wt): the product
-// path never writes them, and nothing here is read from the environment.
+// Process-wide override for TESTS and A/B measurements (plipmi_set_gemm_variant): the product path never writes it, and
+// nothing here is read from the environment.
 static int g_override = -1;    // -1 = the cost model below chooses
 void gemm_set_default_override(int variant) { g_override = variant; }
-static int g_store_wt = 1;     // write-through epilogue stores (default on)
-void gemm_set_store_wt(int on) { g_store_wt = on ? 1 : 0; }
-static int g_trace_ablate = 0;  // parts of the kernel left out in TRACED launches (GemmParams::ablate; timeline experiments)
-void gemm_set_trace_ablate(int bits) { g_trace_ablate = bits; }
 bool gemm_variant_is_built(int dtype, int variant) {
   return dtype == 1 ? gemm_built_bf16(variant) : dtype == 2 ? gemm_built_f16(variant) : gemm_built_f32(variant);
 }
@@ -102,7 +98,6 @@ int gemm_launch(int dtype, int epi, int variant, const GemmParams& p, hipStream_
   GemmLaunchFn fn = dtype == 1 ? gemm_get_bf16(variant, epi) : dtype == 2 ? gemm_get_f16(variant, epi) : gemm_get_f32(variant, epi);
   if (!fn) return (int)hipErrorInvalidValue;
   GemmParams pr = p;
-  pr.store_wt = g_store_wt;
   if (variant >= 0) {
     // column-group raster: minimise A*xn + W*(8/xn) fabric bytes subject to an XCD's W share fitting its L2
     const double esz = dtype == 0 ? 4.0 : 2.0;
@@ -118,9 +113,6 @@ int gemm_launch(int dtype, int epi, int variant, const GemmParams& p, hipStream_
       if (cost < best) { best = cost; best_xn = xn; }
     }
     pr.gw = nbn / best_xn;
-  }
-  if (p.trace) {  // timeline runs may ablate parts of the kernel (never on the product path: trace is null there)
-    if (g_trace_ablate) { pr.ablate = g_trace_ablate; return fn(pr, stream); }
   }
   if (kernel_name) {
     // static table of names: "gemm_nt<dtype,tile,epi>"

@@ -72,33 +72,6 @@ def test_gemm_variants(dtype, variant, epi):
         assert err < tol, f"variant {variant} epi {epi} {M}x{N}x{K}: max err {err:.3e} (tol {tol:.1e})"
 
 
-@pytest.mark.parametrize("variant", [2, 4, 5])
-def test_write_through_epilogue_stores_change_no_bit(variant):
-    """plipmi_set_gemm_store_wt: the same values through `global_store_dwordx4 ... sc0 sc1` (an A/B hook)."""
-    from plip_amd import _lib
-    from plip_amd.engine import gemm_nt, gemm_nt_ln, split_planes
-    dev = torch.device("cuda:0")
-    g = torch.Generator().manual_seed(9)
-    M, N, K = 700, 512, 512
-    a = torch.randn(M, K, generator=g).to(dev).bfloat16()
-    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev).bfloat16()
-    bias = torch.randn(N, generator=g).to(dev)
-    hi0, lo0 = split_planes(torch.randn(M, N, generator=g).to(dev))
-    lib = _lib.load()
-    outs = []
-    try:
-        for wt in (0, 1):
-            lib.plipmi_set_gemm_store_wt(wt)
-            y = gemm_nt(a, w, bias, epilogue=1, variant=variant)
-            hi, lo, st = gemm_nt_ln(3, a, w, bias, variant=variant, out=(hi0.clone(), lo0.clone()))
-            torch.cuda.synchronize()
-            outs.append((y, hi, lo, st))
-    finally:
-        lib.plipmi_set_gemm_store_wt(1)            # the library's default
-    for u, v in zip(*outs):
-        assert torch.equal(u, v)
-
-
 def test_gemm_matches_naive_checker_bitwise_fp32():
     """fp32 MFMA is an fmaf chain: tiled and naive kernels only differ in summation order."""
     from plip_amd.engine import gemm_nt

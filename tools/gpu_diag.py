@@ -357,9 +357,6 @@ def sec_gemmtrace():
     """In-kernel timeline of one GEMM launch: where a workgroup's lifetime goes.
     usage: gpu_diag.py gemmtrace <variant> <M> <N> <K> <epi>"""
     v, M, N, K, epi = (int(x) for x in sys.argv[2:7]) if len(sys.argv) > 6 else (5, 12800, 3072, 768, 1)
-    # this TOOL's switch (the library itself reads no environment): parts of the kernel to leave out of the traced launch
-    from plip_amd import _lib
-    _lib.load().plipmi_set_gemm_trace_ablate(int(os.environ.get("PLIPMI_GEMM_ABLATE", "0")))
     g = torch.Generator().manual_seed(0)
     dtype = torch.bfloat16
     a = torch.randn(M, K, generator=g).to(dev).to(dtype)
@@ -429,26 +426,24 @@ def sec_policy():
     lib = _lib.load()
     B = 256
     cfg, sd, px, ids, mask = _step_inputs(B)
-    arms = sys.argv[2:] or ["bf16:-1:1", "bf16:-1:0", "bf16:4:1", "f16:-1:1", "f16:-1:0"]
+    arms = sys.argv[2:] or ["bf16:-1", "bf16:4", "bf16:6", "f16:-1"]
     models = {}
     res = {(a, ov): [] for a in arms for ov in (False, True)}
     for rep in range(4):
         for arm in arms:
-            dt, var, wt = arm.split(":")
+            dt, var = arm.split(":")
             if dt not in models:
                 models[dt] = PlipModel(cfg, sd, dtype=dt, max_batch=B)
             model = models[dt]
             lib.plipmi_set_gemm_variant(int(var))
-            lib.plipmi_set_gemm_store_wt(int(wt))
             for ov in (False, True):
                 ms = _time(lambda: sharded_pair_logits(model, px, ids, mask, overlap=ov), iters=10, warm=2)
                 if rep:                      # rep 0 = warm-up of clocks / caches
                     res[(arm, ov)].append(ms)
     lib.plipmi_set_gemm_variant(-1)
-    lib.plipmi_set_gemm_store_wt(1)
     for arm in arms:
         a, b = res[(arm, False)], res[(arm, True)]
-        print(f"dtype:variant:write-through {arm:12s} one stream {np.median(a):6.3f} ms (min {min(a):6.3f})   "
+        print(f"dtype:variant {arm:12s} one stream {np.median(a):6.3f} ms (min {min(a):6.3f})   "
               f"two streams {np.median(b):6.3f} ms (min {min(b):6.3f})  -> {B / np.median(b) * 1e3:7.0f} pairs/s")
 
 
@@ -464,7 +459,7 @@ def sec_tiles():
     shapes = [("v.qkv", 12800, 2304, 768, 0), ("v.fc1", 12800, 3072, 768, 1), ("v.out", 12800, 768, 768, 3),
               ("v.fc2", 12800, 768, 3072, 3), ("t.qkv", 19712, 1536, 512, 0), ("t.fc1", 19712, 2048, 512, 1),
               ("t.out", 19712, 512, 512, 3), ("t.fc2", 19712, 512, 2048, 3)]
-    variants = [2, 3, 4, 5]
+    variants = [2, 3, 4, 5, 6]
     names = gemm_variants()
     print("variants:", {v: names[v] for v in variants}, "dtype", hdt)
     g = torch.Generator().manual_seed(0)
@@ -483,17 +478,14 @@ def sec_tiles():
             run = lambda v: gemm_nt_ln(mode, a, w, bias, st, variant=v, out=out)
         best = {}
         for rep in range(2):
-            for wt in (0, 1):
-                lib.plipmi_set_gemm_store_wt(wt)
-                for v in variants:
-                    us = _time(lambda: run(v), iters=20, warm=3) * 1e3
-                    best[(v, wt)] = min(best.get((v, wt), 1e9), us)
-        lib.plipmi_set_gemm_store_wt(1)
+            for v in variants:
+                us = _time(lambda: run(v), iters=20, warm=3) * 1e3
+                best[v] = min(best.get(v, 1e9), us)
         lib_us = _time(lambda: F.linear(a, w, bias.to(hdt)), iters=20, warm=3) * 1e3
-        row = "  ".join(f"v{v}: {best[(v, 0)]:6.1f}/{best[(v, 1)]:6.1f}" for v in variants)
+        row = "  ".join(f"v{v}: {best[v]:6.1f}" for v in variants)
         bv = min(best, key=best.get)
-        print(f"{name:6s} {M}x{N}x{K} {('ln_bias', 'ln_qgelu', '', 'resid_split')[mode]:11s} us plain/write-through  {row}   "
-              f"| best v{bv[0]} wt{bv[1]} {fl / best[bv]:7.1f} TF/s | vendor F.linear+bias {lib_us:6.1f} us {fl / lib_us:7.1f} TF/s")
+        print(f"{name:6s} {M}x{N}x{K} {('ln_bias', 'ln_qgelu', '', 'resid_split')[mode]:11s} us  {row}   "
+              f"| best v{bv} {fl / best[bv]:7.1f} TF/s | vendor F.linear+bias {lib_us:6.1f} us {fl / lib_us:7.1f} TF/s")
 
 
 def sec_cold():
@@ -503,7 +495,7 @@ def sec_cold():
     from plip_amd.engine import gemm_nt_ln, split_planes
     shapes = [("v.qkv", 12800, 2304, 768, 0), ("v.fc1", 12800, 3072, 768, 1), ("v.out", 12800, 768, 768, 3),
               ("v.fc2", 12800, 768, 3072, 3), ("t.fc2", 19712, 512, 2048, 3)]
-    variants = [int(x) for x in sys.argv[2:]] or [2, 3, 4, 5]
+    variants = [int(x) for x in sys.argv[2:]] or [2, 3, 4, 5, 6]
     g = torch.Generator().manual_seed(0)
     for name, M, N, K, mode in shapes:
         per = M * K * 2 + M * N * 4

@@ -28,8 +28,8 @@ for s in $SECTIONS; do
              done ;;
     trace)   echo "${TRACE_ARGS:-6 12800 768 3072 2;5 12800 768 3072 2;4 12800 768 3072 2;6 12800 768 768 2;6 19712 512 2048 2;6 19712 512 512 2;2 12800 2304 768 0;3 12800 3072 768 1;2 19712 1536 512 0;3 19712 2048 512 1}" | tr ';' '\n' | while read a; do
                timeout 120 python tools/gpu_diag.py gemmtrace $a >> gpurun_out/diag_gemmtrace.log 2>&1; done ;;
-    ablate)  for ab in 0 1 8 16 9 17 24 25 4; do echo "=== PLIPMI_GEMM_ABLATE=$ab (1: no K-loop fills, 8: no K-loop barriers, 16: no LDS fragment reads, 4: no epilogue)" >> gpurun_out/diag_ablate.log
-               PLIPMI_GEMM_ABLATE=$ab timeout 120 python tools/gpu_diag.py gemmtrace ${ABLATE_ARGS:-6 12800 768 3072 2} 2>&1 | grep -E "variant|prologue|main loop|epilogue|lifetime" >> gpurun_out/diag_ablate.log; done ;;
+    # (the K-loop ablation of profiles/r03_gemm_kloop.txt needs the hooks of commit ba1f4b8: they cost 4-9 % of the K loop's
+    #  cycles when compiled in, so the product kernels no longer carry them)
     pmcbench) rm -rf gpurun_out/pmc_bench_*
              for ov in 0 1; do for pass in "FETCH_SIZE" "WRITE_SIZE"; do
                (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d "$OLDPWD/gpurun_out/pmc_bench_${pass}_ov$ov" -o pmc -- python "$OLDPWD/bench.py" --steps 3 --warmup 1 --overlap $ov --no-cpu-baseline --no-profile --no-extras >> "$OLDPWD/gpurun_out/pmcbench.log" 2>&1)
