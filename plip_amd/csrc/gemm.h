@@ -30,10 +30,6 @@
 #include <type_traits>
 #include "common.h"
 
-#ifndef PLIPMI_ABLATE_HOOKS
-#define PLIPMI_ABLATE_HOOKS 2
-#endif
-
 namespace plipmi {
 
 // first-class vector (HIP's uint4 struct keeps staging arrays in scratch)
@@ -98,12 +94,6 @@ struct GemmParams {
   // test hook (plipmi_gemm_nt_traced): per workgroup 8 x u64 {start, prologue done, main loop done, epilogue
   // done, logical tile id, HW_ID, k tiles, 0}, s_memtime ticks.  nullptr on the product path.
   unsigned long long* trace = nullptr;
-  // test hook (plipmi_set_gemm_trace_ablate, traced launches only; results are wrong by construction):
-  // bit 0 = skip the global->LDS fills of the K loop, bit 1 = skip the MFMA block (two-stage tiles), bit 2 = skip the epilogue,
-  // bit 3 = skip the K loop's barriers, bit 4 = skip the K loop's LDS fragment reads
-  int ablate = 0;
-  // output stores write through the XCD's L2 (sc0 sc1) instead of leaving dirty lines for the end-of-kernel write-back
-  int store_wt = 0;
 };
 
 // LDS-DMA (global_load_lds_dwordx4): each lane's 16 bytes at `gsrc` land at
@@ -200,13 +190,14 @@ __device__ __forceinline__ void mma16(f32x16& acc, const u32x4& wfrag, const u32
   }
 }
 
-// 16-byte output store.  wt: write through the XCD's L2 (sc0 sc1) -- the line goes to the fabric now, while other
-// workgroups are still in their K loops, instead of staying dirty until the end-of-kernel write-back every launch
-// otherwise ends with (MI355X_MICROARCH.md, "boundary": + B / 6 TB/s for B dirty bytes).  The asm store ends with s_nop 1:
-// hipcc does not know the statement reads its data registers after issue (cdna_hip_programming.md 5.7 item 1).
-__device__ __forceinline__ void store16(void* ptr, const u32x4 v, bool wt) {
-  if (wt) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(ptr), "v"(v) : "memory");
-  else *reinterpret_cast<u32x4*>(ptr) = v;
+// 16-byte output store, written THROUGH the XCD's L2 (sc0 sc1): the line goes to the fabric now, while other workgroups
+// are still in their K loops, instead of staying dirty until the end-of-kernel write-back every launch otherwise ends with
+// (MI355X_MICROARCH.md, "boundary": + B / 6 TB/s for B dirty bytes): -0.5 ... -4 us per launch on the eight production
+// shapes against plain stores (profiles/r03_gemm_tiles.txt, measured while a process-wide switch existed: commit ba1f4b8;
+// as a run-time flag the choice itself cost 1 % of the two-stream step).  The asm store ends with s_nop 1: hipcc does not
+// know the statement reads its data registers after issue (cdna_hip_programming.md 5.7 item 1).
+__device__ __forceinline__ void store16(void* ptr, const u32x4 v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(ptr), "v"(v) : "memory");
 }
 
 // Epilogue split in a LOAD half (bias / residual / position rows; issued back to
@@ -301,8 +292,6 @@ void gemm_nt_kernel(const GemmParams p) {
   static_assert(PA == PA_MIN || (NT / 8) % 8 == 0, "partial last A pass: whole waves in or out");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // timing-experiment hooks (GemmParams::ablate): compiled into the kernels the macro selects
-  const int ablate_bits = (PLIPMI_ABLATE_HOOKS == 2 || (PLIPMI_ABLATE_HOOKS == 1 && NSTAGE == 2)) ? p.ablate : 0;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -489,21 +478,13 @@ void gemm_nt_kernel(const GemmParams p) {
     // last block are read too -- in-bounds LDS bytes nobody multiplies -- so the reads stay branch-free: skipping them behind a
     // wave-uniform branch measured 47.2 vs 44.6 us per launch of the residual GEMMs in the step.)
     u32x4 xf[2][MI], wf[2][NI];
-    const bool rd = !(ablate_bits & 16);
-    if (rd) {
 #pragma unroll
-      for (int i = 0; i < MI; ++i) xf[0][i] = *reinterpret_cast<const u32x4*>(sb + a_tile + i * 32 * 128 + foff[0]);
+    for (int i = 0; i < MI; ++i) xf[0][i] = *reinterpret_cast<const u32x4*>(sb + a_tile + i * 32 * 128 + foff[0]);
 #pragma unroll
-      for (int j = 0; j < NI; ++j) wf[0][j] = *reinterpret_cast<const u32x4*>(sb + w_tile + j * 32 * 128 + foff[0]);
-    } else {
-#pragma unroll
-      for (int i = 0; i < MI; ++i) { xf[0][i] = u32x4{1u, 2u, 3u, 4u}; xf[1][i] = u32x4{1u, 2u, 3u, 4u}; }
-#pragma unroll
-      for (int j = 0; j < NI; ++j) { wf[0][j] = u32x4{1u, 2u, 3u, 4u}; wf[1][j] = u32x4{1u, 2u, 3u, 4u}; }
-    }
+    for (int j = 0; j < NI; ++j) wf[0][j] = *reinterpret_cast<const u32x4*>(sb + w_tile + j * 32 * 128 + foff[0]);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      if (ks < 3 && rd) {
+      if (ks < 3) {
 #pragma unroll
         for (int i = 0; i < MI; ++i)
           xf[(ks + 1) & 1][i] = *reinterpret_cast<const u32x4*>(sb + a_tile + i * 32 * 128 + foff[ks + 1]);
@@ -558,9 +539,7 @@ void gemm_nt_kernel(const GemmParams p) {
     // requests of this wave outstanding (vmcnt retires in order): tile kt+1 has landed, tile kt+2 may still fly.
     constexpr int kLeave = PA_MIN + PW;
     u32x4 xf[2][MI], wf[2][NI];
-    const bool rd = !(ablate_bits & 16);
     auto read_frags = [&](int stage, int ks, int b) {
-      if (!rd) return;
       const char* sb = smem + stage * STAGE;
 #pragma unroll
       for (int i = 0; i < MI; ++i) xf[b][i] = *reinterpret_cast<const u32x4*>(sb + a_tile + i * 32 * 128 + foff[ks]);
@@ -575,15 +554,6 @@ void gemm_nt_kernel(const GemmParams p) {
         for (int j = 0; j < NI; ++j) mma16<T>(acc[i][j], wf[b][j], xf[b][i]);
       }
     };
-    if (!rd) {
-#pragma unroll
-      for (int b = 0; b < 2; ++b) {
-#pragma unroll
-        for (int i = 0; i < MI; ++i) xf[b][i] = u32x4{1u, 2u, 3u, 4u};
-#pragma unroll
-        for (int j = 0; j < NI; ++j) wf[b][j] = u32x4{1u, 2u, 3u, 4u};
-      }
-    }
     stage_issue(0);
     if (KT > 1) stage_issue(1);
     stage_ln_rows();
@@ -594,7 +564,7 @@ void gemm_nt_kernel(const GemmParams p) {
     read_frags(0, 0, 0);
     int cur = 0, nxt = 1, nxt2 = 2;  // stages of tiles kt, kt+1, kt+2
     for (int kt = 0; kt < KT - 1; ++kt) {
-      const bool fetch = kt + 2 < KT && !(ablate_bits & 1);
+      const bool fetch = kt + 2 < KT;
       if constexpr (!kSpread) { if (fetch) stage_issue(nxt2); }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
@@ -607,7 +577,7 @@ void gemm_nt_kernel(const GemmParams p) {
           if (fetch) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kLeave) : "memory");
           else wait_vm0();
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          if (!(ablate_bits & 8)) __syncthreads();
+          __syncthreads();
           read_frags(nxt, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -637,18 +607,18 @@ void gemm_nt_kernel(const GemmParams p) {
     for (int kt = 0; kt < KT - 1; ++kt) {
       const int cur = kt & 1;
       if constexpr (!kSpread) {
-        if (!(ablate_bits & 1)) stage_issue(cur ^ 1);
+        stage_issue(cur ^ 1);
       }
-      if (!(ablate_bits & 2)) compute(cur, (ablate_bits & 1) ? -1 : (cur ^ 1));
+      compute(cur, cur ^ 1);
       wait_vm0();
-      if (!(ablate_bits & 8)) __syncthreads();
+      __syncthreads();
     }
     if constexpr (kRowOperand) {  // the residual / position rows of the first 32-row block travel during the last K step
       load_block(0, add[0]);
       add_ready = true;
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (!(ablate_bits & 2)) compute((KT - 1) & 1, -1);
+    compute((KT - 1) & 1, -1);
   }
   if (trace && tid == 0) trace[2] = __builtin_amdgcn_s_memtime();
 
@@ -664,8 +634,6 @@ void gemm_nt_kernel(const GemmParams p) {
   static_assert(WM * WN * SLAB_BYTES <= NSTAGE * STAGE, "epilogue slabs must fit in the staging buffers");
   static_assert(NI % 2 == 0, "epilogue handles two 32-column MFMA tiles per slab");
   __syncthreads();  // every wave is done reading the last K tile: the staging LDS can be reused
-  if (ablate_bits & 4) return;
-  const bool wt = p.store_wt != 0;
   char* slab = smem + wave * SLAB_BYTES;
   if constexpr (sizeof(T) == 2 && epi_is_colwise(EPI)) {
     // 16-bit outputs whose epilogue is column-wise (bias, QuickGELU): finish the arithmetic in the ACCUMULATOR layout
@@ -725,9 +693,8 @@ void gemm_nt_kernel(const GemmParams p) {
         for (int it = 0; it < 4; ++it) {
           int m = m0 + wm * TM + i * 32 + it * 8 + hr_row;
           const bool in_range = m < Mrt;
-          if (ablate_bits & 32) m &= 255;  // timeline experiment: every tile stores to the same 256 rows (L2-resident)
           if (in_range)
-            store16(reinterpret_cast<OutT*>(p.C) + (size_t)m * p.ldc + n0 + wn * TN + jp * 64 + hr_chunk * 8, o[it], wt);
+            store16(reinterpret_cast<OutT*>(p.C) + (size_t)m * p.ldc + n0 + wn * TN + jp * 64 + hr_chunk * 8, o[it]);
         }
         __builtin_amdgcn_wave_barrier();
       }
@@ -808,8 +775,8 @@ void gemm_nt_kernel(const GemmParams p) {
               lo4[e] = la | (lb << 16);
             }
             const size_t off = (size_t)m * p.ldc + nn;
-            store16(reinterpret_cast<unsigned short*>(p.xb_out) + off, ho, wt);
-            store16(reinterpret_cast<unsigned short*>(p.lo_io) + off, lo4, wt);
+            store16(reinterpret_cast<unsigned short*>(p.xb_out) + off, ho);
+            store16(reinterpret_cast<unsigned short*>(p.lo_io) + off, lo4);
             if ((lane & 7) == 0)
               *reinterpret_cast<float2*>(p.st_out + ((size_t)m * (p.N / kLnSlice) + (n0 + wn * TN + jp * 64) / kLnSlice) * 2) =
                   make_float2(ssum, m2);
@@ -827,7 +794,6 @@ void gemm_nt_kernel(const GemmParams p) {
       for (int it = 0; it < 8; ++it) {
         int m = m0 + wm * TM + i * 32 + it * 4 + rd_row;
         const bool in_range = m < Mrt;
-        if (ablate_bits & 32) m &= 255;  // timeline experiment: every tile stores to the same 256 rows (L2-resident)
         if constexpr (EPI == EPI_RESID_EMIT) {
           // the updated residual row piece (4 columns per lane, 16 lanes = one 64-column slice of one row): fp32 in
           // place, its 16-bit copy for the next GEMM's A operand, and the slice's LayerNorm partials {sum, centred M2}
@@ -897,7 +863,5 @@ bool gemm_variant_is_built(int dtype, int variant);
 bool gemm_skinny_supports(int epi, int M, int N, int K);
 int gemm_launch_skinny(int dtype, int epi, const GemmParams& p, hipStream_t stream, const char** kernel_name);
 void gemm_set_default_override(int variant);  // tests / A-B runs (process-wide hook, not a product knob)
-void gemm_set_store_wt(int on);               // experiment hook: write-through epilogue stores (process-wide)
-void gemm_set_trace_ablate(int bits);         // experiment hook: GemmParams::ablate of traced launches (process-wide)
 
 }  // namespace plipmi
