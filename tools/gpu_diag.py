@@ -399,15 +399,6 @@ def sec_gemmtrace():
     print("  lifetime     :", qc(life), "  wall:", qu(real_life_us))
     print("  end          :", qu(end_us))
     print("  workgroups per XCC:", np.bincount(xcc, minlength=8).tolist())
-    return
-    m0 = xcc == 0
-    first_end = end[m0].min()
-    print(f"  XCC0: {m0.sum()} workgroups, {(start[m0] < first_end).sum()} started before its first one ended")
-    idx = np.nonzero(m0)[0]
-    order = idx[np.argsort(start[idx])]
-    for i in list(order[:4]) + list(order[len(order) // 2: len(order) // 2 + 3]) + list(order[-3:]):
-        print(f"    wg {i:4d} tile {t[i, 4]:4d} hw_id {t[i, 5] & 0xffffffff:08x}: start {start[i] / tick_us:7.2f} "
-              f"pro {pro[i] / tick_us:6.2f} loop {loop[i] / tick_us:7.2f} epi {epi_t[i] / tick_us:6.2f} end {end[i] / tick_us:7.2f} us")
 
 
 def _step_inputs(B=256):
