@@ -37,6 +37,10 @@ def _random_case(seed):
         opts["pooled_last_block"] = False
     if rs.rand() < 0.3:
         opts["graph_batch"] = 0
+    if rs.rand() < 0.3:
+        opts["text_f16"] = True                                  # bf16 engine only
+    if rs.rand() < 0.4 and "ln_fold" not in opts and "pooled_last_block" not in opts:
+        opts["pack_captions"] = True                             # 16-bit engines with the pooled last block
     return cfg, batch, opts, int(rs.randint(0, 1 << 30))
 
 
@@ -58,6 +62,8 @@ def test_random_architecture_matches_the_oracle(seed):
     scale = np.exp(np.float64(sd["logit_scale"]))
     for dtype in ("f32", "bf16", "f16"):
         kw = dict(opts) if dtype != "f32" else {k: v for k, v in opts.items() if k == "graph_batch"}
+        if dtype != "bf16":
+            kw.pop("text_f16", None)
         model = PlipModel(cfg, sd, dtype=dtype, max_batch=B, **kw)
         try:
             for rep in range(3):      # call 1 eager, call 2 captures a hipGraph (small batches), call 3 replays it
