@@ -43,8 +43,11 @@ __device__ __forceinline__ typename half_traits<H>::x8 vtr_fragment(const char* 
 
 // One (sample, head) problem per workgroup.  (Two problems per workgroup with a register prefetch of the next K / V rows
 // was measured slower in round 2 -- registers: three waves per SIMD instead of six to eight -- and is gone.)
+// (amdgpu_waves_per_eu(4, 4): with the default heuristics hipcc parks the MFMA accumulators in AGPRs and pays 96 v_accvgpr
+// copies per wave to get the scores and the outputs back into VGPRs; told it may use 128 registers it needs 77 (S <= 64) / 93
+// (S <= 96) plain VGPRs, no AGPRs, 10-12 % fewer VALU instructions, and one more wave per SIMD than before.)
 template <typename HT, int KT>  // 32-key tiles: S <= 32*KT
-__global__ __launch_bounds__(64 * KT) void attention_mfma_kernel(const HT* __restrict__ qkv, HT* __restrict__ out, int S, int H,
+__global__ __launch_bounds__(64 * KT) __attribute__((amdgpu_waves_per_eu(4, 4))) void attention_mfma_kernel(const HT* __restrict__ qkv, HT* __restrict__ out, int S, int H,
                                                                  int causal, const int64_t* __restrict__ key_mask,
                                                                  const int* __restrict__ cu /* packed rows: sample b owns rows
                                                                  cu[b] .. cu[b+1]-1 of qkv / out (nullptr: b*S .. b*S+S-1) */) {
@@ -87,9 +90,10 @@ __global__ __launch_bounds__(64 * KT) void attention_mfma_kernel(const HT* __res
 #pragma unroll
     for (int i = 0; i < NP; ++i) {   // this thread's 16-byte pieces of the problem's K and V rows -> registers
       const int e = tid + i * NT, row = e >> 3, c = e & 7;
-      const HT* src = base + (size_t)(row < Sb ? row : Sb - 1) * ld + c * 8;
-      kreg[i] = *reinterpret_cast<const u32x4*>(src + D);
-      vreg[i] = *reinterpret_cast<const u32x4*>(src + 2 * D);
+      // wave-uniform base + 32-bit lane offset (a problem spans < 4 GiB): scalar-base global loads, no 64-bit lane arithmetic
+      const unsigned off = ((unsigned)(row < Sb ? row : Sb - 1) * (unsigned)ld + (unsigned)(c * 8)) * (unsigned)sizeof(HT);
+      kreg[i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(base + D) + off);
+      vreg[i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(base + 2 * D) + off);
     }
     // key validity bits (sequence padding and the tokenizer's attention_mask): key = tid
     {
@@ -108,15 +112,21 @@ __global__ __launch_bounds__(64 * KT) void attention_mfma_kernel(const HT* __res
     // these rows, so an LDS image of Q would only cost residency (8-16 KB per workgroup = a third of its LDS).
     u32x4 qf[4];
     {
-      const HT* qrow = base + (size_t)(qidx < Sb ? qidx : Sb - 1) * ld;
+      const unsigned qoff = ((unsigned)(qidx < Sb ? qidx : Sb - 1) * (unsigned)ld + (unsigned)(hi * 8)) * (unsigned)sizeof(HT);
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const u32x4*>(qrow + (ks * 2 + hi) * 8);
+      for (int ks = 0; ks < 4; ++ks)
+        qf[ks] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(base) + qoff + ks * 16 * sizeof(HT));
     }
     __syncthreads();
 
     // scores^T tiles
     f32x16 sc[KT];
+    // key validity words as scalars (wave-uniform): 32 keys per tile
     const unsigned long long m0 = mk[0], m1 = mk[1];
+    const unsigned vw[4] = {(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)m0),
+                            (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(m0 >> 32)),
+                            (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)m1),
+                            (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(m1 >> 32))};
     float rmax = -INFINITY;
 #pragma unroll
     for (int t = 0; t < KT; ++t) {
@@ -130,12 +140,21 @@ __global__ __launch_bounds__(64 * KT) void attention_mfma_kernel(const HT* __res
           sc[t] = half_traits<HT>::mfma32(__builtin_bit_cast(X8, kf), __builtin_bit_cast(X8, qf[ks]), sc[t]);
         }
       }
+      // The keys this lane may use in the tile, as ONE 32-bit word: validity (padding / attention_mask) AND, under the causal
+      // mask, keys 32t + j <= query  <=>  j <= d = query - 32t.  Slot r of the accumulator holds key 32t + 4hi + (r&3) + 8(r>>2):
+      // after a shift by 4hi its bit sits at a compile-time position, so masking a score is a 1-bit field extract (0 / -1),
+      // an AND that turns it into 0.0 / -inf, and an add -- no compares, no 64-bit shifts, no branches.  (The two-operation form,
+      // a bit select against -inf, was miscompiled by this hipcc: its v_bitop3_b32 folding mixed the elements' masks.)
+      unsigned bits = live ? vw[t] : 0u;
+      if (causal) {
+        const int d = qidx - 32 * t;
+        bits &= d < 0 ? 0u : (d >= 31 ? 0xffffffffu : (2u << d) - 1u);
+      }
+      const unsigned nbits = ~(bits >> (4 * hi));        // 1 = masked
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int key = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        const unsigned long long word = key < 64 ? m0 : m1;
-        const bool ok = live && ((word >> (key & 63)) & 1ull) && (!causal || key <= qidx);
-        sc[t][r] = ok ? sc[t][r] : -INFINITY;
+        const unsigned m = (unsigned)__builtin_amdgcn_sbfe((int)nbits, (r & 3) + 8 * (r >> 2), 1);   // masked ? 0xffffffff : 0
+        sc[t][r] += __builtin_bit_cast(float, m & 0xff800000u);                                       // + (-inf) or + 0
         rmax = fmaxf(rmax, sc[t][r]);
       }
     }
@@ -143,12 +162,13 @@ __global__ __launch_bounds__(64 * KT) void attention_mfma_kernel(const HT* __res
     if (active) {
       rmax = fmaxf(rmax, __shfl_xor(rmax, 32, 64));
       const float m_use = (rmax == -INFINITY) ? 0.f : rmax;
+      const float m2 = m_use * 1.4426950408889634f;       // exp(x - m) = 2^(x log2 e - m log2 e): one FMA + v_exp_f32 per score
       float rsum = 0.f;
 #pragma unroll
       for (int t = 0; t < KT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          sc[t][r] = __expf(sc[t][r] - m_use);
+          sc[t][r] = __builtin_amdgcn_exp2f(fmaf(sc[t][r], 1.4426950408889634f, -m2));
           rsum += sc[t][r];
         }
       rsum += __shfl_xor(rsum, 32, 64);

@@ -258,7 +258,7 @@ struct EpilogueOp {
 //           older tile has landed, the newest may still fly).  Needs 3 * (BM + BN) * 128 B of the 160 KB.  The iteration's
 //           barrier sits IN FRONT of its last K step's MFMAs: behind it a wave first requests the next tile's first
 //           fragments, then issues the MFMA group it still holds in registers -- the LDS round trip every wave starts a tile
-//           with runs under matrix work instead of in front of it (2105 -> 1793 cycles per K tile, profiles/r03_gemm_kloop.txt).
+//           with runs under matrix work instead of in front of it (1893 -> 1768 cycles per K tile).
 //           (With two stages the same move buys 0-2 % per kernel and nothing on the step: there the iteration waits for the fill --
 //           profiles/r02_experiments_not_shipped.txt item 6, re-measured in round 3.)
 // ADDR 0: 64-bit per-lane global addresses (any operand size); 1: buffer resource + 32-bit lane offset (< 4 GiB).
