@@ -34,7 +34,7 @@ PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}   # dense MFMA peaks
 HBM_PEAK_GBS = 8000.0                                          # HBM3E 8 TB/s, same table
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -49,7 +49,11 @@ def parse():
                     help="skip the side measurements (f16 engine, dense last block, caption packing, larger batches, "
                          "ViT-L/14@336 share, fp32 engine)")
     ap.add_argument("--overlap", type=int, default=1, help="1: text tower on a second HIP stream (default), 0: one stream")
-    return ap.parse_args()
+    # "gloo": host-only REHEARSAL of the multi-rank control flow (rendezvous, fenced windows, max over ranks, rank-0-only
+    # printing, teardown) for tests/test_bench_ranks.py, which supplies a stub engine through main(model_factory=...).
+    # It measures nothing: the line it prints says so, and without a factory the flag is refused.
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help=argparse.SUPPRESS)
+    return ap.parse_args(argv)
 
 
 def load_pmc_traffic(kernel_name):
@@ -154,7 +158,7 @@ def cpu_baseline(cfg, sd, seconds):
 
 
 def executed_gflop_per_pair(cfg, dtype):
-    """`algorithmic_tflops` prices a pair at SURVEY.md section 8d's dense figure (14.777 GFLOP for ViT-B/32: every token
+    """`dense_equivalent_tflops` prices a pair at SURVEY.md section 8d's dense figure (14.777 GFLOP for ViT-B/32: every token
     through every Linear).  The 16-bit engines run the LAST block's out_proj / fc1 / fc2 only on the row that is pooled
     afterwards (CLS / EOS) -- the other rows of that block cannot reach get_image_features / get_text_features -- so they
     execute slightly fewer FLOPs than that; `executed_tflops` and every kernel roofline use executed FLOPs."""
@@ -202,18 +206,21 @@ def logits_error_vs_hf_golden(model, cfg, sd, px, ids, mask, B, arch, fixture="v
 
 
 def timed_steps(step, n, dev, warmup=0):
+    sync = (lambda: torch.cuda.synchronize(dev)) if dev.type == "cuda" else (lambda: None)
     for _ in range(warmup):
         step()
-    torch.cuda.synchronize(dev)
+    sync()
     t0 = time.perf_counter()
     for _ in range(n):
         out = step()
-    torch.cuda.synchronize(dev)
+    sync()
     return (time.perf_counter() - t0) / n, out
 
 
-def main():
-    args = parse()
+def main(argv=None, model_factory=None):
+    """``model_factory(cfg, sd, device=, dtype=, max_batch=)``: tests only (with --backend gloo); the product path builds
+    ``plip_amd.model.PlipModel`` and fails without an MI355X."""
+    args = parse(argv)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -223,14 +230,27 @@ def main():
                              f"--nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 --master-port 29500 "
                              f"bench.py --gpus {args.gpus} ...")
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
-    if not torch.cuda.is_available():
+    rehearsal = args.backend == "gloo"
+    if rehearsal and model_factory is None:
+        raise SystemExit("--backend gloo is the tests' host-only rehearsal of the multi-rank control flow (it needs a stub "
+                         "engine from main(model_factory=...)); the bench itself runs on MI355X GPUs over RCCL")
+    if not rehearsal and model_factory is not None:
+        raise SystemExit("a model factory is accepted with --backend gloo only")
+    if not rehearsal and not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (ROCm) GPU: torch.cuda.is_available() is False; there is no CPU path")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
+    if rehearsal:
+        dev = torch.device("cpu")
+        args.no_profile = args.no_extras = args.no_cpu_baseline = True
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)       # "nccl" is RCCL on ROCm
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)       # "nccl" is RCCL on ROCm
 
     from plip_amd import weights as W
     from plip_amd.config import get_config
@@ -240,7 +260,7 @@ def main():
     cfg = get_config(args.arch)
     B = args.batch
     sd = W.synthetic_state_dict(cfg, seed=0)                   # same weights on every rank
-    model = PlipModel(cfg, sd, device=dev, dtype=args.dtype, max_batch=B)
+    model = (model_factory or PlipModel)(cfg, sd, device=dev, dtype=args.dtype, max_batch=B)
     px = torch.from_numpy(W.synthetic_pixels(cfg, B, seed=1000 + rank)).to(dev)
     ids_np, mask_np = W.synthetic_ids(cfg, B, seed=2000 + rank)
     ids, mask = torch.from_numpy(ids_np).to(dev), torch.from_numpy(mask_np).to(dev)
@@ -248,11 +268,13 @@ def main():
     def step():
         return sharded_pair_logits(model, px, ids, mask, overlap=bool(args.overlap), equal_shards=True)
 
+    dev_sync = (lambda: torch.cuda.synchronize(dev)) if dev.type == "cuda" else (lambda: None)
+
     def fence():
-        torch.cuda.synchronize(dev)
+        dev_sync()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize(dev)
+        dev_sync()
 
     def window():
         """exactly --steps steps between two fences; max over ranks"""
@@ -372,7 +394,8 @@ def main():
         "metric": "image+text pairs embedded/sec at 224px bs=256",
         "value": round(value, 1), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "vs_baseline": None, "dtype": args.dtype,
+        "data": "synthetic" if not rehearsal else "synthetic; gloo REHEARSAL with a stub engine -- control flow only, not a measurement",
         "config": {"workload": f"full dual encoder (image tower + text tower + L2 normalise + logits_per_image), "
                                f"{args.arch}, bs={B} pairs per GPU, {cfg.image_size}px, {cfg.context_length} tokens, "
                                f"{args.dtype} MFMA / fp32 accumulate (BASELINE.json configs[2])",
@@ -382,8 +405,10 @@ def main():
         "windows": {"ms_per_step": [round(w, 3) for w in win], "median": round(float(np.median(win)), 3), "min": round(min(win), 3),
                     "note": "three back-to-back windows of --steps steps each; `value` / `ms_per_step` are the FIRST (the contract's "
                             "exactly-K-steps measurement), the others show the spread"},
-        "algorithmic_tflops": round(value * cfg.pair_flops() / 1e12, 2),
+        # FLOPs the kernels actually execute (pooled last block) -- THE TFLOP/s figure of this line; and the same rate priced at
+        # SURVEY.md section 8d's dense 14.777 GFLOP per pair (work the engine proves unnecessary and skips), for comparison only
         "executed_tflops": round(value * ex["executed"] * 1e9 / 1e12, 2),
+        "dense_equivalent_tflops": round(value * cfg.pair_flops() / 1e12, 2),
         "executed_gflop_per_pair": ex,
         "roofline": roofline,
         "roofline_two_stream_events": roofline_2s,
@@ -500,8 +525,8 @@ def main():
                 "workload": "ViT-L/14@336 dual encoder, 64 pairs (one GPU's share of configs[4]'s bs=512 on 8 GPUs), same step; parity "
                             "of this architecture: tests/test_gpu_configs.py against HF (tests/golden/vitl14_336_b2.npz)",
                 "pairs_per_s": round(64 / dtl, 1), "ms_per_step": round(dtl * 1e3, 3),
-                "algorithmic_tflops": round(64 * cl.pair_flops() / dtl / 1e12, 1),
-                "frac_of_mfma_peak": round(64 * cl.pair_flops() / dtl / 1e12 / PEAK_TFLOPS[args.dtype], 4)}
+                "dense_equivalent_tflops": round(64 * cl.pair_flops() / dtl / 1e12, 1),
+                "dense_equivalent_frac_of_mfma_peak": round(64 * cl.pair_flops() / dtl / 1e12 / PEAK_TFLOPS[args.dtype], 4)}
             ml.engine.close()
             del ml, pxl
         except Exception as e:  # pragma: no cover

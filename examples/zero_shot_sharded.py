@@ -25,21 +25,37 @@ from plip_amd.dist import all_gather_rows, shard_bounds  # noqa: E402
 from plip_amd.model import PlipModel  # noqa: E402
 
 
-def main():
+def main(argv=None, model_factory=None):
+    """``model_factory`` + ``--backend gloo``: the tests' host-only rehearsal of the multi-rank control flow with a stub
+    engine (tests/test_bench_ranks.py); the example itself runs on MI355X GPUs over RCCL."""
     ap = argparse.ArgumentParser()
     ap.add_argument("--images", type=int, default=4096)
     ap.add_argument("--classes", type=int, default=10)
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--checkpoint", default=None, help="local HF dir or OpenAI .pt; default: synthetic weights")
-    args = ap.parse_args()
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help=argparse.SUPPRESS)
+    args = ap.parse_args(argv)
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    rehearsal = args.backend == "gloo"
+    if rehearsal != (model_factory is not None):
+        raise SystemExit("--backend gloo and a stub model factory go together (tests only)")
+    if rehearsal:
+        dev = torch.device("cpu")
+    else:
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+    sync = (lambda: torch.cuda.synchronize()) if dev.type == "cuda" else (lambda: None)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     cfg = get_config("ViT-B/32")
-    if args.checkpoint:
+    if model_factory is not None:
+        model = model_factory(cfg, None, device=dev, dtype="bf16", max_batch=args.batch)
+    elif args.checkpoint:
         model = PlipModel.from_pretrained(args.checkpoint, device=dev, max_batch=args.batch)
     else:
         model = PlipModel(cfg, W.synthetic_state_dict(cfg, 0), device=dev, max_batch=args.batch)
@@ -48,7 +64,7 @@ def main():
     class_emb = eng.encode_text(torch.from_numpy(prompts), None, normalize=True)   # [C,512], replicated on every rank
     lo, hi = shard_bounds(args.images, rank, world)
     preds = []
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     g = torch.Generator(device="cpu").manual_seed(1000 + rank)
     for s in range(lo, hi, args.batch):
@@ -59,7 +75,7 @@ def main():
         preds.append(am)
     local_pred = torch.cat(preds) if preds else torch.empty(0, dtype=torch.int32, device=dev)
     all_pred = all_gather_rows(local_pred)                              # only 4 bytes per image cross xGMI
-    torch.cuda.synchronize()
+    sync()
     dt = time.perf_counter() - t0
     if rank == 0:
         hist = torch.bincount(all_pred.long(), minlength=args.classes).tolist()

@@ -80,7 +80,8 @@ enum {
   PLIPMI_ERR_INVALID = 1,   /* bad argument / unsupported shape */
   PLIPMI_ERR_HIP = 2,       /* a HIP runtime call failed */
   PLIPMI_ERR_NODEVICE = 3,  /* no gfx950 device visible */
-  PLIPMI_ERR_NOMEM = 4
+  PLIPMI_ERR_NOMEM = 4,
+  PLIPMI_ERR_TOKEN_ID = 5   /* an EARLIER plipmi_encode_text on the handle saw a token id outside the vocabulary (below) */
 };
 
 typedef struct plipmi_engine* plipmi_handle;
@@ -170,8 +171,11 @@ int plipmi_encode_text(plipmi_handle h, const int64_t* ids, const int64_t* atten
 /* Token ids outside [0, vocab_size).  The reference's embedding lookup raises on them (plip.py:68 -> nn.Embedding; on a
  * GPU as a device-side assert that surfaces at the next synchronisation).  plipmi_encode_text only enqueues work, so the
  * ids -- device memory -- are checked BY the embedding kernel: it clamps the lookup (no wild read) and raises a flag in
- * host-visible memory.  The flag is reported, once, by the next plipmi_encode_* call on the handle and by this function
- * (call it after synchronising the stream; PLIPMI_ERR_INVALID = the embeddings of an earlier encode_text are invalid). */
+ * host-visible memory.  The flag is reported, once, as PLIPMI_ERR_TOKEN_ID (= the embeddings of an earlier encode_text
+ * are invalid) by this function -- call it after synchronising the stream -- and by the next plipmi_encode_text on the
+ * handle, which then enqueues nothing: a caller that feeds a long id matrix in chunks may therefore see the error from a
+ * LATER chunk's call, with the earlier chunks' (valid and invalid) rows already written.  The image-side entry points and
+ * the heads never report it: a bad caption does not fail an unrelated plipmi_encode_image. */
 int plipmi_check_async(plipmi_handle h);
 
 /* Small-batch launch amortisation.  An encode call of at most `max_batch` samples (default min(32, cfg.max_batch), see

@@ -115,6 +115,11 @@ class PlipmiError(RuntimeError):
     pass
 
 
+ERR_TOKEN_ID = 5     # include/plipmi.h PLIPMI_ERR_TOKEN_ID
+
+
 def check(rc: int, what: str) -> None:
+    if rc == ERR_TOKEN_ID:      # what the reference's embedding lookup raises on an out-of-range id (plip.py:68)
+        raise IndexError(f"{what}: {last_error()}")
     if rc != 0:
         raise PlipmiError(f"{what} failed (code {rc}): {last_error()}")

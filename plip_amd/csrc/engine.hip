@@ -450,14 +450,15 @@ int run_head(plipmi_engine* e, Tower& t, const float* x, int S, const int64_t* i
 int check_async(plipmi_engine* e) {
   if (e->bad_id && *reinterpret_cast<volatile int*>(e->bad_id) != 0) {
     *reinterpret_cast<volatile int*>(e->bad_id) = 0;
-    return fail(PLIPMI_ERR_INVALID, "an earlier plipmi_encode_text on this handle was given a token id outside [0, %d) "
+    return fail(PLIPMI_ERR_TOKEN_ID, "an earlier plipmi_encode_text on this handle was given a token id outside [0, %d) "
                 "(the reference's embedding lookup raises there, plip.py:68); its embeddings are invalid", e->cfg.vocab_size);
   }
   return PLIPMI_OK;
 }
+// (the sticky token-id flag is reported by plipmi_encode_text and plipmi_check_async only: a bad caption must not fail an
+//  unrelated encode_image, and whether it did used to depend on whether the embedding kernel had already run)
 int check_batch(plipmi_engine* e, int B) {
   if (!e) return fail(PLIPMI_ERR_INVALID, "null handle");
-  RUN(check_async(e));
   if (B < 0 || B > e->cfg.max_batch)
     return fail(PLIPMI_ERR_INVALID, "batch %d outside [0, max_batch=%d]", B, e->cfg.max_batch);
   return PLIPMI_OK;
@@ -668,6 +669,7 @@ int plipmi_encode_image_u8(plipmi_handle h, const uint8_t* tiles, int B, float* 
 int plipmi_encode_text(plipmi_handle h, const int64_t* ids, const int64_t* attention_mask, int B, int eos_token_id,
                        float* out, int normalize, void* stream) {
   RUN(check_batch(h, B));
+  RUN(check_async(h));
   if (B == 0) return PLIPMI_OK;
   if (!ids || !out) return fail(PLIPMI_ERR_INVALID, "null ids/out");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);

@@ -263,6 +263,20 @@ struct EpilogueOp {
 //           profiles/r02_experiments_not_shipped.txt item 6, re-measured in round 3.)
 // ADDR 0: 64-bit per-lane global addresses (any operand size); 1: buffer resource + 32-bit lane offset (< 4 GiB).
 // waves per SIMD the kernel is built for: 2 (LDS caps residency there, so let the allocator use 256 VGPRs)
+// index sets of the staged fill: [p0, p1) without [g0, g1)
+constexpr int count_outside(int p0, int p1, int g0, int g1) {
+  int c = 0;
+  for (int i = p0; i < p1; ++i) c += (i >= g0 && i < g1) ? 0 : 1;
+  return c;
+}
+constexpr int nth_outside(int p0, int p1, int g0, int g1, int k) {
+  for (int i = p0; i < p1; ++i) {
+    if (i >= g0 && i < g1) continue;
+    if (k == 0) return i;
+    --k;
+  }
+  return p0;
+}
 template <typename T, int BM, int BN, int WM, int WN, int EPI, int SCHED = 0, int ADDR = 0, int NSTAGE = 2>
 __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void gemm_nt_kernel(const GemmParams p) {
@@ -275,9 +289,16 @@ void gemm_nt_kernel(const GemmParams p) {
   constexpr int ELEMS16 = 16 / sizeof(T);  // elements per 16-byte chunk
   using OutT = std::conditional_t<sizeof(T) == 4, float, T>;
   static_assert(!(epi_is_ln(EPI) || epi_emits_stats(EPI)) || sizeof(T) == 2, "LayerNorm folding is a 16-bit-engine form");
-  static_assert(SCHED == 0 || SCHED == 1 || SCHED == 5 || SCHED == 6, "schedules: 0, 1, 5 (fill2), 6 (fill3)");
+  static_assert(SCHED == 0 || SCHED == 1 || SCHED == 5 || SCHED == 6 || SCHED == 7 || SCHED == 9,
+                "schedules: 0, 1, 5 (fill2), 6 (fill3), 7 / 9 (hand-placed, fill3 / fill2)");
   static_assert(NSTAGE == 2 || NSTAGE == 3, "two LDS stages or a ring of three");
-  constexpr bool kSpread = SCHED == 5 || SCHED == 6;
+  // 7 / 9: the K step is ONE hand-placed stream -- MFMA, fragment read of the next step, MFMA, read ... -- pinned with a
+  // scheduling fence per slot, so a wave keeps the matrix pipe fed out of its own stream whatever its SIMD partner does
+  // (the burst form idles the pipe whenever both waves of a SIMD are in their read bursts at once).  The fill travels in
+  // batches behind the reads of the first three (7) / two (9) steps.  Measured (profiles/r04_gemm_placed.txt): ring
+  // 1768 -> 1648 cycles per K tile, 256x256 2727 -> 2700; kernels -0.5 ... -2 % -- the clock gives most of it back.
+  constexpr bool kPlaced = SCHED >= 7;
+  constexpr bool kSpread = SCHED >= 5;
   static_assert(!kSpread || ADDR == 1, "the spread fill batches buffer-form requests");
   constexpr int BK = 8 * ELEMS16;          // 128-byte rows
   constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, STAGE = A_BYTES + W_BYTES;
@@ -370,10 +391,12 @@ void gemm_nt_kernel(const GemmParams p) {
   };
   // the same fill cut in parts, one per K step of the MFMA block (SCHED 5 / 6: packed into the first 2 / 3 K steps, so the
   // last request has most of the iteration -- not a quarter of it -- to land before the end-of-iteration wait)
-  constexpr int kFillParts = SCHED == 5 ? 2 : 3;
+  constexpr int kFillParts = (SCHED == 5 || SCHED == 9) ? 2 : 3;
   auto stage_issue_part = [&](int buf, int part) {
     const unsigned base = lds0 + buf * STAGE + wave * 1024;
-    if constexpr (ADDR == 1 && PA == PA_MIN) {
+    if constexpr (kPlaced) {
+      return;   // the hand-placed schedules issue through fill_part_placed / issue_piece below
+    } else if constexpr (ADDR == 1 && PA == PA_MIN) {
       constexpr int PER = (PA + PW + kFillParts - 1) / kFillParts;
       // piece idx of the tile: resource, lane offset and (compile-time) LDS offset
       auto RS = [&](int idx) -> const i32x4& { return idx < PA ? rs_a : rs_w; };
@@ -417,6 +440,47 @@ void gemm_nt_kernel(const GemmParams p) {
       }
       return;
     }
+  };
+
+  // Hand-placed schedules (SCHED 7 / 9): the tile's PA + PW requests are dealt to the first kParts K steps, PER per step, one
+  // statement of up to four requests (A pieces that not every wave owns go singly behind their wave-uniform test).
+  constexpr int kParts = kFillParts;
+  constexpr int PER = (PA + PW + kParts - 1) / kParts;
+  static_assert(!kPlaced || ADDR == 1, "hand-placed schedules use the buffer-form LDS-DMA");
+  auto piece_lds = [](int idx) constexpr { return idx < PA ? idx * NT * 16 : A_BYTES + (idx - PA) * NT * 16; };
+  auto fill_batched = [&](int buf, auto part_c) __attribute__((always_inline)) {
+    constexpr int part = decltype(part_c)::value;
+    constexpr int P0 = part * PER, P1 = (P0 + PER < PA + PW) ? P0 + PER : PA + PW;
+    if constexpr (ADDR == 1 && P0 < P1) {
+      const unsigned base = lds0 + buf * STAGE + wave * 1024;
+      constexpr int G0 = PA_MIN, G1 = PA;   // [G0, G1): A pieces only the first waves own
+#pragma unroll
+      for (int idx = (P0 > G0 ? P0 : G0); idx < (P1 < G1 ? P1 : G1); ++idx)
+        if (a_piece(idx)) glds16_buf(rs_a, a_off[idx < PA ? idx : 0], koff, base + idx * NT * 16);
+      constexpr int NU = count_outside(P0, P1, G0, G1);
+      auto RS = [&](int idx) -> const i32x4& { return idx < PA ? rs_a : rs_w; };
+      auto VO = [&](int idx) { return idx < PA ? a_off[idx < PA ? idx : 0] : w_off[idx >= PA && idx < PA + PW ? idx - PA : 0]; };
+      auto batch = [&](auto b_c) {
+        constexpr int b = decltype(b_c)::value;
+        constexpr int n = NU - 4 * b >= 4 ? 4 : NU - 4 * b;
+        if constexpr (n > 0) {
+          constexpr int I0 = nth_outside(P0, P1, G0, G1, 4 * b), I1 = n > 1 ? nth_outside(P0, P1, G0, G1, 4 * b + 1) : I0,
+                        I2 = n > 2 ? nth_outside(P0, P1, G0, G1, 4 * b + 2) : I0, I3 = n > 3 ? nth_outside(P0, P1, G0, G1, 4 * b + 3) : I0;
+          glds16_buf_n<n, piece_lds(I0), piece_lds(I1), piece_lds(I2), piece_lds(I3)>(base, koff, RS(I0), VO(I0), RS(I1), VO(I1),
+                                                                                    RS(I2), VO(I2), RS(I3), VO(I3));
+        }
+      };
+      static_assert(NU <= 12, "three batches of four per K step");
+      batch(std::integral_constant<int, 0>{});
+      batch(std::integral_constant<int, 1>{});
+      batch(std::integral_constant<int, 2>{});
+      if constexpr (P1 == PA + PW) koff += 128;
+    }
+  };
+  auto fill_part_placed = [&](int buf, int part) __attribute__((always_inline)) {
+    if (part == 0) fill_batched(buf, std::integral_constant<int, 0>{});
+    else if (part == 1) fill_batched(buf, std::integral_constant<int, 1>{});
+    else if (part == 2) fill_batched(buf, std::integral_constant<int, 2>{});
   };
 
   // ---- fragment read offsets (lane-constant) -----------------------------------
@@ -469,6 +533,38 @@ void gemm_nt_kernel(const GemmParams p) {
           const int m = m0 + wm * TM + i * 32 + it * 4 + rd_row;
           dst[jp][it] = EpilogueOp<T, EPI>::load(p, m < Mrt ? m : Mrt - 1, n0 + wn * TN + jp * 64 + rd_col);
         }
+    }
+  };
+
+  // ---- hand-placed K step (SCHED 7 / 9) -------------------------------------------------------------------------
+  // MFMA n of the step (row block n / NI, column block n % NI), then fragment read n of the FOLLOWING step -- in the order the
+  // MFMAs want them: x0, w0 .. w(NI-1), x1 .. x(MI-1) -- then the step's fill requests in the first gap behind the reads; a
+  // scheduling fence closes every slot.  The wave-uniform break of an uneven tile's short wave row also skips the reads that
+  // row has no use for: they sit behind the MFMAs it does not issue.
+  constexpr int NM = MI * NI, NR = MI + NI;
+  constexpr int NM_MIN = kUneven ? (RB - (WM - 1) * MI) * NI : NM;
+  static_assert(!kPlaced || !kUneven || NI + (RB - (WM - 1) * MI) <= NM_MIN, "short wave row: reads must fit its MFMA gaps");
+  constexpr int kFillSlot = NR < NM_MIN ? NR : NM_MIN - 1;
+  u32x4 pxf[kPlaced ? 2 : 1][MI], pwf[kPlaced ? 2 : 1][NI];
+  auto placed_read = [&](const char* sb, int ks, int b, int r) __attribute__((always_inline)) {
+    if (r == 0) pxf[b][0] = *reinterpret_cast<const u32x4*>(sb + a_tile + foff[ks]);
+    else if (r <= NI) pwf[b][r - 1] = *reinterpret_cast<const u32x4*>(sb + w_tile + (r - 1) * 32 * 128 + foff[ks]);
+    else pxf[b][r - NI] = *reinterpret_cast<const u32x4*>(sb + a_tile + (r - NI) * 32 * 128 + foff[ks]);
+  };
+  auto placed_read_all = [&](const char* sb, int ks, int b) __attribute__((always_inline)) {
+#pragma unroll
+    for (int r = 0; r < NR; ++r) placed_read(sb, ks, b, r);
+  };
+  // ks_next < 0: no reads (the tile's last step when nothing follows); part < 0 or fill_buf < 0: no fill
+  auto placed_step = [&](int b, const char* sb_next, int ks_next, int fill_buf, int part) __attribute__((always_inline)) {
+#pragma unroll
+    for (int n = 0; n < NM; ++n) {
+      const int i = n / NI, j = n % NI;
+      if (kUneven && i >= mi_w) break;   // wave-uniform
+      mma16<T>(acc[i][j], pwf[b][j], pxf[b][i]);
+      if (ks_next >= 0 && n < NR) placed_read(sb_next, ks_next, b ^ 1, n);
+      if (part >= 0 && part < kParts && fill_buf >= 0 && n == kFillSlot) fill_part_placed(fill_buf, part);
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
 
@@ -561,8 +657,38 @@ void gemm_nt_kernel(const GemmParams p) {
     else wait_vm0();
     __syncthreads();
     if (trace && tid == 0) trace[1] = __builtin_amdgcn_s_memtime();
-    read_frags(0, 0, 0);
     int cur = 0, nxt = 1, nxt2 = 2;  // stages of tiles kt, kt+1, kt+2
+    if constexpr (kPlaced) {
+      placed_read_all(smem, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      for (int kt = 0; kt < KT - 1; ++kt) {
+        const int fb = kt + 2 < KT ? nxt2 : -1;
+        const char* sc = smem + cur * STAGE;
+        placed_step(0, sc, 1, fb, 0);
+        placed_step(1, sc, 2, fb, 1);
+        placed_step(0, sc, 3, fb, 2);
+        // this wave's pieces of tile kt+1 have landed and its reads of tile kt have returned: publish, then the last K
+        // step's MFMAs with the next tile's first fragment reads between them
+        if (fb >= 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kLeave) : "memory");
+        else wait_vm0();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+        placed_step(1, smem + nxt * STAGE, 0, -1, -1);
+        cur = nxt; nxt = nxt2; nxt2 = 3 - cur - nxt;
+      }
+      if constexpr (kRowOperand) {
+        load_block(0, add[0]);
+        add_ready = true;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      const char* sc = smem + cur * STAGE;
+      placed_step(0, sc, 1, -1, -1);
+      placed_step(1, sc, 2, -1, -1);
+      placed_step(0, sc, 3, -1, -1);
+      placed_step(1, sc, -1, -1, -1);
+    } else {
+    read_frags(0, 0, 0);
     for (int kt = 0; kt < KT - 1; ++kt) {
       const bool fetch = kt + 2 < KT;
       if constexpr (!kSpread) { if (fetch) stage_issue(nxt2); }
@@ -598,6 +724,35 @@ void gemm_nt_kernel(const GemmParams p) {
       mma_step(ks & 1);
       __builtin_amdgcn_sched_barrier(0);
     }
+    }
+  } else if constexpr (kPlaced) {
+    // two stages, hand-placed: the fill of tile kt+1 rides in the first kParts steps of tile kt; every step but the last
+    // carries the next step's fragment reads between its MFMAs; one barrier per tile, behind the last step
+    stage_issue(0);
+    stage_ln_rows();
+    wait_vm0();
+    __syncthreads();
+    if (trace && tid == 0) trace[1] = __builtin_amdgcn_s_memtime();
+    auto tile_placed = [&](int cur, int fb) __attribute__((always_inline)) {
+      const char* sc = smem + cur * STAGE;
+      placed_read_all(sc, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      placed_step(0, sc, 1, fb, 0);
+      placed_step(1, sc, 2, fb, 1);
+      placed_step(0, sc, 3, fb, 2);
+      placed_step(1, sc, -1, fb, 3);
+    };
+    for (int kt = 0; kt < KT - 1; ++kt) {
+      tile_placed(kt & 1, (kt & 1) ^ 1);
+      wait_vm0();
+      __syncthreads();
+    }
+    if constexpr (kRowOperand) {  // the residual / position rows of the first 32-row block travel during the last K tile
+      load_block(0, add[0]);
+      add_ready = true;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    tile_placed((KT - 1) & 1, -1);
   } else {
     stage_issue(0);
     stage_ln_rows();

@@ -33,7 +33,17 @@ const GemmVariant& gemm_variant(int v) { return kVariants[v]; }
 // Process-wide override for TESTS and A/B measurements (plipmi_set_gemm_variant): the product path never writes it, and
 // nothing here is read from the environment.
 static int g_override = -1;    // -1 = the cost model below chooses
-void gemm_set_default_override(int variant) { g_override = variant; }
+static int g_remap[kNumVariants];   // A/B runs: the cost model's choice a runs as g_remap[a] - 1 (0 = itself)
+// variant >= 1000: remap the cost model's choice a = (variant - 1000) / 100 to tile b = variant % 100; -1 clears everything
+void gemm_set_default_override(int variant) {
+  if (variant >= 1000) {
+    const int a = (variant - 1000) / 100, b = variant % 100;
+    if (a < kNumVariants && b < kNumVariants) g_remap[a] = b + 1;
+    return;
+  }
+  g_override = variant;
+  if (variant == -1) for (int& r : g_remap) r = 0;
+}
 bool gemm_variant_is_built(int dtype, int variant) {
   return dtype == 1 ? gemm_built_bf16(variant) : dtype == 2 ? gemm_built_f16(variant) : gemm_built_f32(variant);
 }
@@ -69,6 +79,7 @@ int gemm_default_variant(int dtype, int M, int N, int K) {
     if (rem) cost += (c.per_cu == 2 && rem <= cus) ? 0.6 * t_round : t_round;  // lone workgroups run faster
     if (cost < best_cost) { best_cost = cost; best = c.variant; }
   }
+  if (g_remap[best] > 0 && N % kVariants[g_remap[best] - 1].bn == 0) best = g_remap[best] - 1;
   return best;
 }
 

@@ -166,7 +166,9 @@ class Engine:
             if lo < 0 or hi >= cfg.vocab_size:
                 raise IndexError(f"token id out of range [0,{cfg.vocab_size}): min {lo}, max {hi}")
         # device-resident ids are range-checked BY the embedding kernel; the outcome is known once that work has run:
-        # check_async() after a synchronisation, or the next encode call on this engine, raises (plipmi_check_async)
+        # check_async() after a synchronisation, or the next encode_text on this engine, raises IndexError
+        # (PLIPMI_ERR_TOKEN_ID) -- also from a later chunk of THIS call when B > max_batch: the rows written so far are
+        # then not to be used.  Image-side calls never report it.
         eos = cfg.eos_token_id if eos_token_id is None else int(eos_token_id)
         with torch.cuda.device(self.device):
             ids = input_ids.to(device=self.device, dtype=torch.int64).contiguous()

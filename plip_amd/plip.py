@@ -10,6 +10,12 @@ are not reproduced: ``retrieval`` read a never-assigned ``self.image_vectors``
 (plip.py:114) -- here ``index_images`` sets it -- and the batch loop no longer syncs
 and copies to the host once per batch (plip.py:50): batches are enqueued back to back
 and copied once.
+
+``batch_size`` keeps its place in every signature, but it no longer sizes the ENGINE calls: the reference hard-codes
+``batch_size=8`` in ``zero_shot_classification`` / ``retrieval`` (plip.py:90-91,112), a tenth of the engine's bs=256
+rate.  A row's embedding is bit-identical whatever batch it travels in (tests/test_gpu_parity.py), so the host loops
+prepare the caller's batches one by one (same routing, same preprocessing per batch) and hand them to the towers
+``engine.max_batch`` rows at a time.  ``PLIP.coalesce = False`` restores one engine call per caller batch.
 """
 from __future__ import annotations
 
@@ -65,16 +71,20 @@ def _uniform_u8_images(chunk, n_px):
 
 
 class PLIP:
+    coalesce = True          # engine calls carry up to engine.max_batch rows whatever ``batch_size`` says (module docstring)
+
     def __init__(self, model_name: str = None, auth_token=None, *, model: Optional[PlipModel] = None,
                  tokenizer: Optional[Callable] = None, tokenizer_dir: Optional[str] = None, dtype: str = "bf16",
                  max_batch: int = 256, device: str = "cuda:0", pack_captions: bool = False, text_f16: bool = False):
         """``model_name``: local HF directory (what ``CLIPModel/CLIPProcessor.from_pretrained`` take, plip.py:26-27)
         or an OpenAI-clip ``.pt`` state dict.  The tokenizer comes from ``tokenizer`` (a callable), else from
         ``tokenizer_dir`` / the model directory when it holds ``vocab.json`` + ``merges.txt``; with neither,
-        ``encode_text`` still takes token ids.  ``pack_captions`` (extension, bf16 engine): the text tower computes only
+        ``encode_text`` still takes token ids.  ``pack_captions`` (extension, 16-bit engines): the text tower computes only
         the positions up to each caption's EOS token -- bit-identical embeddings, cost proportional to the caption lengths
         instead of the padded 77 (include/plipmi.h ``plipmi_set_text_packing``).  ``dtype``: "bf16" | "f16" | "f32";
-        ``text_f16`` (bf16 engine): the text tower on IEEE-half operands (PLIPMI_FLAG_TEXT_TOWER_F16)."""
+        ``text_f16`` (bf16 engine): the text tower on IEEE-half operands (PLIPMI_FLAG_TEXT_TOWER_F16).  The engine's other
+        per-handle options (ln_fold, pooled_last_block, mfma_attention, graph_batch) are reached by building the model
+        explicitly -- ``PLIP(model=PlipModel.from_pretrained(path, **engine_options))``."""
         if not torch.cuda.is_available():
             raise RuntimeError("plip_amd.PLIP needs an MI355X (ROCm) GPU; there is no CPU path")
         self.device = device
@@ -105,7 +115,19 @@ class PLIP:
         n_px = self.model.config.image_size
         if num_workers > 0 and not torch.is_tensor(images) and not isinstance(images, np.ndarray) and len(images):
             return self._encode_images_pipelined(list(images), batch_size, num_workers)
-        outs = []
+        eng = self.model.engine
+        cap = max(int(batch_size), int(getattr(eng, "max_batch", batch_size))) if self.coalesce else int(batch_size)
+        outs, pend, kind, rows = [], [], None, 0
+
+        def flush():
+            nonlocal pend, kind, rows
+            if pend:
+                if len(pend) > 1 and any(t.is_cuda for t in pend):
+                    pend = [t.to(eng.device) for t in pend]
+                t = pend[0] if len(pend) == 1 else torch.cat(pend)
+                outs.append(eng.encode_image_u8(t) if kind == "tiles" else self.model.get_image_features(pixel_values=t))
+            pend, kind, rows = [], None, 0
+
         with torch.no_grad():
             for s in range(0, len(images), batch_size):
                 chunk = images[s:s + batch_size]
@@ -113,21 +135,22 @@ class PLIP:
                     from PIL import Image                                  # plip.py:34 opens the paths of a batch
                     chunk = [Image.open(c) if isinstance(c, str) else c for c in chunk]
                 tiles = _native_u8_tiles(chunk, n_px)
+                same = _uniform_u8_images(chunk, n_px) if tiles is None else None
                 if tiles is not None:      # already n_px x n_px uint8: normalise on the GPU, fused into the unfold
-                    outs.append(self.model.engine.encode_image_u8(torch.from_numpy(tiles)))
-                    continue
-                same = _uniform_u8_images(chunk, n_px)
-                if same is not None:       # one size, not the model's: Pillow-exact resize + crop on the GPU as well
-                    eng = self.model.engine
-                    outs.append(eng.encode_image_u8(eng.resize_crop_u8(torch.from_numpy(same), crop=_CROP)))
-                    continue
-                if torch.is_tensor(chunk):
-                    px = chunk
+                    k, t = "tiles", torch.from_numpy(tiles)
+                elif same is not None:     # one size, not the model's: Pillow-exact resize + crop on the GPU as well
+                    k, t = "tiles", eng.resize_crop_u8(torch.from_numpy(same), crop=_CROP)
+                elif torch.is_tensor(chunk):
+                    k, t = "pixels", chunk
                 elif isinstance(chunk, np.ndarray) and chunk.dtype != np.uint8:
-                    px = torch.from_numpy(chunk)
+                    k, t = "pixels", torch.from_numpy(chunk)
                 else:
-                    px = torch.from_numpy(preprocess_images(list(chunk), n_px, crop=_CROP))
-                outs.append(self.model.get_image_features(pixel_values=px))
+                    k, t = "pixels", torch.from_numpy(preprocess_images(list(chunk), n_px, crop=_CROP))
+                if pend and (k != kind or t.dtype != pend[0].dtype or rows + t.shape[0] > cap):
+                    flush()
+                pend.append(t)
+                kind, rows = k, rows + t.shape[0]
+            flush()
         if not outs:
             return np.zeros((0, self.model.config.projection_dim), np.float32)
         return torch.cat(outs).detach().cpu().numpy()
@@ -182,10 +205,13 @@ class PLIP:
             ids, mask = self.tokenizer(list(text), ctx)
             ids, mask = torch.as_tensor(ids), (None if mask is None else torch.as_tensor(mask))
         outs = []
+        step = int(batch_size)
+        if self.coalesce:      # the captions are tokenised already: only the size of the engine calls changes
+            step = max(step, int(getattr(self.model.engine, "max_batch", step)))
         with torch.no_grad():
-            for s in range(0, len(ids), batch_size):
-                m = None if mask is None else mask[s:s + batch_size]
-                outs.append(self.model.get_text_features(input_ids=ids[s:s + batch_size], attention_mask=m))
+            for s in range(0, len(ids), step):
+                m = None if mask is None else mask[s:s + step]
+                outs.append(self.model.get_text_features(input_ids=ids[s:s + step], attention_mask=m))
         if not outs:
             return np.zeros((0, self.model.config.projection_dim), np.float32)
         return torch.cat(outs).detach().cpu().numpy()
@@ -204,10 +230,12 @@ class PLIP:
     def _nearest_neighbours(self, k, key_vectors, space_vectors, normalize=True, debug=False):
         eng = self.model.engine
         key_vectors, space_vectors = np.asarray(key_vectors), np.asarray(space_vectors)
-        # argsort()[:, -k:] hands back every column when k exceeds the corpus -- and for k = 0, since [-0:] is [0:]
-        # (plip.py:84): the same here instead of failing
+        # argsort()[:, -k:] (plip.py:84) is a SLICE: it hands back every column when k exceeds the corpus, every column for
+        # k = 0 ([-0:] is [0:]), and for k < 0 it drops the |k| weakest columns ([|k|:] of the ascending order), i.e. keeps
+        # the n - |k| best.  Same counts here instead of failing.
         n_space = space_vectors.shape[0]
-        k = n_space if int(k) <= 0 else min(int(k), n_space)
+        k = int(k)
+        k = n_space if k == 0 else (max(n_space + k, 0) if k < 0 else min(k, n_space))
         if k == 0 or key_vectors.shape[0] == 0:
             return np.zeros((key_vectors.shape[0], k), np.int64)
         kv = torch.as_tensor(np.ascontiguousarray(key_vectors, dtype=np.float32)).to(eng.device)

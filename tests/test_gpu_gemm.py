@@ -132,7 +132,7 @@ def _slice_stats(x):
 
 
 @pytest.mark.parametrize("hdt", list(HALF.values()), ids=list(HALF))
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, -1, -3])
+@pytest.mark.parametrize("variant", list(range(NVAR)) + [-1, -3])
 @pytest.mark.parametrize("mode", [0, 1])
 def test_layernorm_folded_consumer_epilogue(variant, mode, hdt):
     """y = [quickgelu](Linear(LayerNorm(x))) computed as rstd * (bf16(x) @ W'^T) + c2 with W' = bf16(W * g, rows centred)
@@ -178,7 +178,7 @@ def test_layernorm_folded_consumer_epilogue(variant, mode, hdt):
 
 
 @pytest.mark.parametrize("hdt", list(HALF.values()), ids=list(HALF))
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, -1, -3])
+@pytest.mark.parametrize("variant", list(range(NVAR)) + [-1, -3])
 def test_layernorm_folded_producer_epilogue(variant, hdt):
     """x += A @ W^T + bias in place (fp32), plus the bf16 copy and the per-slice {sum, centred M2} of the updated rows,
     the latter against fp64 statistics of the kernel's OWN fp32 output (so the check is exact to fp32 round-off)."""
@@ -205,7 +205,7 @@ def test_layernorm_folded_producer_epilogue(variant, hdt):
 
 
 @pytest.mark.parametrize("hdt", list(HALF.values()), ids=list(HALF))
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, -1])
+@pytest.mark.parametrize("variant", list(range(NVAR)) + [-1])
 def test_split_plane_residual_epilogue(variant, hdt):
     """The engine's residual update: the fp32 stream lives as two 16-bit planes, hi = the value rounded to bf16 (the next
     GEMM's A operand), lo = the signed remainder of its bit pattern, hi + lo == the fp32 value EXACTLY.  The kernel must

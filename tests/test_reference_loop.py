@@ -108,6 +108,36 @@ def test_reference_host_loops_on_the_drop_in_model_cpu(tmp_path):
     assert ours.retrieval(CAPTIONS, top_k=10).shape == ref.retrieval(CAPTIONS, top_k=10).shape == (4, 5)
     # ... and for k = 0 too ([:, -0:] is [:, 0:]): ADVICE r2
     np.testing.assert_array_equal(ours.retrieval(CAPTIONS, top_k=0), ref.retrieval(CAPTIONS, top_k=0))
+    # ... and k < 0 drops the |k| weakest columns ([:, -k:] == [:, |k|:] of the ascending order): ADVICE r3
+    np.testing.assert_array_equal(ours.retrieval(CAPTIONS, top_k=-2), ref.retrieval(CAPTIONS, top_k=-2))
+    assert ours.retrieval(CAPTIONS, top_k=-2).shape == (4, 3) and ours.retrieval(CAPTIONS, top_k=-9).shape == (4, 0)
+
+    # --- batch_size no longer sizes the ENGINE calls: the caller's batches of 2 / 3 reach the towers
+    #     max_batch rows at a time, same arrays; coalesce = False is one engine call per caller batch --------------------
+    def calls_of(fn):
+        model.engine.calls.clear()
+        out = fn()
+        return out, [c for c in model.engine.calls if c[0].startswith("encode")]
+    u8 = lambda calls: [c for c in calls if c[0] != "encode_image"]      # (the stand-in's u8 route logs its inner call too)
+    tiles = [np.asarray(im.convert("RGB").resize((cfg.image_size, cfg.image_size))) for im in images] * 4      # 20 native tiles
+    ids = np.asarray(tok(CAPTIONS * 5, return_tensors="np", max_length=77, padding="max_length", truncation=True)["input_ids"])
+    assert model.engine.max_batch == 8
+    a_img, c_img = calls_of(lambda: ours.encode_images(tiles, batch_size=2))
+    a_txt, c_txt = calls_of(lambda: ours.encode_text(ids, batch_size=3))
+    assert [c[1][0] for c in u8(c_img)] == [8, 8, 4] and [c[1][0] for c in c_txt] == [8, 8, 4]
+    ours.coalesce = False
+    b_img, d_img = calls_of(lambda: ours.encode_images(tiles, batch_size=2))
+    b_txt, d_txt = calls_of(lambda: ours.encode_text(ids, batch_size=3))
+    del ours.coalesce
+    assert [c[1][0] for c in u8(d_img)] == [2] * 10 and [c[1][0] for c in d_txt] == [3] * 6 + [2]
+    np.testing.assert_allclose(a_img, b_img, rtol=0, atol=2e-6)
+    np.testing.assert_allclose(a_txt, b_txt, rtol=0, atol=2e-6)
+    # mixed routes keep their per-batch routing and their order: 2 native tiles, 2 odd-sized images, 2 native tiles
+    mixed = tiles[:2] + images[:2] + tiles[2:4]
+    m_img, c_mix = calls_of(lambda: ours.encode_images(mixed, batch_size=2))
+    assert [c[0] for c in c_mix] == ["encode_image_u8", "encode_image", "encode_image", "encode_image_u8", "encode_image"]
+    np.testing.assert_allclose(m_img[:2], a_img[:2], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(m_img[4:6], a_img[2:4], rtol=0, atol=2e-6)
 
     # --- the restatement the GPU box runs (no /root/reference there) IS the reference's loop: identical arrays -------------
     restated = Hh.ReferenceHostLoops(model, processor, "cpu")

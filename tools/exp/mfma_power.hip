@@ -1,0 +1,169 @@
+// mfma_power.hip -- micro-benchmark (experiment, not product): sustained MFMA rate under the chip's power budget for the two
+// bf16 MFMA shapes on RANDOM operands, bare and with an LDS fragment-read stream beside them.
+//   hipcc --offload-arch=gfx950 -O3 -o mfma_power mfma_power.hip && ./mfma_power
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+// MODE 0: 32x32x16, 8 accumulators (4 A x 2 B fragments); 1: 16x16x32, 32 accumulators (8 A x 4 B): same FLOPs / same
+// operand bytes per "step" (8 x 32K FLOP).  LDS = number of ds_read_b128 per step (0, 6, 12) refreshing fragments.
+// AG = 1: the accumulators are pinned to the accumulation register file (AGPRs) through inline asm ("a" constraint)
+template <int MODE, int LDS, int AG = 0>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void k(const u32x4* __restrict__ src, float* __restrict__ out, int iters, unsigned long long* clk) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  u32x4* l = reinterpret_cast<u32x4*>(smem);
+  for (int i = tid; i < 4096; i += 512) l[i] = src[(blockIdx.x * 4096 + i) % (1 << 20)];
+  __syncthreads();
+  constexpr int NA = MODE == 0 ? 4 : 8, NB = MODE == 0 ? 2 : 4;
+  u32x4 a[NA], b[NB];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) a[i] = l[(tid * 7 + i * 613) & 4095];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) b[i] = l[(tid * 11 + i * 389 + 77) & 4095];
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  if constexpr (MODE == 0) {
+    f32x16 acc[NA][NB];
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+#pragma unroll
+      for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    int off = (lane * 16 + (tid >> 6) * 1024) & 0xffff;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int i = 0; i < NA; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+          if constexpr (AG) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(b[j]), "v"(a[i]));
+          else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b[j]), __builtin_bit_cast(bf16x8, a[i]), acc[i][j], 0, 0, 0);
+          constexpr int n = 0;
+          if (LDS > 0 && (i * NB + j) < LDS) {
+            const int r = i * NB + j;
+            u32x4 v = *reinterpret_cast<const u32x4*>(smem + ((off + r * 4096) & 0xffff));
+            if (r < NA) a[r] = v; else b[(r - NA) % NB] = v;
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      off = (off + 8192) & 0xffff;
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+#pragma unroll
+      for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s += acc[i][j][e];
+    out[blockIdx.x * 512 + tid] = s;
+  } else {
+    f32x4 acc[NA][NB];
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+#pragma unroll
+      for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+    int off = (lane * 16 + (tid >> 6) * 1024) & 0xffff;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int i = 0; i < NA; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+          if constexpr (AG) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(b[j]), "v"(a[i]));
+          else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b[j]), __builtin_bit_cast(bf16x8, a[i]), acc[i][j], 0, 0, 0);
+          // 32 MFMAs of 16K FLOP per step: the same LDS reads per FLOP means one read per (4 MFMAs / (8 / LDS)) ...
+          if (LDS > 0 && ((i * NB + j) % 2 == 0) && (i * NB + j) / 2 < LDS) {
+            const int r = (i * NB + j) / 2;
+            u32x4 v = *reinterpret_cast<const u32x4*>(smem + ((off + r * 4096) & 0xffff));
+            if (r < NA) a[r] = v; else b[(r - NA) % NB] = v;
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      off = (off + 8192) & 0xffff;
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+#pragma unroll
+      for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s += acc[i][j][e];
+    out[blockIdx.x * 512 + tid] = s;
+  }
+  if (tid == 0) {
+    clk[blockIdx.x * 2] = __builtin_amdgcn_s_memtime() - t0;
+    clk[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memrealtime() - r0;
+  }
+}
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s failed: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+template <int MODE, int LDS, int AG = 0>
+void run(const char* name, const u32x4* src, float* out, unsigned long long* clk, int iters, bool zero) {
+  auto kern = k<MODE, LDS, AG>;
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  const int blocks = 256;
+  for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), 65536, 0, src, out, iters, clk);
+  CK(hipDeviceSynchronize());
+  float best = 1e9f, sum = 0.f;
+  const int reps = 6;
+  for (int r = 0; r < reps; ++r) {
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), 65536, 0, src, out, iters, clk);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    best = ms < best ? ms : best; sum += ms;
+  }
+  std::vector<unsigned long long> h(blocks * 2);
+  CK(hipMemcpy(h.data(), clk, blocks * 16, hipMemcpyDeviceToHost));
+  double cyc = 0, real = 0;
+  for (int i = 0; i < blocks; ++i) { cyc += h[2 * i]; real += h[2 * i + 1]; }
+  const double flop = (double)blocks * 8 /*waves*/ * iters * 8 * 32768.0 * 2 / 2;   // 8 x 32K-MAC... 32x32x16 = 32768 FLOP
+  const double fl = (double)blocks * 8 * (double)iters * 8.0 * 32768.0;
+  (void)flop;
+  printf("%-34s %s operands: %8.3f ms (mean %8.3f)  %7.1f TFLOP/s   shader clock %.3f GHz   MFMA issue %.1f %% of cycles\n", name,
+         zero ? "ZERO  " : "random", best, sum / reps, fl / (best * 1e-3) / 1e12, cyc / real / 10.0 / 1e0 / 1e0 * 1e-0 / 100.0 * 100.0 / 100.0,
+         100.0 * (double)iters * 8 * 32.0 * 2 / (cyc / blocks));
+}
+
+int main() {
+  u32x4* src; float* out; unsigned long long* clk;
+  const size_t n = 1 << 20;
+  CK(hipMalloc(&src, n * 16)); CK(hipMalloc(&out, 256 * 512 * 4)); CK(hipMalloc(&clk, 256 * 16));
+  std::vector<unsigned> h(n * 4);
+  for (int zero = 0; zero < 2; ++zero) {
+    unsigned s = 12345u;
+    for (auto& v : h) {   // random bf16 pairs in [-2, 2): sign + exponent 0x3f/0x3e/0x40.. + random mantissa
+      s = s * 1664525u + 1013904223u; unsigned a = s >> 16;
+      s = s * 1664525u + 1013904223u; unsigned b = s >> 16;
+      auto mk = [](unsigned r) { return (unsigned)(((r & 1) << 15) | ((0x3e + ((r >> 1) & 3)) << 8 >> 1 << 0) | ((r >> 3) & 0x7f)) & 0xffffu; };
+      v = zero ? 0u : ((mk(a) << 16) | mk(b));
+    }
+    CK(hipMemcpy(src, h.data(), n * 16, hipMemcpyHostToDevice));
+    const int iters = 6000;
+    run<0, 0>("32x32x16, bare", src, out, clk, iters, zero);
+    run<0, 0, 1>("32x32x16, bare, AGPR acc", src, out, clk, iters, zero);
+    run<1, 0>("16x16x32, bare", src, out, clk, iters, zero);
+    run<1, 0, 1>("16x16x32, bare, AGPR acc", src, out, clk, iters, zero);
+    run<0, 6, 1>("32x32x16 + 6 ds_read / 8, AGPR", src, out, clk, iters, zero);
+    run<1, 6, 1>("16x16x32 + 6 ds_read / 16, AGPR", src, out, clk, iters, zero);
+    run<1, 3, 1>("16x16x32 + 3 ds_read / 16, AGPR", src, out, clk, iters, zero);
+    run<0, 6>("32x32x16 + 6 ds_read_b128 / 8 MFMA", src, out, clk, iters, zero);
+    run<1, 6>("16x16x32 + 6 ds_read_b128 / 16 MFMA", src, out, clk, iters, zero);
+    run<0, 3>("32x32x16 + 3 ds_read_b128 / 8 MFMA", src, out, clk, iters, zero);
+    run<1, 3>("16x16x32 + 3 ds_read_b128 / 16 MFMA", src, out, clk, iters, zero);
+  }
+  return 0;
+}

@@ -265,6 +265,7 @@ def sec_libgemm():
               ("v.fc2", 12800, 768, 3072), ("t.qkv", 19712, 1536, 512), ("t.out", 19712, 512, 512),
               ("t.fc1", 19712, 2048, 512), ("t.fc2", 19712, 512, 2048), ("big", 8192, 8192, 8192)]
     names = gemm_variants()
+    LV = [int(x) for x in sys.argv[2:] if x.isdigit()] or [2, 3, 4, 5, 6]
     for dt in (torch.bfloat16, torch.float16):
         g = torch.Generator().manual_seed(0)
         print(f"== {dt}")
@@ -278,14 +279,14 @@ def sec_libgemm():
             for rep in range(3):
                 for key, fn in [("F.linear", lambda: F.linear(a, w, bias_h)), ("torch.mm", lambda: torch.mm(a, w.t(), out=out)),
                                 ("own", lambda: gemm_nt(a, w, bias, epilogue=0, out=out))] + \
-                               [(v, (lambda v=v: gemm_nt(a, w, bias, epilogue=0, variant=v, out=out))) for v in (2, 3, 4, 5, 6)]:
+                               [(v, (lambda v=v: gemm_nt(a, w, bias, epilogue=0, variant=v, out=out))) for v in LV]:
                     ms = _time(fn, iters=20, warm=3)
                     best[key] = min(best.get(key, 1e9), ms)
             f = 2.0 * M * N * K / 1e9
-            bv = min((2, 3, 4, 5, 6), key=lambda v: best[v])
+            bv = min(LV, key=lambda v: best[v])
             print(f"{name:6s} {M:6d}x{N:5d}x{K:5d}: F.linear+bias {f / best['F.linear']:7.1f}  torch.mm {f / best['torch.mm']:7.1f}  "
                   f"gemm_nt(bias) engine's tile {f / best['own']:7.1f}  best tile {f / best[bv]:7.1f} ({names[bv]})  TF/s   "
-                  f"[{best['F.linear'] * 1e3:.1f} / {best['own'] * 1e3:.1f} us]")
+                  f"[{best['F.linear'] * 1e3:.1f} / {best['own'] * 1e3:.1f} us]   per tile: " + " ".join(f"v{v} {f / best[v]:6.1f}" for v in LV))
 
 
 def sec_towerswap():
@@ -450,7 +451,7 @@ def sec_tiles():
     shapes = [("v.qkv", 12800, 2304, 768, 0), ("v.fc1", 12800, 3072, 768, 1), ("v.out", 12800, 768, 768, 3),
               ("v.fc2", 12800, 768, 3072, 3), ("t.qkv", 19712, 1536, 512, 0), ("t.fc1", 19712, 2048, 512, 1),
               ("t.out", 19712, 512, 512, 3), ("t.fc2", 19712, 512, 2048, 3)]
-    variants = [2, 3, 4, 5, 6]
+    variants = [int(x) for x in sys.argv[2:] if x.lstrip("-").isdigit()] or [2, 3, 4, 5, 6]
     names = gemm_variants()
     print("variants:", {v: names[v] for v in variants}, "dtype", hdt)
     g = torch.Generator().manual_seed(0)
@@ -477,6 +478,113 @@ def sec_tiles():
         bv = min(best, key=best.get)
         print(f"{name:6s} {M}x{N}x{K} {('ln_bias', 'ln_qgelu', '', 'resid_split')[mode]:11s} us  {row}   "
               f"| best v{bv} {fl / best[bv]:7.1f} TF/s | vendor F.linear+bias {lib_us:6.1f} us {fl / lib_us:7.1f} TF/s")
+
+
+def sec_stepab():
+    """In-process interleaved A/B of the bs=256 bf16 step under remapped tile choices (test hook plipmi_set_gemm_variant
+    1000 + 100 a + b: the cost model's choice a runs as tile b).  arguments: arms like  base  2>7  2>7,3>9,6>10"""
+    from plip_amd import _lib
+    from plip_amd.dist import sharded_pair_logits
+    lib = _lib.load()
+    B = 256
+    cfg, sd, px, ids, mask = _step_inputs(B)
+    model = PlipModel(cfg, sd, dtype=os.environ.get("STEPAB_DTYPE", "bf16"), max_batch=B)
+    arms = sys.argv[2:] or ["base"]
+    names = gemm_variants()
+    ref = None
+    res = {a: {False: [], True: []} for a in arms}
+    for rep in range(3):
+        for arm in arms:
+            lib.plipmi_set_gemm_variant(-1)
+            if arm != "base":
+                for pair in arm.split(","):
+                    a, b = (int(x) for x in pair.split(">"))
+                    lib.plipmi_set_gemm_variant(1000 + 100 * a + b)
+            for ov in (False, True):
+                ms = _time(lambda: sharded_pair_logits(model, px, ids, mask, overlap=ov), iters=20, warm=3)
+                res[arm][ov].append(ms)
+            if rep == 0:
+                out = sharded_pair_logits(model, px, ids, mask, overlap=False)[0].float().cpu()
+                if ref is None:
+                    ref = out
+                print(f"arm {arm:24s} logits max |diff| vs first arm {float((out - ref).abs().max()):.3e}")
+    lib.plipmi_set_gemm_variant(-1)
+    for arm in arms:
+        one, two = res[arm][False], res[arm][True]
+        print(f"{arm:24s} one stream {min(one):6.3f} ms (median {sorted(one)[1]:6.3f})   two streams {min(two):6.3f} ms (median {sorted(two)[1]:6.3f})"
+              f"   {B / min(two) * 1e3:8.0f} pairs/s")
+    print("tiles:", {i: n for i, n in enumerate(names)})
+    model.engine.close()
+
+
+def sec_cumask():
+    """Experiment: the two towers on CU-masked HIP streams (hipExtStreamCreateWithCUMask) instead of two plain streams -- each
+    tower owns a share of the CUs, so one tower's K loops run beside the other's memory-bound phases by construction.
+    arguments: masks as  name:spec  with spec = 'lo<N>' (first N mask bits), 'xcd<K>' (bits i with i % 8 < K), 'even'"""
+    import ctypes as C
+    from plip_amd.dist import sharded_pair_logits
+    hip = C.CDLL("libamdhip64.so")
+    B = 256
+    cfg, sd, px, ids, mask = _step_inputs(B)
+    model = PlipModel(cfg, sd, dtype="bf16", max_batch=B)
+    eng = model.engine
+    ncu = torch.cuda.get_device_properties(0).multi_processor_count
+
+    def bits(spec, invert=False):
+        if spec.startswith("lo"):
+            n = int(spec[2:]); on = [i < n for i in range(ncu)]
+        elif spec.startswith("xcd"):
+            k = int(spec[3:]); on = [(i % 8) < k for i in range(ncu)]
+        elif spec == "even":
+            on = [(i % 2) == 0 for i in range(ncu)]
+        elif spec.startswith("se"):      # blocks of 8 consecutive bits, first K of every 16
+            k = int(spec[2:]); on = [((i // 8) % 2) < 1 if k == 1 else True for i in range(ncu)]
+        else:
+            raise ValueError(spec)
+        if invert:
+            on = [not b for b in on]
+        words = (C.c_uint32 * ((ncu + 31) // 32))()
+        for i, b in enumerate(on):
+            if b:
+                words[i // 32] |= (1 << (i % 32))
+        return words, sum(on)
+
+    def masked_stream(spec, invert=False):
+        words, n = bits(spec, invert)
+        st = C.c_void_p()
+        rc = hip.hipExtStreamCreateWithCUMask(C.byref(st), C.c_uint32(len(words)), words)
+        assert rc == 0, rc
+        return torch.cuda.ExternalStream(st.value, device=dev), n
+
+    def step_masked(vis, txt_s):
+        main = torch.cuda.current_stream(dev)
+        vis.wait_stream(main); txt_s.wait_stream(main)
+        with torch.cuda.stream(txt_s):
+            t = eng.encode_text(ids, mask, True)
+        with torch.cuda.stream(vis):
+            i = eng.encode_image(px, True)
+        main.wait_stream(vis); main.wait_stream(txt_s)
+        return eng.logits(i, t, scale=eng.logit_scale_exp, want_text=False)[0]
+
+    ref = sharded_pair_logits(model, px, ids, mask, overlap=True)[0]
+    print(f"{ncu} CUs; plain two streams {_time(lambda: sharded_pair_logits(model, px, ids, mask, overlap=True), iters=20, warm=3):.3f} ms, "
+          f"one stream {_time(lambda: sharded_pair_logits(model, px, ids, mask, overlap=False), iters=20, warm=3):.3f} ms")
+    for spec in sys.argv[2:] or ["lo128", "lo160", "lo152", "xcd4", "xcd5", "even"]:
+        vis, nv = masked_stream(spec)
+        txt_s, nt = masked_stream(spec, invert=True)
+        out = step_masked(vis, txt_s)
+        torch.cuda.synchronize()
+        same = bool(torch.equal(out, ref))
+        ms = min(_time(lambda: step_masked(vis, txt_s), iters=20, warm=3) for _ in range(2))
+        # each tower alone on its share
+        with torch.cuda.stream(vis):
+            tv = _time(lambda: eng.encode_image(px, True), iters=10, warm=2)
+        with torch.cuda.stream(txt_s):
+            tt = _time(lambda: eng.encode_text(ids, mask, True), iters=10, warm=2)
+        print(f"mask {spec:8s}: vision on {nv:3d} CUs, text on {nt:3d}: step {ms:.3f} ms ({B / ms * 1e3:.0f} pairs/s) bit-identical {same};  "
+              f"alone on its share: vision {tv:.3f} ms, text {tt:.3f} ms")
+    print(f"plain two streams again {_time(lambda: sharded_pair_logits(model, px, ids, mask, overlap=True), iters=20, warm=3):.3f} ms")
+    model.engine.close()
 
 
 def sec_cold():
@@ -645,5 +753,5 @@ def sec_e2e():
 if __name__ == "__main__":
     t0 = time.time()
     {"gemm": sec_gemm, "attn": sec_attn, "tiny": sec_tiny, "vitb32": sec_vitb32, "gemmbench": sec_gemmbench, "lnbench": sec_lnbench, "latency": sec_latency, "libgemm": sec_libgemm, "tiles": sec_tiles, "parity": sec_parity, "sustain": sec_sustain, "power": sec_power, "cold": sec_cold, "towerswap": sec_towerswap, "e2e": sec_e2e, "gemmone": sec_gemmone, "policy": sec_policy, "ldpad": sec_ldpad, "gemmtrace": sec_gemmtrace,
-     "overlap": sec_overlap}[sys.argv[1]]()
+     "overlap": sec_overlap, "stepab": sec_stepab, "cumask": sec_cumask}[sys.argv[1]]()
     print(f"[{sys.argv[1]} done in {time.time() - t0:.1f} s]")
