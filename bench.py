@@ -398,7 +398,9 @@ def main(argv=None, model_factory=None):
         "data": "synthetic" if not rehearsal else "synthetic; gloo REHEARSAL with a stub engine -- control flow only, not a measurement",
         "config": {"workload": f"full dual encoder (image tower + text tower + L2 normalise + logits_per_image), "
                                f"{args.arch}, bs={B} pairs per GPU, {cfg.image_size}px, {cfg.context_length} tokens, "
-                               f"{args.dtype} MFMA / fp32 accumulate (BASELINE.json configs[2])",
+                               f"{args.dtype} MFMA / fp32 accumulate (BASELINE.json configs[2])" +
+                               (f"; the first {model.engine.text_f16_layers} of the {cfg.t_layers} text blocks on f16 MFMA operands "
+                                f"(plipmi_config.text_f16_layers, the engine default)" if getattr(model.engine, "text_f16_layers", 0) else ""),
                    "arch": args.arch, "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
                    "collective": "none" if world == 1 else "RCCL all-gather of [B,512] fp32 image+text embeddings",
                    "streams": 2 if args.overlap else 1, "device": model.engine.device_name},
@@ -449,21 +451,24 @@ def main(argv=None, model_factory=None):
             del mo
         except Exception as e:  # pragma: no cover
             res[other] = {"error": repr(e)}
-        # the bf16 engine with its text tower on IEEE-half operands (PLIPMI_FLAG_TEXT_TOWER_F16): the text side carries most of
-        # the bf16 engine's cosine error and 40 % of its time
+        # the bf16 engine's precision dial (plipmi_config.text_f16_layers): how many LEADING text blocks run on IEEE-half operands.
+        # The headline engine uses the default; 0 = pure bf16, t_layers = the whole text tower (PLIPMI_FLAG_TEXT_TOWER_F16's engine)
         if args.dtype == "bf16":
-            try:
-                mm = side_engine("bf16", text_f16=True)
-                dtm, _ = timed_steps(lambda: sharded_pair_logits(mm, px, ids, mask, overlap=bool(args.overlap), equal_shards=True),
-                                     args.steps, dev, args.warmup)
-                res["bf16_image_f16_text"] = {
-                    "note": "the same step on a bf16 engine created with PLIPMI_FLAG_TEXT_TOWER_F16 (image tower bf16, text tower f16)",
-                    "pairs_per_s": round(B / dtm, 1), "ms_per_step": round(dtm * 1e3, 3),
-                    "logits_max_abs_err": logits_error_vs_hf_golden(mm, cfg, sd, px, ids, mask, B, args.arch)}
-                mm.engine.close()
-                del mm
-            except Exception as e:  # pragma: no cover
-                res["bf16_image_f16_text"] = {"error": repr(e)}
+            dial = {}
+            for n in sorted({0, 4, cfg.t_layers} - {model.engine.text_f16_layers}):
+                try:
+                    mm = side_engine("bf16", text_f16_layers=n)
+                    dtm, _ = timed_steps(lambda: sharded_pair_logits(mm, px, ids, mask, overlap=bool(args.overlap), equal_shards=True),
+                                         args.steps, dev, args.warmup)
+                    dial[str(n)] = {"pairs_per_s": round(B / dtm, 1), "ms_per_step": round(dtm * 1e3, 3),
+                                    "logits_max_abs_err": logits_error_vs_hf_golden(mm, cfg, sd, px, ids, mask, B, args.arch)}
+                    mm.engine.close()
+                    del mm
+                except Exception as e:  # pragma: no cover
+                    dial[str(n)] = {"error": repr(e)}
+            res["text_f16_layers"] = {
+                "note": "the same step on bf16 engines with that many leading text blocks on f16 operands (image tower bf16 in all of "
+                        f"them); the headline engine runs {model.engine.text_f16_layers}", "engines": dial}
         # A/B: the same step with the last block computed on EVERY token (as HF does), i.e. the dense 14.777 GFLOP per pair
         try:
             md = side_engine(args.dtype, pooled_last_block=False)

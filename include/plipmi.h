@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define PLIPMI_VERSION 300 /* 0.3.0: plipmi_config grew `flags` and `graph_batch`; PLIPMI_F16; fp8-weights mode removed */
+#define PLIPMI_VERSION 310 /* 0.3.1: plipmi_config grew `text_f16_layers`; PLIPMI_ERR_TOKEN_ID (0.3.0: `flags`, `graph_batch`, PLIPMI_F16) */
 
 /* arithmetic the towers' GEMMs and attention run in (accumulation, LayerNorm,
  * softmax statistics, residual stream, projections and logits are always fp32):
@@ -107,6 +107,10 @@ typedef struct plipmi_config {
   int32_t flags;           /* PLIPMI_FLAG_* bits, 0 = the product defaults */
   int32_t graph_batch;     /* small-batch hipGraph replay: 0 = default (batches of <= min(32, max_batch) samples),
                             * > 0 = that many, < 0 = never (plipmi_set_graph_batch changes it later) */
+  int32_t text_f16_layers; /* bf16 engine: this many LEADING blocks of the text tower run on IEEE-half (f16) MFMA operands, the
+                            * rest of the tower and the whole image tower on bf16.  The bf16 engine's embedding error is mostly
+                            * operand rounding in the text tower's first blocks; 0 = a pure bf16 engine,
+                            * t_layers = PLIPMI_FLAG_TEXT_TOWER_F16.  The residual stream stays exact fp32 across the switch. */
 } plipmi_config;
 
 /* One pre-LN transformer block, HF CLIPEncoderLayer naming; all DEVICE pointers
@@ -254,8 +258,13 @@ const char* plipmi_gemm_variant_name(int variant);
 /* 1 if this build of the library carries `variant` for `dtype`, else 0 */
 int plipmi_gemm_variant_built(int dtype, int variant);
 /* TEST / A-B HOOK, process-wide, not used by the product path: force every GEMM onto one tile variant (>= 0), or back
- * to the engine's own choice (-1).  (The library reads no environment variables.) */
+ * to the engine's own choice (-1); 1000 + 100 a + b re-maps the engine's choice a to tile b (A/B runs of the step;
+ * -1 clears the map too).  (The library reads no environment variables.) */
 void plipmi_set_gemm_variant(int variant);
+/* Test hook: the residual-stream planes {hi, lo} (n values, n % 4 == 0) from `from_dtype`'s split format to `to_dtype`'s
+ * (PLIPMI_BF16 / PLIPMI_F16), in place -- what a text tower with plipmi_config.text_f16_layers does between its f16 and
+ * its bf16 blocks.  Exact: both formats hold the fp32 value bit for bit (|x| < 65504). */
+int plipmi_recode_planes(void* hi, void* lo, size_t n, int from_dtype, int to_dtype, void* stream);
 /* same call with explicit leading dimensions (in elements) for A [M,K] and W [N,K]: rows may be padded */
 int plipmi_gemm_nt_ld(int dtype, int epilogue, int variant, int M, int N, int K, const void* A, int lda, const void* W,
                       int ldw, const float* bias, float alpha, void* C, void* stream);

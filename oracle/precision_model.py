@@ -107,9 +107,13 @@ def _attention(qkv, B, S, H, causal, key_mask, rnd=_DEFAULT):
     return rnd("att", o.transpose(0, 2, 1, 3).reshape(B, S, D))
 
 
-def _layers(x, sd, prefix, L, H, causal, key_mask, eps, plan, hidden, rnd=_DEFAULT):
+def _layers(x, sd, prefix, L, H, causal, key_mask, eps, plan, hidden, rnd=_DEFAULT, lead=0):
+    """``lead``: the first ``lead`` blocks round their operands to f16 whatever ``rnd`` says for the rest
+    (plipmi_config.text_f16_layers: a bf16 text tower whose leading blocks run on IEEE-half operands)."""
     B, S, D = x.shape
+    rnd_rest, rnd_lead = rnd, Rounding("f16", rnd.sites)
     for i in range(L):
+        rnd = rnd_lead if i < lead else rnd_rest
         p = f"{prefix}.encoder.layers.{i}"
         g1, b1 = _f(sd, f"{p}.layer_norm1.weight"), _f(sd, f"{p}.layer_norm1.bias")
         parts = []
@@ -144,14 +148,16 @@ def vision_tower(pixels, sd, cfg, plan="folded", return_hidden=False, dtype="bf1
     return (emb, hidden) if return_hidden else emb
 
 
-def text_tower(ids, sd, cfg, attention_mask=None, plan="folded", return_hidden=False, dtype="bf16", sites=ALL_SITES):
+def text_tower(ids, sd, cfg, attention_mask=None, plan="folded", return_hidden=False, dtype="bf16", sites=ALL_SITES,
+               lead_f16=0):
     rnd = Rounding(dtype, sites)
     ids = np.asarray(ids)
     B, S = ids.shape
     x = _f(sd, "text_model.embeddings.token_embedding.weight")[ids] + \
         _f(sd, "text_model.embeddings.position_embedding.weight")[None, :S]
     hidden = [x]
-    x = _layers(x, sd, "text_model", cfg.t_layers, cfg.t_heads, True, attention_mask, cfg.layer_norm_eps, plan, hidden, rnd)
+    x = _layers(x, sd, "text_model", cfg.t_layers, cfg.t_heads, True, attention_mask, cfg.layer_norm_eps, plan, hidden, rnd,
+                lead_f16)
     x = O.layer_norm(x, _f(sd, "text_model.final_layer_norm.weight"), _f(sd, "text_model.final_layer_norm.bias"),
                      cfg.layer_norm_eps)
     pooled = x[np.arange(B), O.eos_positions(ids, cfg.eos_token_id)]

@@ -19,7 +19,7 @@ class Config(C.Structure):
         "image_size", "patch_size", "v_width", "v_layers", "v_heads", "v_mlp", "vocab_size",
         "context_length", "t_width", "t_layers", "t_heads", "t_mlp", "projection_dim")] + [
         ("layer_norm_eps", C.c_float), ("compute_dtype", C.c_int32), ("max_batch", C.c_int32), ("flags", C.c_int32),
-        ("graph_batch", C.c_int32)]
+        ("graph_batch", C.c_int32), ("text_f16_layers", C.c_int32)]
 
 
 _LAYER_FIELDS = ("ln1_w", "ln1_b", "q_w", "q_b", "k_w", "k_b", "v_w", "v_b", "o_w", "o_b",
@@ -68,6 +68,7 @@ SYMBOLS = {
     "plipmi_gemm_variant_name": (C.c_char_p, [_i]),
     "plipmi_set_gemm_variant": (None, [_i]),
     "plipmi_gemm_variant_built": (_i, [_i, _i]),
+    "plipmi_recode_planes": (_i, [_vp, _vp, C.c_size_t, _i, _i, _vp]),
     "plipmi_set_text_packing": (_i, [_vp, _i]),
     "plipmi_gemm_nt_ln": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp]),
     "plipmi_gemm_nt_ld": (_i, [_i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _f, _vp, _vp]),

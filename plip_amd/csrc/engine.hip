@@ -56,6 +56,13 @@ struct LayerW {
 struct Tower {
   int D = 0, F = 0, L = 0, H = 0, S = 0;
   int dtype = 0;   // operand type of this tower's GEMMs / attention (the engine's, or f16 for the text tower under PLIPMI_FLAG_TEXT_TOWER_F16)
+  // plipmi_config.text_f16_layers: the first lead_f16 blocks of a bf16 text tower run on IEEE-half operands (the blocks where
+  // bf16's operand rounding costs the embeddings most -- DESIGN.md section 2.1), the rest on the tower's type.  `cur` = the
+  // operand type of the block being enqueued (what run_gemm / attention launch with); `planes` = the split format the
+  // residual planes {h, lo} currently hold: a block whose type differs re-codes them first (recode_planes).
+  int lead_f16 = 0;
+  int cur = 0, planes = 0;
+  int layer_dtype(int l) const { return l < lead_f16 ? PLIPMI_F16 : dtype; }
   std::vector<LayerW> layers;
   // workspace
   float* x = nullptr;
@@ -236,9 +243,10 @@ void carve(plipmi_engine* e, Carver& c) {
 }
 
 int pack_tower(plipmi_engine* e, Tower& t, const plipmi_layer_weights* src, hipStream_t s) {
-  const int D = t.D, F = t.F, dt = t.dtype;
+  const int D = t.D, F = t.F;
   const float qscale = 0.125f;  // head_dim 64 -> 64^-0.5, a power of two: folding it into Wq/bq is exact
   for (int l = 0; l < t.L; ++l) {
+    const int dt = t.layer_dtype(l);
     const plipmi_layer_weights& w = src[l];
     LayerW& d = t.layers[l];
     if (e->ln_fold) {
@@ -300,8 +308,8 @@ int run_gemm(plipmi_engine* e, const Tower& t, int epi, const void* A, const voi
                            : (double)M * N * (epi_is_resid(epi) ? 8.0 : 4.0) + (epi == EPI_RESID_EMIT ? (double)M * N * 2.0 : 0.0);
   Scope sc(e, s, name, 2.0 * M * N * (double)K, ((double)M * K + (double)N * K) * e->esz + out_bytes);
   const int rc = (skinny && e->half() && gemm_skinny_supports(epi, M, N, K))
-                     ? gemm_launch_skinny(t.dtype, epi, p, s, &name)
-                     : gemm_launch(t.dtype, epi, -1, p, s, &name);
+                     ? gemm_launch_skinny(t.cur, epi, p, s, &name)
+                     : gemm_launch(t.cur, epi, -1, p, s, &name);
   if (e->prof) sc.rename(name_with_role(name, role));
   if (rc != 0) return fail(PLIPMI_ERR_HIP, "gemm launch (%s, M=%d N=%d K=%d) failed: %s", name, M, N, K,
                            hipGetErrorString((hipError_t)rc));
@@ -309,6 +317,19 @@ int run_gemm(plipmi_engine* e, const Tower& t, int epi, const void* A, const voi
 }
 
 #define RUN(expr) do { int rc_ = (expr); if (rc_ != PLIPMI_OK) return rc_; } while (0)
+
+// Block l is about to be enqueued: launch with its operand type and, on a LayerNorm-folded engine, make the residual planes
+// speak it (hi IS the block's A operand).  The planes are re-coded in place, exactly: both formats hold the fp32 value bit for
+// bit (|x| < 65504), so a mixed tower's stream is the very stream of the unmixed ones up to the blocks' own arithmetic.
+int enter_block(plipmi_engine* e, Tower& t, int l, int M, hipStream_t s) {
+  t.cur = t.layer_dtype(l);
+  if (e->ln_fold && t.planes != t.cur) {
+    Scope sc(e, s, "recode_planes", 0, (double)M * t.D * 8);
+    HIP_TRY(launch_recode_planes(t.h, t.lo, (size_t)M * t.D, t.planes, t.cur, s));
+    t.planes = t.cur;
+  }
+  return PLIPMI_OK;
+}
 
 // n_layers pre-LN residual blocks over the tower's residual stream x (CLIPEncoderLayer, modeling_clip.py:362-383)
 int run_layers(plipmi_engine* e, Tower& t, int B, int n_layers, int causal, const int64_t* key_mask, hipStream_t s,
@@ -320,7 +341,7 @@ int run_layers(plipmi_engine* e, Tower& t, int B, int n_layers, int causal, cons
   const int* md = t.packed ? t.mdev : nullptr;
   auto attention = [&]() -> int {
     Scope sc(e, s, impl ? "attention_mfma" : "attention_valu", 4.0 * B * t.H * (double)t.S * t.S * 64, (double)M * 4 * D * e->esz);
-    HIP_TRY(launch_attention(t.qkv, t.att, t.dtype, B, t.S, t.H, causal, key_mask, impl, s, cu));
+    HIP_TRY(launch_attention(t.qkv, t.att, t.cur, B, t.S, t.H, causal, key_mask, impl, s, cu));
     return PLIPMI_OK;
   };
   if (e->ln_fold) {
@@ -333,6 +354,7 @@ int run_layers(plipmi_engine* e, Tower& t, int B, int n_layers, int causal, cons
     LnArgs emit; emit.xb_out = t.h; emit.st_out = t.st; emit.lo_io = t.lo;
     for (int l = 0; l < n_layers; ++l) {
       const LayerW& w = t.layers[l];
+      RUN(enter_block(e, t, l, M, s));
       RUN(run_gemm(e, t, EPI_BIAS_LN, t.h, w.wqkv, t.qkv, w.bqkv, M, 3 * D, D, 3 * D, 0, s, "qkv", &use, md));
       RUN(attention());
       RUN(run_gemm(e, t, EPI_RESID_SPLIT, t.att, w.wo, nullptr, w.bo, M, D, D, D, 0, s, "out_proj", &emit, md));
@@ -342,19 +364,20 @@ int run_layers(plipmi_engine* e, Tower& t, int B, int n_layers, int causal, cons
     if (!more_follow) {
       if (t.packed) return fail(PLIPMI_ERR_INVALID, "packed rows have no every-token form");   // a consumer of plain fp32 rows follows (the every-token head, plipmi_debug_hidden)
       Scope sc(e, s, "join_planes", 0, (double)M * D * 8);
-      HIP_TRY(launch_join_planes(t.h, t.lo, t.x, (size_t)M * D, t.dtype, s));
+      HIP_TRY(launch_join_planes(t.h, t.lo, t.x, (size_t)M * D, t.planes, s));
     }
     return PLIPMI_OK;
   }
   for (int l = 0; l < n_layers; ++l) {
     const LayerW& w = t.layers[l];
+    RUN(enter_block(e, t, l, M, s));
     { Scope sc(e, s, "layernorm", 0, (double)M * D * (4 + e->esz));
-      HIP_TRY(launch_layernorm(t.x, D, w.ln1w, w.ln1b, t.h, t.dtype, M, D, eps, s)); }
+      HIP_TRY(launch_layernorm(t.x, D, w.ln1w, w.ln1b, t.h, t.cur, M, D, eps, s)); }
     RUN(run_gemm(e, t, EPI_BIAS, t.h, w.wqkv, t.qkv, w.bqkv, M, 3 * D, D, 3 * D, 0, s, "qkv"));
     RUN(attention());
     RUN(run_gemm(e, t, EPI_BIAS_RESID, t.att, w.wo, t.x, w.bo, M, D, D, D, 0, s, "out_proj"));
     { Scope sc(e, s, "layernorm", 0, (double)M * D * (4 + e->esz));
-      HIP_TRY(launch_layernorm(t.x, D, w.ln2w, w.ln2b, t.h, t.dtype, M, D, eps, s)); }
+      HIP_TRY(launch_layernorm(t.x, D, w.ln2w, w.ln2b, t.h, t.cur, M, D, eps, s)); }
     RUN(run_gemm(e, t, EPI_BIAS_QGELU, t.h, w.w1, t.mlp, w.b1, M, F, D, F, 0, s, "fc1"));
     RUN(run_gemm(e, t, EPI_BIAS_RESID, t.mlp, w.w2, t.x, w.b2, M, D, F, D, 0, s, "fc2"));
   }
@@ -374,11 +397,12 @@ int run_last_block_pooled(plipmi_engine* e, Tower& t, int B, int causal, const i
   const int impl = (&t == &e->vis) ? e->attn_impl_vis : e->attn_impl_txt;
   LnArgs use; use.stats = t.st; use.ns = D / kLnSlice; use.inv_d = 1.0f / (float)D; use.eps = e->cfg.layer_norm_eps;
   const int* cu = t.packed ? t.cu : nullptr;
+  RUN(enter_block(e, t, t.L - 1, M, s));
   RUN(run_gemm(e, t, EPI_BIAS_LN, t.h, w.wqkv, t.qkv, w.bqkv, M, 3 * D, D, 3 * D, 0, s, "qkv", &use, t.packed ? t.mdev : nullptr));
   { Scope sc(e, s, impl ? "attention_mfma" : "attention_valu", 4.0 * B * t.H * (double)t.S * t.S * 64, (double)M * 4 * D * e->esz);
-    HIP_TRY(launch_attention(t.qkv, t.att, t.dtype, B, t.S, t.H, causal, key_mask, impl, s, cu)); }
+    HIP_TRY(launch_attention(t.qkv, t.att, t.cur, B, t.S, t.H, causal, key_mask, impl, s, cu)); }
   { Scope sc(e, s, "pool_gather", 0, (double)B * D * (2 * e->esz + 8));
-    HIP_TRY(launch_pool_gather(t.att, t.h, t.lo, t.S, D, ids, eos_id, t.attp, t.xp, B, t.dtype, s, cu)); }
+    HIP_TRY(launch_pool_gather(t.att, t.h, t.lo, t.S, D, ids, eos_id, t.attp, t.xp, B, t.cur, s, cu)); }
   LnArgs emit; emit.xb_out = t.hp; emit.st_out = t.stp;
   RUN(run_gemm(e, t, EPI_RESID_EMIT, t.attp, w.wo, t.xp, w.bo, B, D, D, D, 0, s, "~out_proj_pooled", &emit));
   use.stats = t.stp;
@@ -391,6 +415,7 @@ int run_last_block_pooled(plipmi_engine* e, Tower& t, int B, int causal, const i
 int vision_embed(plipmi_engine* e, const float* pixels, const uint8_t* tiles_u8, int B, hipStream_t s) {
   const plipmi_config& g = e->cfg;
   Tower& t = e->vis;
+  t.cur = t.planes = t.layer_dtype(0);
   if (tiles_u8) {
     Scope sc(e, s, "unfold_patches_u8", 0, (double)B * 3 * g.image_size * g.image_size + (double)B * e->np * e->kpad * e->esz);
     HIP_TRY(launch_unfold_patches_u8(tiles_u8, e->patches, t.dtype, B, g.image_size, g.patch_size, e->kpad, s));
@@ -412,16 +437,17 @@ int vision_embed(plipmi_engine* e, const float* pixels, const uint8_t* tiles_u8,
 
 int text_embed(plipmi_engine* e, const int64_t* ids, int B, hipStream_t s, int eos_id = -1) {
   Tower& t = e->txt;
+  t.cur = t.planes = t.layer_dtype(0);     // the embedding kernel emits the planes in the first block's format
   if (t.packed) {
     { Scope sc(e, s, "text_pack", 0, (double)B * t.S * 12);
       HIP_TRY(launch_text_pack(ids, B, t.S, eos_id, t.cu, t.rowmap, t.mdev, s)); }
     Scope sc(e, s, "text_embed", 0, (double)B * t.S * t.D * 8.2);
     HIP_TRY(launch_text_embed_emit_packed(ids, e->tok, e->tpos, t.h, t.lo, t.st, t.rowmap, t.mdev, B * t.S, t.S, t.D,
-                                          e->cfg.vocab_size, e->bad_id, t.dtype, s));
+                                          e->cfg.vocab_size, e->bad_id, t.planes, s));
     return PLIPMI_OK;
   }
   Scope sc(e, s, "text_embed", 0, (double)B * t.S * t.D * (e->ln_fold ? 8.2 : 8.0));
-  if (e->ln_fold) HIP_TRY(launch_text_embed_emit(ids, e->tok, e->tpos, t.h, t.lo, t.st, B, t.S, t.D, e->cfg.vocab_size, e->bad_id, t.dtype, s));
+  if (e->ln_fold) HIP_TRY(launch_text_embed_emit(ids, e->tok, e->tpos, t.h, t.lo, t.st, B, t.S, t.D, e->cfg.vocab_size, e->bad_id, t.planes, s));
   else HIP_TRY(launch_text_embed(ids, e->tok, e->tpos, t.x, B, t.S, t.D, e->cfg.vocab_size, e->bad_id, s));
   return PLIPMI_OK;
 }
@@ -540,6 +566,8 @@ int plipmi_create(const plipmi_config* cfg, const plipmi_weights* w, void* strea
     return fail(PLIPMI_ERR_INVALID, "unknown bits in plipmi_config.flags (0x%x)", (unsigned)g.flags);
   if ((g.flags & PLIPMI_FLAG_TEXT_TOWER_F16) && g.compute_dtype != PLIPMI_BF16)
     return fail(PLIPMI_ERR_INVALID, "PLIPMI_FLAG_TEXT_TOWER_F16 is a mode of the bf16 engine (compute_dtype PLIPMI_BF16)");
+  if (g.text_f16_layers < 0 || g.text_f16_layers > g.t_layers || (g.text_f16_layers > 0 && g.compute_dtype != PLIPMI_BF16))
+    return fail(PLIPMI_ERR_INVALID, "text_f16_layers = %d: 0 .. t_layers leading text blocks, bf16 engine only", g.text_f16_layers);
   if (g.v_heads <= 0 || g.t_heads <= 0 || g.v_width != g.v_heads * 64 || g.t_width != g.t_heads * 64)
     return fail(PLIPMI_ERR_INVALID, "head_dim must be 64 (v_width=%d/%d heads, t_width=%d/%d heads)", g.v_width,
                 g.v_heads, g.t_width, g.t_heads);
@@ -566,6 +594,9 @@ int plipmi_create(const plipmi_config* cfg, const plipmi_weights* w, void* strea
   e->esz = e->half() ? 2 : 4;
   e->vis.dtype = e->dtype;
   e->txt.dtype = (g.flags & PLIPMI_FLAG_TEXT_TOWER_F16) ? PLIPMI_F16 : e->dtype;
+  e->txt.lead_f16 = e->txt.dtype == PLIPMI_BF16 ? g.text_f16_layers : 0;
+  e->vis.cur = e->vis.planes = e->vis.dtype;
+  e->txt.cur = e->txt.planes = e->txt.layer_dtype(0);
   e->ln_fold = e->half() && !(g.flags & PLIPMI_FLAG_SEPARATE_LAYERNORM);
   e->pooled_last = e->ln_fold && !(g.flags & PLIPMI_FLAG_DENSE_LAST_BLOCK);
   e->text_pack = e->pooled_last && (g.flags & PLIPMI_FLAG_PACK_CAPTIONS);
@@ -899,6 +930,12 @@ int plipmi_check_async(plipmi_handle h) {
   if (!h) return fail(PLIPMI_ERR_INVALID, "null handle");
   return check_async(h);
 }
+int plipmi_recode_planes(void* hi, void* lo, size_t n, int from_dtype, int to_dtype, void* stream) {
+  if (!hi || !lo) return fail(PLIPMI_ERR_INVALID, "null planes");
+  HIP_TRY(launch_recode_planes(hi, lo, n, from_dtype, to_dtype, reinterpret_cast<hipStream_t>(stream)));
+  return PLIPMI_OK;
+}
+
 int plipmi_gemm_variant_built(int dtype, int variant) {
   if (dtype != PLIPMI_F32 && dtype != PLIPMI_BF16 && dtype != PLIPMI_F16) return 0;
   return gemm_variant_is_built(dtype, variant) ? 1 : 0;

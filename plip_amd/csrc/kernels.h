@@ -19,6 +19,8 @@ hipError_t launch_layernorm_emit(const float* x, const float* g, const float* b,
                                  float eps, int dtype, hipStream_t s);
 // the two planes back to plain fp32 (n % 4 == 0 elements)
 hipError_t launch_join_planes(const void* hi, const void* lo, float* x, size_t n, int dtype, hipStream_t s);
+// {hi, lo} planes of n values from one 16-bit operand type's split format to the other's (1 bf16, 2 f16), in place, exact
+hipError_t launch_recode_planes(void* hi, void* lo, size_t n, int from_dtype, int to_dtype, hipStream_t s);
 // weight folding at plipmi_create: Wf[n,:] = H(pre * (W[n,:] * g - mean_k(W[n,:] * g))), c2[n] = pre * (W[n,:].b + bias[n])
 hipError_t launch_fold_ln(const float* W, const float* bias, const float* g, const float* b, void* Wf, float* c2, int rows,
                           int K, float pre, int dtype, hipStream_t s);

@@ -195,6 +195,26 @@ hipError_t launch_join_planes(const void* hi, const void* lo, float* x, size_t n
   return hipGetLastError();
 }
 
+// the residual planes from one operand type's split format to the other's, in place: both hold the fp32 value exactly
+// (common.h split_f32), so this is a change of code, not of value; hi becomes the next block's A operand
+template <typename HF, typename HT>
+__global__ __launch_bounds__(256) void recode_planes_kernel(unsigned short* __restrict__ hi, unsigned short* __restrict__ lo, size_t n4) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const float4 v = load4_split<HF>(hi + i * 4, lo + i * 4);
+  store4_split<HT>(hi + i * 4, lo + i * 4, v.x, v.y, v.z, v.w);
+}
+hipError_t launch_recode_planes(void* hi, void* lo, size_t n, int from_dtype, int to_dtype, hipStream_t s) {
+  if (n == 0 || from_dtype == to_dtype) return hipSuccess;
+  if (n % 4 || (from_dtype != 1 && from_dtype != 2) || (to_dtype != 1 && to_dtype != 2)) return hipErrorInvalidValue;
+  const dim3 grid((unsigned)((n / 4 + 255) / 256));
+  if (from_dtype == 2)
+    hipLaunchKernelGGL((recode_planes_kernel<f16_t, bf16_t>), grid, dim3(256), 0, s, (unsigned short*)hi, (unsigned short*)lo, n / 4);
+  else
+    hipLaunchKernelGGL((recode_planes_kernel<bf16_t, f16_t>), grid, dim3(256), 0, s, (unsigned short*)hi, (unsigned short*)lo, n / 4);
+  return hipGetLastError();
+}
+
 template <typename H>
 __global__ __launch_bounds__(256) void fold_ln_kernel(const float* __restrict__ W, const float* __restrict__ bias,
                                                       const float* __restrict__ g, const float* __restrict__ b,

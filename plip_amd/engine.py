@@ -17,6 +17,13 @@ _DTYPES = {"fp32": _lib.F32, "f32": _lib.F32, "float32": _lib.F32, torch.float32
            "bf16": _lib.BF16, "bfloat16": _lib.BF16, torch.bfloat16: _lib.BF16,
            # IEEE half operands: same matrix-core rate as bf16, 8x smaller operand rounding; the reference's own GPU dtype
            "f16": _lib.F16, "fp16": _lib.F16, "float16": _lib.F16, "half": _lib.F16, torch.float16: _lib.F16}
+# bf16 engine: leading text blocks that run on f16 operands by default.  The bf16 engine's cosine error is mostly operand
+# rounding in the FIRST text blocks (the residual stream is small there, so a block's rounding error is large against it:
+# profiles/r04_text_layer_precision.txt); two f16 blocks of 24 take the bs=256 fixture from 8.3e-4 to 6.3e-4 of the 1e-3 bar
+# (heavy-tailed checkpoint 8.4e-4 -> 4.7e-4) for 1.5 % of the step (profiles/r04_text_f16_layers.txt).
+# text_f16_layers=0 is the pure bf16 engine, =t_layers the TEXT_TOWER_F16 one.
+DEFAULT_TEXT_F16_LAYERS = 2
+
 _TORCH_DTYPE = {_lib.F32: torch.float32, _lib.BF16: torch.bfloat16, _lib.F16: torch.float16}
 
 
@@ -34,10 +41,12 @@ class Engine:
     def __init__(self, cfg: PlipConfig, state_dict: Mapping[str, object], device="cuda:0", dtype="bf16",
                  max_batch: int = 256, *, ln_fold: bool = True, pooled_last_block: bool = True,
                  pack_captions: bool = False, mfma_attention: bool = True, graph_batch: Optional[int] = None,
-                 text_f16: bool = False):
+                 text_f16: bool = False, text_f16_layers: Optional[int] = None):
         """``ln_fold`` / ``pooled_last_block`` / ``mfma_attention`` = False select the A/B forms of the 16-bit engines
         (separate LayerNorm kernels, the last block on every token, the exact VALU attention kernel);
         ``text_f16`` (bf16 engine only): the text tower runs on IEEE-half operands, the image tower stays bf16;
+        ``text_f16_layers`` (bf16 engine only): only that many LEADING text blocks do (None = the engine default,
+        ``DEFAULT_TEXT_F16_LAYERS``; 0 = a pure bf16 engine) -- plipmi_config.text_f16_layers;
         ``graph_batch``: None = default small-batch hipGraph replay (<= 32 samples), 0 = never, n = up to n samples.
         All of it is per-handle configuration (include/plipmi.h plipmi_config.flags): no environment variables."""
         cfg.validate()
@@ -56,6 +65,11 @@ class Engine:
                       (_lib.FLAG_PACK_CAPTIONS if pack_captions else 0) | (0 if mfma_attention else _lib.FLAG_VALU_ATTENTION) |
                       (_lib.FLAG_TEXT_TOWER_F16 if text_f16 else 0))
         gb = 0 if graph_batch is None else (-1 if int(graph_batch) <= 0 else int(graph_batch))
+        if text_f16_layers is None:
+            text_f16_layers = min(DEFAULT_TEXT_F16_LAYERS, cfg.t_layers) if (self.dtype_code == _lib.BF16 and not text_f16) else 0
+        if text_f16_layers and (self.dtype_code != _lib.BF16 or text_f16):
+            raise ValueError("text_f16_layers is a mode of the bf16 engine (and excludes text_f16, which is all of them)")
+        self.text_f16_layers = int(text_f16_layers)
         self.max_batch = int(max_batch)
         self.lib = _lib.load()
         self._h = C.c_void_p()
@@ -70,7 +84,8 @@ class Engine:
                 dev[k] = t.detach().to(device=self.device, dtype=torch.float32).contiguous()
             c = _lib.Config(cfg.image_size, cfg.patch_size, cfg.v_width, cfg.v_layers, cfg.v_heads, cfg.v_mlp,
                             cfg.vocab_size, cfg.context_length, cfg.t_width, cfg.t_layers, cfg.t_heads, cfg.t_mlp,
-                            cfg.projection_dim, cfg.layer_norm_eps, self.dtype_code, self.max_batch, self.flags, gb)
+                            cfg.projection_dim, cfg.layer_norm_eps, self.dtype_code, self.max_batch, self.flags, gb,
+                            self.text_f16_layers)
             w = _lib.Weights()
 
             def layers(prefix, n):
@@ -457,6 +472,18 @@ def join_planes(hi: torch.Tensor, lo: torch.Tensor) -> torch.Tensor:
     u = ((h << 16) + lo.to(torch.int64)) & 0xFFFFFFFF
     u = torch.where(u >= 2 ** 31, u - 2 ** 32, u)
     return u.to(torch.int32).view(torch.float32)
+
+
+def recode_planes(hi: torch.Tensor, lo: torch.Tensor, to_dtype) -> tuple:
+    """The residual planes re-coded in place for the other 16-bit operand type (plipmi_recode_planes): returns (hi, lo) views."""
+    lib = _lib.load()
+    frm = _code(hi.dtype)
+    to = _code(to_dtype)
+    assert hi.is_cuda and lo.is_cuda and hi.is_contiguous() and lo.is_contiguous() and lo.dtype == torch.int16
+    with torch.cuda.device(hi.device):
+        _lib.check(lib.plipmi_recode_planes(_ptr(hi), _ptr(lo), hi.numel(), frm, to,
+                                            C.c_void_p(torch.cuda.current_stream(hi.device).cuda_stream)), "plipmi_recode_planes")
+    return hi.view(_TORCH_DTYPE[to]), lo
 
 
 def gemm_variant_built(dtype, variant: int) -> bool:

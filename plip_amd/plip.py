@@ -75,14 +75,16 @@ class PLIP:
 
     def __init__(self, model_name: str = None, auth_token=None, *, model: Optional[PlipModel] = None,
                  tokenizer: Optional[Callable] = None, tokenizer_dir: Optional[str] = None, dtype: str = "bf16",
-                 max_batch: int = 256, device: str = "cuda:0", pack_captions: bool = False, text_f16: bool = False):
+                 max_batch: int = 256, device: str = "cuda:0", pack_captions: bool = False, text_f16: bool = False,
+                 text_f16_layers: Optional[int] = None):
         """``model_name``: local HF directory (what ``CLIPModel/CLIPProcessor.from_pretrained`` take, plip.py:26-27)
         or an OpenAI-clip ``.pt`` state dict.  The tokenizer comes from ``tokenizer`` (a callable), else from
         ``tokenizer_dir`` / the model directory when it holds ``vocab.json`` + ``merges.txt``; with neither,
         ``encode_text`` still takes token ids.  ``pack_captions`` (extension, 16-bit engines): the text tower computes only
         the positions up to each caption's EOS token -- bit-identical embeddings, cost proportional to the caption lengths
         instead of the padded 77 (include/plipmi.h ``plipmi_set_text_packing``).  ``dtype``: "bf16" | "f16" | "f32";
-        ``text_f16`` (bf16 engine): the text tower on IEEE-half operands (PLIPMI_FLAG_TEXT_TOWER_F16).  The engine's other
+        ``text_f16`` (bf16 engine): the text tower on IEEE-half operands (PLIPMI_FLAG_TEXT_TOWER_F16); ``text_f16_layers``
+        (bf16 engine): only that many leading text blocks (plipmi_config.text_f16_layers; None = the default).  The engine's other
         per-handle options (ln_fold, pooled_last_block, mfma_attention, graph_batch) are reached by building the model
         explicitly -- ``PLIP(model=PlipModel.from_pretrained(path, **engine_options))``."""
         if not torch.cuda.is_available():
@@ -99,7 +101,8 @@ class PLIP:
             if cand and os.path.exists(os.path.join(cand, "vocab.json")) and os.path.exists(os.path.join(cand, "merges.txt")):
                 tokenizer = load_tokenizer(cand)
         if model is None:
-            model = PlipModel.from_pretrained(model_name, device=device, dtype=dtype, max_batch=max_batch, text_f16=text_f16)
+            model = PlipModel.from_pretrained(model_name, device=device, dtype=dtype, max_batch=max_batch, text_f16=text_f16,
+                                              text_f16_layers=text_f16_layers)
         self.model = model.to(self.device)
         if pack_captions:
             self.model.engine.set_text_packing(True)

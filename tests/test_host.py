@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.plipmi_version() == 300
+    assert lib.plipmi_version() == 310
     names = []
     i = 0
     while lib.plipmi_gemm_variant_name(i):
@@ -50,7 +50,7 @@ def test_struct_layouts_match_header():
     import ctypes as C
 
     from plip_amd import _lib
-    assert C.sizeof(_lib.Config) == 18 * 4
+    assert C.sizeof(_lib.Config) == 19 * 4
     assert C.sizeof(_lib.LayerWeights) == 16 * 8
     assert C.sizeof(_lib.Weights) == 15 * 8
     assert C.sizeof(_lib.KernelStat) == 96 + 8 + 3 * 8

@@ -587,6 +587,46 @@ def sec_cumask():
     model.engine.close()
 
 
+def sec_mixed():
+    """plipmi_config.text_f16_layers: cost and parity of a bf16 engine whose first N text blocks run on f16 operands -- the
+    step interleaved across engines in one process, parity against the HF goldens of both bs=256 checkpoints."""
+    from plip_amd.dist import sharded_pair_logits
+    from oracle.make_golden import case_inputs
+    B = 256
+    cfg, sd, px, ids, mask = _step_inputs(B)
+    arms = [int(a) for a in sys.argv[2:]] or [0, 2, 4, 6, 12]
+    models = {n: PlipModel(cfg, sd, dtype="bf16", max_batch=B, text_f16_layers=n) for n in arms}
+    res = {n: {False: [], True: []} for n in arms}
+    for rep in range(3):
+        for n in arms:
+            for ov in (False, True):
+                res[n][ov].append(_time(lambda: sharded_pair_logits(models[n], px, ids, mask, overlap=ov), iters=20, warm=3))
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "vitb32_b256.npz"))
+    scale = float(np.exp(np.float64(sd["logit_scale"])))
+    base = min(res[arms[0]][True])
+    for n in arms:
+        out = models[n](input_ids=ids, pixel_values=px, attention_mask=mask)
+        cos = np.abs(out.logits_per_image.cpu().numpy() - gold["logits_per_image"]).max() / scale
+        et = np.abs(out.text_embeds.cpu().numpy() - gold["text_embeds"]).max()
+        ei = np.abs(out.image_embeds.cpu().numpy() - gold["image_embeds"]).max()
+        one, two = res[n][False], res[n][True]
+        print(f"first {n:2d} text blocks on f16: one stream {min(one):6.3f} ms  two streams {min(two):6.3f} ms (median {sorted(two)[1]:6.3f}) "
+              f"{B / min(two) * 1e3:8.0f} pairs/s ({100 * (base / min(two) - 1):+5.1f} %)  |  cosine err {cos:.2e}  text_embeds {et:.2e}  image_embeds {ei:.2e}")
+        models[n].engine.close()
+    try:      # the heavy-tailed checkpoint
+        cfg2, sd2, px2, ids2, mask2 = case_inputs("vitb32_b256_heavy")
+        g2 = np.load(os.path.join(ROOT, "tests", "golden", "vitb32_b256_heavy.npz"))
+        s2 = float(np.exp(np.float64(sd2["logit_scale"])))
+        for n in arms:
+            m = PlipModel(cfg2, sd2, dtype="bf16", max_batch=B, text_f16_layers=n)
+            out = m(input_ids=torch.from_numpy(ids2), pixel_values=torch.from_numpy(px2), attention_mask=torch.from_numpy(mask2))
+            print(f"heavy-tailed checkpoint, first {n:2d} on f16: cosine err {np.abs(out.logits_per_image.cpu().numpy() - g2['logits_per_image']).max() / s2:.2e}  "
+                  f"text_embeds {np.abs(out.text_embeds.cpu().numpy() - g2['text_embeds']).max():.2e}  image_embeds {np.abs(out.image_embeds.cpu().numpy() - g2['image_embeds']).max():.2e}")
+            m.engine.close()
+    except Exception as e:
+        print("heavy-tailed fixture:", repr(e))
+
+
 def sec_cold():
     """The production GEMMs with operands that are NOT resident in the 256 MiB Infinity Cache: every launch takes its A
     operand and its residual planes / output from the next of a ring of buffers (> 600 MB in total), as the engine's
@@ -753,5 +793,5 @@ def sec_e2e():
 if __name__ == "__main__":
     t0 = time.time()
     {"gemm": sec_gemm, "attn": sec_attn, "tiny": sec_tiny, "vitb32": sec_vitb32, "gemmbench": sec_gemmbench, "lnbench": sec_lnbench, "latency": sec_latency, "libgemm": sec_libgemm, "tiles": sec_tiles, "parity": sec_parity, "sustain": sec_sustain, "power": sec_power, "cold": sec_cold, "towerswap": sec_towerswap, "e2e": sec_e2e, "gemmone": sec_gemmone, "policy": sec_policy, "ldpad": sec_ldpad, "gemmtrace": sec_gemmtrace,
-     "overlap": sec_overlap, "stepab": sec_stepab, "cumask": sec_cumask}[sys.argv[1]]()
+     "overlap": sec_overlap, "stepab": sec_stepab, "cumask": sec_cumask, "mixed": sec_mixed}[sys.argv[1]]()
     print(f"[{sys.argv[1]} done in {time.time() - t0:.1f} s]")
