@@ -190,6 +190,15 @@ int plipmi_check_async(plipmi_handle h);
  * zero_shot_classification runs both towers at batch 8 (plip.py:90-91), where the step is launch-bound. */
 int plipmi_set_graph_batch(plipmi_handle h, int max_batch);
 
+/* Latency path (16-bit engines; OFF by default).  The big GEMM tiles walk K serially whatever M is -- fc2 at batch 8 is 48
+ * dependent K tiles for 24 workgroups -- so after plipmi_set_latency_batch(h, n) an encode call of at most n samples runs every
+ * GEMM of its tower on the split-K small-M kernel instead (csrc/gemm_skinny.hip): pair latency 1.16 -> 0.79 ms at batch 1,
+ * 1.32 -> 1.09 ms at batch 8 (it loses from batch 16 on).  Same arithmetic, another fp32 summation order -- which moves the
+ * roundings of the 16-bit activations: embeddings of the two regimes differ by up to 6e-4 (both inside the parity bar).
+ * INSIDE a regime a row's embedding does not depend on the batch it arrives in, bit for bit; with the path off (n = 0, the
+ * default) that holds for every batch size. */
+int plipmi_set_latency_batch(plipmi_handle h, int max_batch);
+
 /* Caption packing (16-bit engines, off by default; PLIPMI_FLAG_PACK_CAPTIONS starts with it on).  CLIPTextTransformer is causal and
  * pools the EOS row only (modeling_clip.py:543-581), so the positions behind a caption's EOS token -- the tokenizer's
  * padding to 77 -- cannot influence text_embeds; the reference computes them anyway.  With packing on, plipmi_encode_text

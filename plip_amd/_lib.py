@@ -57,6 +57,7 @@ SYMBOLS = {
     "plipmi_encode_image_u8": (_i, [_vp, _vp, _i, _vp, _i, _vp]),
     "plipmi_encode_text": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _vp]),
     "plipmi_check_async": (_i, [_vp]),
+    "plipmi_set_latency_batch": (_i, [_vp, _i]),
     "plipmi_set_graph_batch": (_i, [_vp, _i]),
     "plipmi_l2_normalize": (_i, [_vp, _vp, _i, _i, _vp]),
     "plipmi_logits": (_i, [_vp, _vp, _i, _vp, _i, _i, _f, _vp, _vp, _vp, _vp]),

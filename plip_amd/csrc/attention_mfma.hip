@@ -231,6 +231,9 @@ __global__ __launch_bounds__(64 * KT) __attribute__((amdgpu_waves_per_eu(4, 4)))
 // (B*H, ceil(S/128)).  Because a lane owns one query column in BOTH accumulator layouts (scores^T and O^T), the
 // running max / running sum / rescale of the online softmax are per-lane scalars: no cross-lane traffic beyond the
 // one lane^32 exchange per chunk.  K and V^T chunks are staged through LDS exactly like the short-sequence kernel.
+// Round 4: the NEXT chunk's K / V rows travel global -> registers while the current chunk is multiplied (32 VGPRs of
+// staging; the LDS write waits behind the chunk's barrier), so a workgroup no longer stands still for a global round trip
+// per chunk; and the short kernel's per-score arithmetic -- one 32-bit mask word per tile, additive -inf, exp as FMA + v_exp_f32.
 // ---------------------------------------------------------------------------------------------
 template <typename HT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void attention_flash_kernel(const HT* __restrict__ qkv, HT* __restrict__ out,
@@ -239,6 +242,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   using X8 = typename half_traits<HT>::x8;
   using X4 = typename half_traits<HT>::x4;
   constexpr int SP = 128;
+  constexpr int NP = SP * 8 / 256;   // 16-byte pieces of a chunk's K (and V) rows per thread: 4
+  constexpr float kLog2e = 1.4426950408889634f;
   __shared__ __attribute__((aligned(16))) char Qs[SP * 128];
   __shared__ __attribute__((aligned(16))) char Ks[SP * 128];
   __shared__ __attribute__((aligned(16))) char Vs[2 * SP * 64];
@@ -249,14 +254,41 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   const int D = H * 64, ld = 3 * D;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const HT* base = qkv + (size_t)b * S * ld + h * 64;
+  const HT* base = qkv + (size_t)b * S * ld + h * 64;     // wave-uniform (blockIdx only)
 
-  const int qrows = min(SP, (S - qbase + 31) & ~31);  // 32-row tiles that hold at least one real query
-  for (int e = tid; e < qrows * 8; e += 256) {  // the query block, whole 128-byte lines, GEMM swizzle
-    const int row = e >> 3, c = e & 7;
-    const int rg = qbase + row < S ? qbase + row : S - 1;
-    const u32x4 q16 = *reinterpret_cast<const u32x4*>(base + (size_t)rg * ld + c * 8);
-    *reinterpret_cast<u32x4*>(Qs + row * 128 + ((c ^ ((row >> 1) & 7)) << 4)) = q16;
+  int nchunks = (S + SP - 1) / SP;
+  if (causal) nchunks = min(nchunks, (qbase + SP - 1) / SP + 1);  // chunks entirely above the diagonal
+
+  // this thread's pieces of a chunk: rows (tid + i*256) >> 3, 16-byte column c = tid & 7 (the same for every i)
+  u32x4 kreg[NP], vreg[NP];
+  auto fetch = [&](int kbase) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int row = (tid + i * 256) >> 3, c = tid & 7;
+      const int rg = kbase + row < S ? kbase + row : S - 1;       // rows past the sequence end re-read the last row (masked)
+      // wave-uniform base + 32-bit lane offset (a sample's qkv rows span < 4 GiB): scalar-base loads, no 64-bit lane arithmetic
+      const unsigned off = ((unsigned)rg * (unsigned)ld + (unsigned)(c * 8)) * (unsigned)sizeof(HT);
+      kreg[i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(base + D) + off);
+      vreg[i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(base + 2 * D) + off);
+    }
+  };
+  fetch(0);
+
+  {  // the query block, whole 128-byte lines, GEMM swizzle: all four loads of a thread in flight together (rows past the
+     // sequence end re-read its last row; their outputs are never stored)
+    u32x4 q16[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int row = (tid + i * 256) >> 3, c = tid & 7;
+      const int rg = qbase + row < S ? qbase + row : S - 1;
+      q16[i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(base) +
+                                               ((unsigned)rg * (unsigned)ld + (unsigned)(c * 8)) * (unsigned)sizeof(HT));
+    }
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int row = (tid + i * 256) >> 3, c = tid & 7;
+      *reinterpret_cast<u32x4*>(Qs + row * 128 + ((c ^ ((row >> 1) & 7)) << 4)) = q16[i];
+    }
   }
 
   const int q0 = wave * 32;  // inside the block
@@ -274,8 +306,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     for (int r = 0; r < 16; ++r) acc[dt][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;  // l_run: this lane's half of the row sum
 
-  int nchunks = (S + SP - 1) / SP;
-  if (causal) nchunks = min(nchunks, (qbase + SP - 1) / SP + 1);  // chunks entirely above the diagonal
   for (int ch = 0; ch < nchunks; ++ch) {
     const int kbase = ch * SP;
     __syncthreads();  // everyone is done reading the previous chunk
@@ -285,16 +315,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       const unsigned long long bits = __ballot(ok);
       if (lane == 0) mk[wave] = bits;
     }
-    const int krows = min(SP, (S - kbase + 31) & ~31);  // key tiles past the sequence end are never read
-    for (int e = tid; e < krows * 8; e += 256) {
-      const int row = e >> 3, c = e & 7;
-      const int rg = kbase + row < S ? kbase + row : S - 1;
-      const HT* src = base + (size_t)rg * ld + c * 8 + D;
-      const u32x4 k16 = *reinterpret_cast<const u32x4*>(src);
-      const u32x4 v16 = *reinterpret_cast<const u32x4*>(src + D);
-      *reinterpret_cast<u32x4*>(Ks + row * 128 + ((c ^ ((row >> 1) & 7)) << 4)) = k16;
-      *reinterpret_cast<u32x4*>(Vs + (c >> 2) * (SP * 64) + row * 64 + (c & 3) * 16) = v16;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {   // the chunk fetched during the previous iteration (or the prologue) -> LDS
+      const int row = (tid + i * 256) >> 3, c = tid & 7;
+      *reinterpret_cast<u32x4*>(Ks + row * 128 + ((c ^ ((row >> 1) & 7)) << 4)) = kreg[i];
+      *reinterpret_cast<u32x4*>(Vs + (c >> 2) * (SP * 64) + row * 64 + (c & 3) * 16) = vreg[i];
     }
+    if (ch + 1 < nchunks) fetch(kbase + SP);   // in flight while this chunk is multiplied
     __syncthreads();
     if (!active) continue;
     if (ch == 0) {
@@ -303,14 +330,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         qf[ks] = *reinterpret_cast<const u32x4*>(Qs + (q0 + lrow) * 128 + (((ks * 2 + hi) ^ lsw) << 4));
     }
     // two 64-key halves per staged chunk: 32 score registers live instead of 64 (3 waves/SIMD), one online-softmax
-    // update per half.  Validity bits of the half, pre-shifted so that bit (r&3)+8(r>>2) of tile t's word is
-    // this lane's key slot r.
+    // update per half
     const unsigned long long mhalf[2] = {mk[0], mk[1]};
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
       if (kbase + 64 * hf >= S) break;                           // wave-uniform: past the sequence end
       if (causal && kbase + 64 * hf > qbase + q0 + 31) break;  // wave-uniform: the rest is above the diagonal
-      const unsigned vw[2] = {(unsigned)(mhalf[hf] & 0xffffffffull) >> (4 * hi), (unsigned)(mhalf[hf] >> 32) >> (4 * hi)};
       f32x16 sc[2];
       float cmax = -INFINITY;
 #pragma unroll
@@ -326,24 +351,41 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             sc[tt] = half_traits<HT>::mfma32(__builtin_bit_cast(X8, kf), __builtin_bit_cast(X8, qf[ks]), sc[tt]);
           }
         }
-        const int kfirst = kbase + 32 * t + 4 * hi;  // key of slot 0
+        // the keys this lane may use in the tile as ONE 32-bit word (validity AND causal limit), then per score a 1-bit field
+        // extract, an AND that makes it 0.0 / -inf, an add -- the short kernel's form (see there for why not a bit select)
+        unsigned bits = live ? (unsigned)(mhalf[hf] >> (32 * tt)) : 0u;
+        if (causal) {
+          const int d = qidx - (kbase + 32 * t);
+          bits &= d < 0 ? 0u : (d >= 31 ? 0xffffffffu : (2u << d) - 1u);
+        }
+        if (__ballot(bits != 0xffffffffu) == 0ull) {
+          // every key of the tile is usable by every query of the wave (the common case away from the sequence end and the
+          // diagonal): no masking arithmetic at all
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int slot = (r & 3) + 8 * (r >> 2);
-          const bool ok = live && ((vw[tt] >> slot) & 1u) && (!causal || kfirst + slot <= qidx);
-          sc[tt][r] = ok ? sc[tt][r] : -INFINITY;
-          cmax = fmaxf(cmax, sc[tt][r]);
+          for (int r = 0; r < 16; ++r) cmax = fmaxf(cmax, sc[tt][r]);
+        } else {
+          const unsigned nbits = ~(bits >> (4 * hi));        // 1 = masked; slot r holds key 32t + 4hi + (r&3) + 8(r>>2)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const unsigned m = (unsigned)__builtin_amdgcn_sbfe((int)nbits, (r & 3) + 8 * (r >> 2), 1);
+            sc[tt][r] += __builtin_bit_cast(float, m & 0xff800000u);
+            cmax = fmaxf(cmax, sc[tt][r]);
+          }
         }
       }
       cmax = fmaxf(cmax, __shfl_xor(cmax, 32, 64));
       const float m_new = fmaxf(m_run, cmax);
       const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-      const float scale = (m_run == -INFINITY) ? 0.f : __expf(m_run - m_use);  // acc, l_run are 0 while m_run = -inf
+      const float m2 = m_use * kLog2e;
+      const float scale = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(fmaf(m_run, kLog2e, -m2));  // acc, l_run are 0 while m_run = -inf
+      const bool moved = m_new != m_run;    // (NaN-free: -inf != -inf is false, a first finite maximum is a move)
       m_run = m_new;
+      if (__ballot(moved) != 0ull) {        // wave-uniform: once the running maxima have settled the 32 rescaling multiplies go
 #pragma unroll
-      for (int dt = 0; dt < 2; ++dt)
+        for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[dt][r] *= scale;
+          for (int r = 0; r < 16; ++r) acc[dt][r] *= scale;
+      }
       float csum = 0.f;
 #pragma unroll
       for (int tt = 0; tt < 2; ++tt) {
@@ -354,7 +396,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
           X8 pf;
 #pragma unroll
           for (int jj = 0; jj < 8; ++jj) {
-            const float pv = __expf(sc[tt][8 * s2 + jj] - m_use);
+            const float pv = __builtin_amdgcn_exp2f(fmaf(sc[tt][8 * s2 + jj], kLog2e, -m2));   // exp(x - m): one FMA + v_exp_f32
             csum += pv;
             pf[jj] = (HT)pv;
           }

@@ -27,6 +27,12 @@
 #ifndef PLIPMI_DEFAULT_ATTENTION
 #define PLIPMI_DEFAULT_ATTENTION 1
 #endif
+// Batches of at most this many samples take the latency path (split-K small-M GEMMs) -- 0: nobody does unless the caller asks
+// (plipmi_set_latency_batch).  It is faster up to batch 8 (pair latency 1.16 -> 0.79 ms at batch 1, 1.32 -> 1.09 ms at 8;
+// slower from 16 on: profiles/r04_small_batch_latency.txt), but its other summation order moves the 16-bit activations'
+// roundings: embeddings of the two regimes differ by up to 6e-4, and by default a row's embedding is the same bits whatever
+// batch it arrives in -- which the host loops' coalescing (plip_amd/plip.py) and the caches' consumers rely on.
+static constexpr int kLatencyBatch = 0;
 
 using namespace plipmi;
 
@@ -62,6 +68,9 @@ struct Tower {
   // residual planes {h, lo} currently hold: a block whose type differs re-codes them first (recode_planes).
   int lead_f16 = 0;
   int cur = 0, planes = 0;
+  // latency path (set per forward): the batch is small (<= plipmi_engine::latency_batch samples), so every GEMM of the tower
+  // takes the split-K small-M kernel instead of walking K serially on a handful of big tiles
+  bool small = false;
   int layer_dtype(int l) const { return l < lead_f16 ? PLIPMI_F16 : dtype; }
   std::vector<LayerW> layers;
   // workspace
@@ -117,6 +126,10 @@ struct plipmi_engine {
   bool text_pack = false;
   // small-batch hipGraph replay (plipmi_config.graph_batch, plipmi_set_graph_batch): batches of at most this many samples
   int graph_batch = 0;
+  // latency path: batches of at most this many samples run their GEMMs on the split-K small-M kernel (16-bit engines).  The
+  // reference drives zero_shot_classification / retrieval at batch 8 (plip.py:90-91,112).  Results of the two regimes differ
+  // by fp32 summation order only; inside a regime a row's embedding does not depend on the batch it arrives in.
+  int latency_batch = 0;
   std::map<std::tuple<int, int, int, int, int>, GraphEntry> graphs;
   void* g_vin = nullptr;      // staged image input (fp32 pixels or uint8 tiles) [graph_batch_cap, 3, H, W] x 4 B
   int64_t* g_tin = nullptr;   // staged ids   [graph_batch_cap, ctx]
@@ -299,8 +312,9 @@ int run_gemm(plipmi_engine* e, const Tower& t, int epi, const void* A, const voi
     p.ln_stats = ln->stats; p.ln_ns = ln->ns; p.ln_inv_d = ln->inv_d; p.ln_eps = ln->eps;
     p.xb_out = ln->xb_out; p.st_out = ln->st_out; p.lo_io = ln->lo_io;
   }
-  const bool skinny = role[0] == '~';     // '~role': pooled-row GEMM of the last block -> the small-M split-K kernel when it fits
+  bool skinny = role[0] == '~';     // '~role': pooled-row GEMM of the last block -> the small-M split-K kernel when it fits
   if (skinny) ++role;
+  skinny = skinny || (t.small && !m_dev);   // latency path: the whole tower of a small batch (packed rows keep the big kernels)
   const char* name = "gemm_nt";
   // algorithmic bytes: operands once, output once (bf16 outputs 2 B, fp32 residual read + written -- as one array or as two
   // 16-bit planes --, + bf16 copy when EPI_RESID_EMIT writes one)
@@ -493,6 +507,7 @@ int check_batch(plipmi_engine* e, int B) {
 // the three tower forwards, on whatever pointers they are given (caller's, or the staging buffers under capture)
 int image_forward(plipmi_handle h, const float* pixels, const uint8_t* tiles, int B, float* out, int normalize,
                          hipStream_t s) {
+  h->vis.small = h->half() && B <= h->latency_batch;
   RUN(vision_embed(h, pixels, tiles, B, s));
   if (h->pooled_last) {
     RUN(run_layers(h, h->vis, B, h->vis.L - 1, 0, nullptr, s, /*more_follow=*/true));
@@ -508,6 +523,7 @@ int text_forward(plipmi_handle h, const int64_t* ids, const int64_t* mask, int B
   // they are left out of every kernel.  Needs the pooled last block (no every-token consumer) and the bf16 MFMA attention.
   struct Unpack { Tower& t; ~Unpack() { t.packed = false; } } unpack{h->txt};
   h->txt.packed = h->text_pack && h->ln_fold && h->pooled_last && h->attn_impl_txt == 1 && h->txt.S <= 128;
+  h->txt.small = h->half() && B <= h->latency_batch;
   RUN(text_embed(h, ids, B, s, eos_token_id));
   if (h->pooled_last) {
     RUN(run_layers(h, h->txt, B, h->txt.L - 1, 1, mask, s, /*more_follow=*/true));
@@ -600,6 +616,7 @@ int plipmi_create(const plipmi_config* cfg, const plipmi_weights* w, void* strea
   e->ln_fold = e->half() && !(g.flags & PLIPMI_FLAG_SEPARATE_LAYERNORM);
   e->pooled_last = e->ln_fold && !(g.flags & PLIPMI_FLAG_DENSE_LAST_BLOCK);
   e->text_pack = e->pooled_last && (g.flags & PLIPMI_FLAG_PACK_CAPTIONS);
+  e->latency_batch = e->half() ? kLatencyBatch : 0;
   e->graph_batch_cap = std::min(g.max_batch, 32);
   e->graph_batch = g.graph_batch < 0 ? 0 : g.graph_batch == 0 ? e->graph_batch_cap : std::min(g.graph_batch, e->graph_batch_cap);
   e->np = tokens - 1;
@@ -717,6 +734,17 @@ int plipmi_set_graph_batch(plipmi_handle h, int max_batch) {
   return PLIPMI_OK;
 }
 
+int plipmi_set_latency_batch(plipmi_handle h, int max_batch) {
+  if (!h) return fail(PLIPMI_ERR_INVALID, "null handle");
+  const int v = h->half() ? std::max(0, max_batch) : 0;
+  if (v != h->latency_batch) {       // captured forwards hold the other regime's launches
+    for (auto& kv : h->graphs) if (kv.second.exec) hipGraphExecDestroy(kv.second.exec);
+    h->graphs.clear();
+  }
+  h->latency_batch = v;
+  return PLIPMI_OK;
+}
+
 int plipmi_set_text_packing(plipmi_handle h, int on) {
   if (!h) return fail(PLIPMI_ERR_INVALID, "null handle");
   if (on && !h->pooled_last)
@@ -737,6 +765,7 @@ int plipmi_debug_hidden(plipmi_handle h, int tower, int layer, const void* input
   Tower& t = tower == PLIPMI_VISION ? h->vis : h->txt;
   if (tower != PLIPMI_VISION && tower != PLIPMI_TEXT) return fail(PLIPMI_ERR_INVALID, "tower must be 0 or 1");
   if (layer < 0 || layer > t.L) return fail(PLIPMI_ERR_INVALID, "layer %d outside [0,%d]", layer, t.L);
+  t.small = h->half() && B <= h->latency_batch;
   if (tower == PLIPMI_VISION) RUN(vision_embed(h, reinterpret_cast<const float*>(input), nullptr, B, s));
   else RUN(text_embed(h, reinterpret_cast<const int64_t*>(input), B, s));
   RUN(run_layers(h, t, B, layer, tower == PLIPMI_TEXT, nullptr, s));

@@ -1,6 +1,8 @@
 // gemm_inst.h -- per-dtype instantiation table of gemm_nt_kernel (included by gemm_f32.hip / gemm_bf16.hip /
 // gemm_f16.hip so the three compile in parallel).
 #pragma once
+#include <mutex>
+
 #include "gemm.h"
 
 namespace plipmi {
@@ -13,12 +15,13 @@ int launch_tiled(const GemmParams& p, hipStream_t stream) {
   // + rstd per tile row for the LayerNorm-folded epilogues
   constexpr int LDS = NSTAGE * (BM + BN) * 128 + (epi_is_ln(EPI) ? BM * 4 : 0);
   auto kern = gemm_nt_kernel<T, BM, BN, WM, WN, EPI, SCHED, ADDR, NSTAGE>;
-  static bool attr_set = false;  // one handle per process; set once per instantiation
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  // once per instantiation and process, also when two handles are created from two threads (a handle itself is not thread-safe)
+  static std::once_flag attr_once;
+  static hipError_t attr_rc = hipSuccess;
+  std::call_once(attr_once, [&]() {
+    attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+  });
+  if (attr_rc != hipSuccess) return (int)attr_rc;
   const int nblk = ((p.M + BM - 1) / BM) * (p.N / BN);
   hipLaunchKernelGGL(kern, dim3(nblk), dim3(NT), LDS, stream, p);
   return (int)hipGetLastError();

@@ -13,10 +13,12 @@
 //   * the same fused epilogues as the big kernel's LayerNorm-folded family: rstd * acc + c2 (-> bf16, optional
 //     QuickGELU), and the in-place fp32 residual update that also emits bf16(x) and the row's {sum, centred M2} of the
 //     64-column slice (= exactly this tile's width).
-// Used by the bf16 engine for the LAST block of each tower, whose out_proj / fc1 / fc2 only ever matter for the pooled row
-// of each sample (engine.hip: run_last_block_pooled): M = batch size.  (Not used for the other blocks of small batches:
-// its K-split summation order differs from the big kernel's, and a row's embedding is kept bit-identical across batch
-// sizes -- every batch size takes the same kernel family per block.)
+// Used by the 16-bit engines (a) for the LAST block of each tower, whose out_proj / fc1 / fc2 only ever matter for the pooled
+// row of each sample (engine.hip: run_last_block_pooled): M = batch size, at every batch size; and (b), round 4, for EVERY GEMM
+// of a small batch (engine.hip: latency path, batches of at most plipmi_engine::latency_batch samples -- the reference drives
+// its heads at batch 8, plip.py:90-91): the big tiles walk K serially whatever M is (fc2: 48 dependent K tiles = 45 us for
+// 400 rows), this kernel splits it 8 ways.  A row's result never depends on the other rows of ITS call, so embeddings are
+// bit-identical across batch sizes within each of the two regimes; between them they differ by fp32 summation order.
 #include "gemm.h"
 
 namespace plipmi {
@@ -100,6 +102,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(const GemmParams p
   }
   const int m = m0 + r, n = n0 + c8;
   const bool in_range = m < p.M;
+  // (EPI_PATCH: p.bias is the position table [(np + 1), N]; its row 0 is read here and unused)
   const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n), b1 = *reinterpret_cast<const float4*>(p.bias + n + 4);
   const float bias[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
   if constexpr (epi_is_colwise(EPI)) {
@@ -112,8 +115,53 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(const GemmParams p
       o[e] = from_f32<T>(y);
     }
     if (in_range) *reinterpret_cast<X8*>(reinterpret_cast<T*>(p.C) + (size_t)m * p.ldc + n) = o;
+  } else if constexpr (EPI == EPI_PATCH) {
+    // patch row m = img * np + pp -> token row img * (np + 1) + 1 + pp of the fp32 embedding rows, plus its position row
+    const int mm = in_range ? m : p.M - 1;
+    const int img = mm / p.np, pp = mm - img * p.np;
+    const float4 p0 = *reinterpret_cast<const float4*>(p.bias + (size_t)(1 + pp) * p.N + n), p1 = *reinterpret_cast<const float4*>(p.bias + (size_t)(1 + pp) * p.N + n + 4);
+    float* crow = reinterpret_cast<float*>(p.C) + ((size_t)img * (p.np + 1) + 1 + pp) * p.ldc + n;
+    if (in_range) {
+      *reinterpret_cast<float4*>(crow) = make_float4(v[0] + p0.x, v[1] + p0.y, v[2] + p0.z, v[3] + p0.w);
+      *reinterpret_cast<float4*>(crow + 4) = make_float4(v[4] + p1.x, v[5] + p1.y, v[6] + p1.z, v[7] + p1.w);
+    }
+  } else if constexpr (EPI == EPI_RESID_SPLIT) {
+    // the residual stream as two 16-bit planes (gemm.h EPI_RESID_SPLIT): join, (x + bias) + product, split, statistics of
+    // the tile's 64-column slice -- a lane owns 8 consecutive columns of a row, 8 lanes the slice, as in the big kernel
+    const size_t off = (size_t)(in_range ? m : p.M - 1) * p.ldc + n;
+    const u32x4 h = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned short*>(p.xb_out) + off);
+    const u32x4 l = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned short*>(p.lo_io) + off);
+    float o[8], s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      o[2 * e] = join_f32<T>(h[e] & 0xffffu, l[e] & 0xffffu);
+      o[2 * e + 1] = join_f32<T>(h[e] >> 16, l[e] >> 16);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (o[e] + bias[e]) + v[e];
+    s = ((o[0] + o[1]) + (o[2] + o[3])) + ((o[4] + o[5]) + (o[6] + o[7]));
+    const float ssum = row8_sum(s);
+    const float mj = ssum * (1.0f / kLnSlice);
+    float q = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const float d = o[e] - mj; q = fmaf(d, d, q); }
+    const float m2 = row8_sum(q);
+    if (in_range) {
+      u32x4 ho, lo4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        unsigned ha, la, hb, lb;
+        split_f32<T>(o[2 * e], ha, la);
+        split_f32<T>(o[2 * e + 1], hb, lb);
+        ho[e] = ha | (hb << 16);
+        lo4[e] = la | (lb << 16);
+      }
+      *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(p.xb_out) + off) = ho;
+      *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(p.lo_io) + off) = lo4;
+      if ((tid & 7) == 0) *reinterpret_cast<float2*>(p.st_out + ((size_t)m * (p.N / kLnSlice) + n0 / kLnSlice) * 2) = make_float2(ssum, m2);
+    }
   } else {
-    static_assert(epi_is_resid(EPI), "skinny epilogues: bias / QuickGELU (optionally LayerNorm-folded) and the residual forms");
+    static_assert(epi_is_resid(EPI), "skinny epilogues: bias / QuickGELU (optionally LayerNorm-folded), patch rows and the residual forms");
     float* crow = reinterpret_cast<float*>(p.C) + (size_t)(in_range ? m : p.M - 1) * p.ldc + n;
     const float4 x0 = *reinterpret_cast<const float4*>(crow), x1 = *reinterpret_cast<const float4*>(crow + 4);
     const float xo[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
@@ -169,7 +217,7 @@ int launch_skinny(const GemmParams& p, hipStream_t s) {
 
 bool gemm_skinny_supports(int epi, int M, int N, int K) {
   const bool epi_ok = epi == EPI_BIAS || epi == EPI_BIAS_QGELU || epi == EPI_BIAS_RESID || epi == EPI_BIAS_LN ||
-                      epi == EPI_QGELU_LN || epi == EPI_RESID_EMIT;
+                      epi == EPI_QGELU_LN || epi == EPI_RESID_EMIT || epi == EPI_RESID_SPLIT || epi == EPI_PATCH;
   return epi_ok && M > 0 && N % SK_BN == 0 && K % 256 == 0;
 }
 
@@ -182,6 +230,8 @@ static int launch_skinny_epi(int epi, const GemmParams& p, hipStream_t s) {
     case EPI_BIAS_LN: return launch_skinny<T, EPI_BIAS_LN>(p, s);
     case EPI_QGELU_LN: return launch_skinny<T, EPI_QGELU_LN>(p, s);
     case EPI_RESID_EMIT: return launch_skinny<T, EPI_RESID_EMIT>(p, s);
+    case EPI_RESID_SPLIT: return launch_skinny<T, EPI_RESID_SPLIT>(p, s);
+    case EPI_PATCH: return launch_skinny<T, EPI_PATCH>(p, s);
     default: return (int)hipErrorInvalidValue;
   }
 }
@@ -191,11 +241,11 @@ int gemm_launch_skinny(int dtype, int epi, const GemmParams& p, hipStream_t s, c
   if ((dtype != 1 && dtype != 2) || !gemm_skinny_supports(epi, p.M, p.N, p.K) || p.lda % 8 || p.ldw % 8) return (int)hipErrorInvalidValue;
   static const char* names[2][EPI_COUNT] = {
       {"gemm_skinny<bf16,32x64_splitk,bias>", "gemm_skinny<bf16,32x64_splitk,bias_qgelu>", "gemm_skinny<bf16,32x64_splitk,bias_resid>",
-       nullptr, nullptr, "gemm_skinny<bf16,32x64_splitk,ln_bias>", "gemm_skinny<bf16,32x64_splitk,ln_qgelu>",
-       "gemm_skinny<bf16,32x64_splitk,resid_emit>", nullptr},
+       nullptr, "gemm_skinny<bf16,32x64_splitk,patch>", "gemm_skinny<bf16,32x64_splitk,ln_bias>", "gemm_skinny<bf16,32x64_splitk,ln_qgelu>",
+       "gemm_skinny<bf16,32x64_splitk,resid_emit>", "gemm_skinny<bf16,32x64_splitk,resid_split>"},
       {"gemm_skinny<f16,32x64_splitk,bias>", "gemm_skinny<f16,32x64_splitk,bias_qgelu>", "gemm_skinny<f16,32x64_splitk,bias_resid>",
-       nullptr, nullptr, "gemm_skinny<f16,32x64_splitk,ln_bias>", "gemm_skinny<f16,32x64_splitk,ln_qgelu>",
-       "gemm_skinny<f16,32x64_splitk,resid_emit>", nullptr}};
+       nullptr, "gemm_skinny<f16,32x64_splitk,patch>", "gemm_skinny<f16,32x64_splitk,ln_bias>", "gemm_skinny<f16,32x64_splitk,ln_qgelu>",
+       "gemm_skinny<f16,32x64_splitk,resid_emit>", "gemm_skinny<f16,32x64_splitk,resid_split>"}};
   if (kernel_name) *kernel_name = names[dtype - 1][epi];
   return dtype == 1 ? launch_skinny_epi<bf16_t>(epi, p, s) : launch_skinny_epi<f16_t>(epi, p, s);
 }

@@ -41,13 +41,15 @@ class Engine:
     def __init__(self, cfg: PlipConfig, state_dict: Mapping[str, object], device="cuda:0", dtype="bf16",
                  max_batch: int = 256, *, ln_fold: bool = True, pooled_last_block: bool = True,
                  pack_captions: bool = False, mfma_attention: bool = True, graph_batch: Optional[int] = None,
-                 text_f16: bool = False, text_f16_layers: Optional[int] = None):
+                 text_f16: bool = False, text_f16_layers: Optional[int] = None, latency_batch: int = 0):
         """``ln_fold`` / ``pooled_last_block`` / ``mfma_attention`` = False select the A/B forms of the 16-bit engines
         (separate LayerNorm kernels, the last block on every token, the exact VALU attention kernel);
         ``text_f16`` (bf16 engine only): the text tower runs on IEEE-half operands, the image tower stays bf16;
         ``text_f16_layers`` (bf16 engine only): only that many LEADING text blocks do (None = the engine default,
         ``DEFAULT_TEXT_F16_LAYERS``; 0 = a pure bf16 engine) -- plipmi_config.text_f16_layers;
         ``graph_batch``: None = default small-batch hipGraph replay (<= 32 samples), 0 = never, n = up to n samples.
+        ``latency_batch``: batches of at most that many samples run on the split-K small-M GEMMs (plipmi_set_latency_batch;
+        faster up to batch 8, embeddings then differ from the big-batch path's by up to 6e-4 -- off by default).
         All of it is per-handle configuration (include/plipmi.h plipmi_config.flags): no environment variables."""
         cfg.validate()
         if not torch.cuda.is_available():
@@ -120,6 +122,8 @@ class Engine:
             stream.synchronize()  # packing done -> the fp32 upload copies can go
             del dev
         self.device_name = self.lib.plipmi_device_name(self._h).decode()
+        if latency_batch:
+            self.set_latency_batch(latency_batch)
 
     # ------------------------------------------------------------------
     def close(self):
@@ -215,6 +219,11 @@ class Engine:
     def set_graph_batch(self, max_batch: int):
         """Batches of at most ``max_batch`` samples replay a captured hipGraph (0 = always launch eagerly)."""
         _lib.check(self.lib.plipmi_set_graph_batch(self._h, int(max_batch)), "plipmi_set_graph_batch")
+
+    def set_latency_batch(self, max_batch: int):
+        """Batches of at most ``max_batch`` samples (0 = never, the default) run their GEMMs on the split-K small-M kernel
+        (include/plipmi.h plipmi_set_latency_batch): same arithmetic, fp32 summation order of its own."""
+        _lib.check(self.lib.plipmi_set_latency_batch(self._h, int(max_batch)), "plipmi_set_latency_batch")
 
     def set_text_packing(self, on: bool):
         """Captions packed to their live rows (0 .. EOS): bit-identical text_embeds, cost proportional to the caption

@@ -47,7 +47,7 @@ class PlipModel:
                  max_batch: int = 256, **engine_options):
         """``dtype``: "bf16", "f16" (the reference's own GPU type; 8x smaller operand rounding at the same speed) or "f32".
         ``engine_options``: the per-handle switches of :class:`plip_amd.engine.Engine` (ln_fold, pooled_last_block,
-        pack_captions, mfma_attention, graph_batch, text_f16, text_f16_layers)."""
+        pack_captions, mfma_attention, graph_batch, text_f16, text_f16_layers, latency_batch)."""
         self.config = cfg
         self.engine = Engine(cfg, state_dict, device=device, dtype=dtype, max_batch=max_batch, **engine_options)
         self.device = self.engine.device

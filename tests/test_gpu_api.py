@@ -5,6 +5,7 @@ import pytest
 import torch
 
 from oracle import clip_oracle as O
+from oracle.make_golden import case_inputs
 
 pytestmark = pytest.mark.gpu
 
@@ -461,6 +462,46 @@ def test_device_resident_out_of_range_ids_surface_an_error(dtype, engines):
         eng.check_async()
     with pytest.raises(IndexError):
         eng.encode_text(torch.from_numpy(ids).clamp(min=cfg.vocab_size), None)    # host-resident ids: checked up front
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_latency_path_small_batches_on_split_k_gemms(dtype, golden):
+    """plipmi_set_latency_batch: batches of at most n samples run every GEMM of their towers -- patch
+    embedding, q/k/v, out_proj, fc1, fc2 with the engine's own epilogues -- on the split-K small-M kernel.  Same arithmetic:
+    inside the parity bar against HF; a row's embedding independent of its batch INSIDE the regime; against the big-tile
+    regime the other summation order moves 16-bit roundings (bounded here), which is why the path is opt-in."""
+    from plip_amd.model import PlipModel
+    g = golden("vitb32_b4")
+    cfg, sd, px, ids, mask = case_inputs("vitb32_b4")
+    px, ids, mask = torch.from_numpy(px), torch.from_numpy(ids), torch.from_numpy(mask)
+    big = PlipModel(cfg, sd, dtype=dtype, max_batch=32)
+    fast = PlipModel(cfg, sd, dtype=dtype, max_batch=32, latency_batch=8)
+    try:
+        ob = big(input_ids=ids, pixel_values=px, attention_mask=mask)
+        of = fast(input_ids=ids, pixel_values=px, attention_mask=mask)
+        scale = np.exp(np.float64(sd["logit_scale"]))
+        cos = {"bf16": 1e-3, "f16": 2.5e-4}[dtype]
+        for o in (ob, of):
+            assert np.abs(o.logits_per_image.cpu().numpy() - g["logits_per_image"]).max() / scale < cos
+        d = max(float((ob.image_embeds - of.image_embeds).abs().max()), float((ob.text_embeds - of.text_embeds).abs().max()))
+        assert 0 < d < {"bf16": 2e-3, "f16": 4e-4}[dtype]                     # another summation order, not another result
+        # inside the regime: rows do not depend on their batch (1 of 4, 2 of 4), eager == graph replay (calls 2, 3 replay)
+        one = fast.get_image_features(pixel_values=px[2:3])
+        full = fast.get_image_features(pixel_values=px)
+        assert torch.equal(one, full[2:3]) and torch.equal(fast.get_image_features(pixel_values=px[2:3]), one)
+        t_full = fast.get_text_features(input_ids=ids, attention_mask=mask)
+        assert torch.equal(fast.get_text_features(input_ids=ids[1:3], attention_mask=mask[1:3]), t_full[1:3])
+        assert torch.equal(fast.get_text_features(input_ids=ids, attention_mask=mask), t_full)
+        # above the threshold the engine is the big-tile engine, bit for bit
+        rs = np.random.RandomState(3)
+        px20 = torch.from_numpy(rs.randn(20, 3, cfg.image_size, cfg.image_size).astype(np.float32))
+        assert torch.equal(fast.get_image_features(pixel_values=px20), big.get_image_features(pixel_values=px20))
+        # hidden states of the latency path against the big path's: a 16-bit rounding apart at most
+        hb, hf = big.engine.hidden("text", cfg.t_layers, ids), fast.engine.hidden("text", cfg.t_layers, ids)
+        assert float((hb - hf).abs().max()) < {"bf16": 1.5e-1, "f16": 4e-2}[dtype]
+    finally:
+        big.engine.close()
+        fast.engine.close()
 
 
 def test_engine_switches_are_constructor_arguments_not_environment(engines, monkeypatch):

@@ -83,3 +83,35 @@ def test_fully_masked_tail_chunks_do_not_disturb_the_running_softmax():
     out2 = attention(qkv, 1, S, H, False, mask2, impl=1)
     assert torch.isfinite(out2).all()
     assert (out2.double() - _ref(qkv, 1, S, H, False, mask2)).abs().max().item() < 3e-2
+
+
+@pytest.mark.parametrize("S,H,causal", [(77, 2, True), (50, 2, False), (300, 2, False)])
+def test_masked_key_rows_contribute_nothing_and_a_non_finite_one_poisons_like_hfs_additive_mask(S, H, causal):
+    """The MFMA kernels mask ADDITIVELY (score + (0 | -inf): ADVICE r3 -- a select was miscompiled by hipcc 7.2's v_bitop3
+    folding), which is also what HF does (attention_mask is added to the scores, modeling_clip.py:259-277).  Pinned here:
+    (a) whatever FINITE values sit in masked key / value rows -- padding rows hold real embeddings, never zeros -- cannot
+    reach any query; (b) a NaN in a masked KEY row does reach the queries that would have multiplied it (NaN + -inf = NaN
+    -> the row maximum), exactly as in HF; it never appears in the engine, whose masked rows are finite activations."""
+    from plip_amd.engine import attention
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(S)
+    B, n_valid = 2, S // 2
+    qkv = torch.randn(B * S, 3 * H * 64, generator=g)
+    qkv[:, : H * 64] *= 0.125
+    mask = (torch.arange(S)[None, :] < n_valid).long().repeat(B, 1).to(dev)
+    base = qkv.to(dev).to(torch.bfloat16)
+    want = attention(base, B, S, H, causal, mask, impl=1)
+    loud = base.clone().view(B, S, 3, H * 64)
+    loud[:, n_valid:, 1:] = 3.0e4                                   # masked K and V rows: huge but finite
+    got = attention(loud.view(B * S, -1), B, S, H, causal, mask, impl=1)
+    torch.cuda.synchronize()
+    live = torch.zeros(B, S, dtype=torch.bool)
+    live[:, :n_valid] = True                                        # (rows of masked QUERIES are don't-cares downstream)
+    assert torch.equal(got.view(B, S, -1)[live.to(dev)], want.view(B, S, -1)[live.to(dev)])
+    bad = base.clone().view(B, S, 3, H * 64)
+    bad[0, S - 1, 1, :64] = float("nan")                            # one masked key row of sample 0, head 0
+    out = attention(bad.view(B * S, -1), B, S, H, causal, mask, impl=1).view(B, S, H, 64)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out[1]).all() and torch.isfinite(out[0, :, 1]).all()          # other sample / other head untouched
+    if not causal:
+        assert torch.isnan(out[0, :n_valid, 0]).all()               # additive mask: NaN + -inf stays NaN (as in HF)

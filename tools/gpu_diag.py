@@ -219,39 +219,47 @@ def sec_lnbench():
 
 def sec_latency():
     """Small-batch latency of one zero_shot_classification-sized step (the reference runs both towers at batch 8,
-    plip.py:90-91): eager launches vs hipGraph replay, wall time per call with a host sync (what a caller sees)."""
+    plip.py:90-91): big-tile GEMMs vs the latency path (split-K small-M GEMMs, plipmi_set_latency_batch), eager launches vs
+    hipGraph replay; wall time per call with a host sync (what a caller sees) and the host's enqueue cost."""
     import time
     cfg = get_config("ViT-B/32")
     sd = W.synthetic_state_dict(cfg, 0)
     model = PlipModel(cfg, sd, dtype="bf16", max_batch=32)
     eng = model.engine
-    for B in (1, 8, 32):
+    for B in (1, 8, 16, 32):
         px = torch.from_numpy(W.synthetic_pixels(cfg, B, 1)).to(dev)
         ids = torch.from_numpy(W.synthetic_ids(cfg, B, 2)[0]).to(dev)
-        for mode, gb in (("eager", 0), ("graph", 32)):
-            eng.set_graph_batch(gb)
-            for _ in range(4):
-                eng.encode_image(px, True); eng.encode_text(ids, None, True)
-            torch.cuda.synchronize()
-            res = {}
-            for what, fn in (("image", lambda: eng.encode_image(px, True)), ("text", lambda: eng.encode_text(ids, None, True)),
-                             ("pair_2streams", lambda: eng.encode_pair(px, ids, None, True, True))):
-                for _ in range(3):
-                    fn()
+        ref = None
+        for path, lb in (("big tiles", 0), ("split-K", 32)):
+            eng.set_latency_batch(lb)
+            for mode, gb in (("eager", 0), ("graph", 32)):
+                eng.set_graph_batch(gb)
+                for _ in range(4):
+                    eng.encode_image(px, True); eng.encode_text(ids, None, True)
                 torch.cuda.synchronize()
-                n = 30
-                t0 = time.perf_counter()
-                for _ in range(n):
-                    fn()
+                res = {}
+                for what, fn in (("image", lambda: eng.encode_image(px, True)), ("text", lambda: eng.encode_text(ids, None, True)),
+                                 ("pair_2streams", lambda: eng.encode_pair(px, ids, None, True, True))):
+                    for _ in range(3):
+                        fn()
                     torch.cuda.synchronize()
-                res[what] = (time.perf_counter() - t0) / n * 1e3
-                t0 = time.perf_counter()
-                for _ in range(n):
-                    fn()
-                host = (time.perf_counter() - t0) / n * 1e3        # enqueue cost only (no sync inside)
-                torch.cuda.synchronize()
-                res[what + "_enqueue"] = host
-            print(f"B={B:3d} {mode:5s}: " + "  ".join(f"{k} {v:.3f} ms" for k, v in res.items()))
+                    n = 30
+                    t0 = time.perf_counter()
+                    for _ in range(n):
+                        fn()
+                        torch.cuda.synchronize()
+                    res[what] = (time.perf_counter() - t0) / n * 1e3
+                    t0 = time.perf_counter()
+                    for _ in range(n):
+                        fn()
+                    host = (time.perf_counter() - t0) / n * 1e3        # enqueue cost only (no sync inside)
+                    torch.cuda.synchronize()
+                    res[what + "_enqueue"] = host
+                out = torch.cat(eng.encode_pair(px, ids, None, True, True))
+                if ref is None:
+                    ref = out
+                print(f"B={B:3d} {path:9s} {mode:5s}: " + "  ".join(f"{k} {v:.3f} ms" for k, v in res.items()) +
+                      f"   | max |embedding diff| vs big tiles {float((out - ref).abs().max()):.1e}")
     model.engine.close()
 
 
