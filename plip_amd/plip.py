@@ -50,6 +50,19 @@ def _native_u8_tiles(chunk, n_px):
     return np.stack(arrs) if arrs else None
 
 
+def _all_native_tiles(chunk, n_px) -> bool:
+    """every element an n_px x n_px uint8 RGB array or PIL image (what _native_u8_tiles would stack)"""
+    if len(chunk) == 0:
+        return False
+    for im in chunk:
+        if isinstance(im, np.ndarray):
+            if im.dtype != np.uint8 or im.shape != (n_px, n_px, 3):
+                return False
+        elif isinstance(im, str) or not (hasattr(im, "size") and hasattr(im, "mode") and im.size == (n_px, n_px)):
+            return False
+    return True
+
+
 def _uniform_u8_images(chunk, n_px):
     """Equally sized uint8 RGB images (arrays or PIL) that still need resize/crop -> one [B,H,W,3] array, else None."""
     if torch.is_tensor(chunk) or isinstance(chunk, np.ndarray) or len(chunk) == 0:
@@ -124,7 +137,9 @@ class PLIP:
 
         def flush():
             nonlocal pend, kind, rows
-            if pend:
+            if kind == "stage":            # native tiles: each copied ONCE, into the pinned staging rows; one H2D, one engine call
+                outs.append(eng.encode_image_u8(self._fill_stage(pend, n_px, cap)))
+            elif pend:
                 if len(pend) > 1 and any(t.is_cuda for t in pend):
                     pend = [t.to(eng.device) for t in pend]
                 t = pend[0] if len(pend) == 1 else torch.cat(pend)
@@ -137,6 +152,16 @@ class PLIP:
                 if isinstance(chunk, (list, tuple)) and any(isinstance(c, str) for c in chunk):
                     from PIL import Image                                  # plip.py:34 opens the paths of a batch
                     chunk = [Image.open(c) if isinstance(c, str) else c for c in chunk]
+                if self.coalesce and isinstance(chunk, (list, tuple)) and len(chunk) <= cap:
+                    # already n_px x n_px uint8 (normalised on the GPU, fused into the unfold): each tile is copied ONCE, into
+                    # a pinned staging buffer of max_batch rows -- 32 small np.stack calls + a torch.cat + a pageable H2D
+                    # cost more than the towers (profiles/r04_small_batch_latency.txt)
+                    if _all_native_tiles(chunk, n_px):
+                        if kind is not None and (kind != "stage" or rows + len(chunk) > cap):
+                            flush()
+                        pend.extend(chunk)
+                        kind, rows = "stage", rows + len(chunk)
+                        continue
                 tiles = _native_u8_tiles(chunk, n_px)
                 same = _uniform_u8_images(chunk, n_px) if tiles is None else None
                 if tiles is not None:      # already n_px x n_px uint8: normalise on the GPU, fused into the unfold
@@ -149,7 +174,7 @@ class PLIP:
                     k, t = "pixels", torch.from_numpy(chunk)
                 else:
                     k, t = "pixels", torch.from_numpy(preprocess_images(list(chunk), n_px, crop=_CROP))
-                if pend and (k != kind or t.dtype != pend[0].dtype or rows + t.shape[0] > cap):
+                if kind is not None and (k != kind or t.dtype != pend[0].dtype or rows + t.shape[0] > cap):
                     flush()
                 pend.append(t)
                 kind, rows = k, rows + t.shape[0]
@@ -157,6 +182,18 @@ class PLIP:
         if not outs:
             return np.zeros((0, self.model.config.projection_dim), np.float32)
         return torch.cat(outs).detach().cpu().numpy()
+
+    _stage = None            # pinned uint8 [max_batch, n, n, 3] staging rows of the coalescing host loop (allocated on first use)
+
+    def _fill_stage(self, tiles, n_px, cap) -> torch.Tensor:
+        """The native tiles of one engine call (arrays or PIL) -> the first len(tiles) rows of the pinned staging buffer.
+        (Plain row copies: a thread pool was measured 3x slower -- numpy keeps the GIL for 150 KB copies.)"""
+        if self._stage is None or self._stage.shape[0] < cap or self._stage.shape[1] != n_px:
+            self._stage = torch.empty((cap, n_px, n_px, 3), dtype=torch.uint8, pin_memory=torch.cuda.is_available())
+        dst = self._stage.numpy()
+        for i, im in enumerate(tiles):
+            dst[i] = im if isinstance(im, np.ndarray) else np.asarray(im.convert("RGB"), dtype=np.uint8)
+        return self._stage[:len(tiles)]
 
     def _encode_images_pipelined(self, images: list, batch_size: int, num_workers: int):
         """Same routing per batch as the loop above (raw tiles / GPU resize / host Pillow), one batch ahead."""

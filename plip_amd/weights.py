@@ -387,11 +387,14 @@ def load_checkpoint(path: str, arch: str | None = None, trust_pickle: bool = Fal
         sd = load_file(path)
     else:
         import pickle
+        import zipfile
         try:
             sd = torch.load(path, map_location="cpu", weights_only=True)
         except (OSError, TypeError):
             raise                                     # missing / unreadable file, or a torch without weights_only: not a pickle question
-        except (pickle.UnpicklingError, RuntimeError) as e:   # what weights_only=True raises on a code-carrying pickle
+        except (pickle.UnpicklingError, RuntimeError, EOFError, AttributeError, ImportError, KeyError, zipfile.BadZipFile) as e:
+            # what weights_only=True raises on a code-carrying pickle -- and what old / odd checkpoints (legacy pickles naming
+            # modules that are gone, truncated archives) raise on their way there: all of them get the guidance below
             if not (trust_pickle or os.environ.get("PLIPMI_TRUST_PICKLE") == "1"):
                 raise RuntimeError(
                     f"{path} is not a plain tensor state dict ({type(e).__name__}: {str(e)[:200]}). Loading it needs full "

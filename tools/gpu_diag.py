@@ -263,6 +263,36 @@ def sec_latency():
     model.engine.close()
 
 
+def sec_zeroshot():
+    """PLIP.zero_shot_classification (plip.py:89-103: both encoders at the hard-coded batch_size=8) on 256 native tiles + 10
+    labels: one engine call per caller batch (round 3's behaviour, PLIP.coalesce = False) vs the caller's batches handed to the
+    towers max_batch rows at a time (the default) -- same labels, wall time per call incl. host work and the copy back."""
+    import time
+    from plip_amd.plip import PLIP
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_gpu_api import fake_tokenizer
+    cfg = get_config("ViT-B/32")
+    model = PlipModel(cfg, W.synthetic_state_dict(cfg, 0), dtype="bf16", max_batch=256)
+    plip = PLIP(model=model, tokenizer=fake_tokenizer(cfg))
+    rs = np.random.RandomState(0)
+    tiles = [rs.randint(0, 256, size=(cfg.image_size, cfg.image_size, 3), dtype=np.uint8) for _ in range(256)]
+    labels = [f"an h&e image of tissue class {i} " + "x " * i for i in range(10)]
+    res = {}
+    for co in (False, True, False, True):
+        plip.coalesce = co
+        plip.zero_shot_classification(tiles, labels)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            pred = plip.zero_shot_classification(tiles, labels)
+        res.setdefault(co, []).append(((time.perf_counter() - t0) / 5 * 1e3, pred))
+    a, b = min(r[0] for r in res[False]), min(r[0] for r in res[True])
+    same = res[False][0][1] == res[True][0][1]
+    print(f"zero_shot_classification(256 tiles, 10 labels): one engine call per batch of 8: {a:7.2f} ms   coalesced to max_batch: {b:7.2f} ms   "
+          f"({a / b:.1f}x)   identical labels: {same}")
+    model.engine.close()
+
+
 def sec_libgemm():
     """Calibration only (never used by the product): what the vendor GEMM library (hipBLASLt/rocBLAS behind
     torch.nn.functional.linear / torch.mm) reaches on the production shapes -- an external yardstick for gemm_nt.  Like for
@@ -801,5 +831,5 @@ def sec_e2e():
 if __name__ == "__main__":
     t0 = time.time()
     {"gemm": sec_gemm, "attn": sec_attn, "tiny": sec_tiny, "vitb32": sec_vitb32, "gemmbench": sec_gemmbench, "lnbench": sec_lnbench, "latency": sec_latency, "libgemm": sec_libgemm, "tiles": sec_tiles, "parity": sec_parity, "sustain": sec_sustain, "power": sec_power, "cold": sec_cold, "towerswap": sec_towerswap, "e2e": sec_e2e, "gemmone": sec_gemmone, "policy": sec_policy, "ldpad": sec_ldpad, "gemmtrace": sec_gemmtrace,
-     "overlap": sec_overlap, "stepab": sec_stepab, "cumask": sec_cumask, "mixed": sec_mixed}[sys.argv[1]]()
+     "overlap": sec_overlap, "stepab": sec_stepab, "cumask": sec_cumask, "mixed": sec_mixed, "zeroshot": sec_zeroshot}[sys.argv[1]]()
     print(f"[{sys.argv[1]} done in {time.time() - t0:.1f} s]")
