@@ -551,12 +551,12 @@ def main(argv=None, model_factory=None):
             e16 = model.engine.encode_image(px, True)
             res["fp32_pairs"] = {"workload": "full dual encoder bs=256 on the exact-fp32 MFMA engine (v_mfma_f32_32x32x2_f32)",
                                  "pairs_per_s": round(B / dtp, 1), "ms_per_step": round(dtp * 1e3, 3),
-                                 "algorithmic_tflops": round(B * cfg.pair_flops() / dtp / 1e12, 2),
+                                 "dense_tflops": round(B * cfg.pair_flops() / dtp / 1e12, 2),
                                  "frac_of_fp32_mfma_peak": round(B * cfg.pair_flops() / dtp / 1e12 / PEAK_TFLOPS["f32"], 4)}
             res["config1_fp32_image_tower"] = {
                 "workload": "ViT-B/32 image tower only, bs=256, fp32 (v_mfma_f32_32x32x2_f32), synthetic 224px tiles",
                 "images_per_s": round(B / dt32, 1), "ms_per_step": round(dt32 * 1e3, 3),
-                "algorithmic_tflops": round(B * cfg.image_flops() / dt32 / 1e12, 2),
+                "dense_tflops": round(B * cfg.image_flops() / dt32 / 1e12, 2),
                 "roofline": None if dom32 is None else {
                     "bound": "mfma", "kernel": dom32["name"], "peak": PEAK_TFLOPS["f32"], "unit": "TFLOP/s",
                     "achieved": round(dom32["flops"] / (dom32["total_ms"] * 1e9), 2),

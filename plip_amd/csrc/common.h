@@ -39,11 +39,13 @@ template <> struct half_traits<bf16_t> {
   using x8 = bf16x8; using x4 = bf16x4;
   static constexpr const char* name = "bf16";
   __device__ __forceinline__ static f32x16 mfma32(x8 a, x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+  __device__ __forceinline__ static f32x4 mfma16(x8 a, x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 };
 template <> struct half_traits<f16_t> {
   using x8 = f16x8; using x4 = f16x4;
   static constexpr const char* name = "f16";
   __device__ __forceinline__ static f32x16 mfma32(x8 a, x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+  __device__ __forceinline__ static f32x4 mfma16(x8 a, x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 };
 template <typename T> constexpr bool is_half_v = sizeof(T) == 2;
 

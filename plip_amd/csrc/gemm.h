@@ -277,6 +277,13 @@ constexpr int nth_outside(int p0, int p1, int g0, int g1, int k) {
   }
   return p0;
 }
+// SCHED 7 / 8 (16-bit operand types): the K loop in v_mfma_f32_16x16x32 instead of 32x32x16 -- the same FLOPs per cycle with a
+//    quarter of the accumulator registers per instruction.  Under the chip's power budget bare random-data streams of it sustain
+//    1880-1980 TFLOP/s against 1600-1720 for the 32x32 form (profiles/r04_mfma_power_ceiling.txt; the vendor library's kernels
+//    are MI16x16 throughout), and in the K loop the shader clock settles ~0.1 GHz higher.  The K step is ONE hand-placed stream
+//    -- MFMA, fragment read, MFMA, read ... with the fill's LDS-DMA batches behind the reads -- pinned with a scheduling fence
+//    per slot.  7: ring of three stages; 8: two stages, the tile's barrier in front of its last MFMA groups.
+//    profiles/r04_gemm_m16.txt: q/k/v 957 -> 1022, fc1 1076 -> 1131, fc2 1145 -> 1176 TFLOP/s, the step -2 ... -3 %.
 template <typename T, int BM, int BN, int WM, int WN, int EPI, int SCHED = 0, int ADDR = 0, int NSTAGE = 2>
 __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void gemm_nt_kernel(const GemmParams p) {
@@ -289,16 +296,13 @@ void gemm_nt_kernel(const GemmParams p) {
   constexpr int ELEMS16 = 16 / sizeof(T);  // elements per 16-byte chunk
   using OutT = std::conditional_t<sizeof(T) == 4, float, T>;
   static_assert(!(epi_is_ln(EPI) || epi_emits_stats(EPI)) || sizeof(T) == 2, "LayerNorm folding is a 16-bit-engine form");
-  static_assert(SCHED == 0 || SCHED == 1 || SCHED == 5 || SCHED == 6 || SCHED == 7 || SCHED == 9,
-                "schedules: 0, 1, 5 (fill2), 6 (fill3), 7 / 9 (hand-placed, fill3 / fill2)");
+  static_assert(SCHED == 0 || SCHED == 1 || SCHED == 5 || SCHED == 6 || SCHED == 7 || SCHED == 8,
+                "schedules: 0, 1, 5 (fill2), 6 (fill3), 7 / 8 (16x16x32 form: ring of three / two stages)");
   static_assert(NSTAGE == 2 || NSTAGE == 3, "two LDS stages or a ring of three");
-  // 7 / 9: the K step is ONE hand-placed stream -- MFMA, fragment read of the next step, MFMA, read ... -- pinned with a
-  // scheduling fence per slot, so a wave keeps the matrix pipe fed out of its own stream whatever its SIMD partner does
-  // (the burst form idles the pipe whenever both waves of a SIMD are in their read bursts at once).  The fill travels in
-  // batches behind the reads of the first three (7) / two (9) steps.  Measured (profiles/r04_gemm_placed.txt): ring
-  // 1768 -> 1648 cycles per K tile, 256x256 2727 -> 2700; kernels -0.5 ... -2 % -- the clock gives most of it back.
-  constexpr bool kPlaced = SCHED >= 7;
   constexpr bool kSpread = SCHED >= 5;
+  constexpr bool kM16 = SCHED >= 7;
+  static_assert(!kM16 || sizeof(T) == 2, "the 16x16x32 form: 16-bit operands");
+  static_assert(!kM16 || NSTAGE == (SCHED == 7 ? 3 : 2), "schedule 7 runs on the ring, 8 on two stages");
   static_assert(!kSpread || ADDR == 1, "the spread fill batches buffer-form requests");
   constexpr int BK = 8 * ELEMS16;          // 128-byte rows
   constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, STAGE = A_BYTES + W_BYTES;
@@ -391,11 +395,11 @@ void gemm_nt_kernel(const GemmParams p) {
   };
   // the same fill cut in parts, one per K step of the MFMA block (SCHED 5 / 6: packed into the first 2 / 3 K steps, so the
   // last request has most of the iteration -- not a quarter of it -- to land before the end-of-iteration wait)
-  constexpr int kFillParts = (SCHED == 5 || SCHED == 9) ? 2 : 3;
+  constexpr int kFillParts = SCHED == 5 ? 2 : 3;
   auto stage_issue_part = [&](int buf, int part) {
     const unsigned base = lds0 + buf * STAGE + wave * 1024;
-    if constexpr (kPlaced) {
-      return;   // the hand-placed schedules issue through fill_part_placed / issue_piece below
+    if constexpr (kM16) {
+      return;   // the hand-placed schedules issue through fill_part_placed below
     } else if constexpr (ADDR == 1 && PA == PA_MIN) {
       constexpr int PER = (PA + PW + kFillParts - 1) / kFillParts;
       // piece idx of the tile: resource, lane offset and (compile-time) LDS offset
@@ -442,11 +446,11 @@ void gemm_nt_kernel(const GemmParams p) {
     }
   };
 
-  // Hand-placed schedules (SCHED 7 / 9): the tile's PA + PW requests are dealt to the first kParts K steps, PER per step, one
+  // Hand-placed schedules (SCHED 7 / 8): the tile's PA + PW requests are dealt to the first kParts K steps, PER per step, one
   // statement of up to four requests (A pieces that not every wave owns go singly behind their wave-uniform test).
   constexpr int kParts = kFillParts;
   constexpr int PER = (PA + PW + kParts - 1) / kParts;
-  static_assert(!kPlaced || ADDR == 1, "hand-placed schedules use the buffer-form LDS-DMA");
+  static_assert(!kM16 || ADDR == 1, "hand-placed schedules use the buffer-form LDS-DMA");
   auto piece_lds = [](int idx) constexpr { return idx < PA ? idx * NT * 16 : A_BYTES + (idx - PA) * NT * 16; };
   auto fill_batched = [&](int buf, auto part_c) __attribute__((always_inline)) {
     constexpr int part = decltype(part_c)::value;
@@ -492,13 +496,23 @@ void gemm_nt_kernel(const GemmParams p) {
   const int a_tile = wm * TM * 128;
   const int w_tile = A_BYTES + wn * TN * 128;
 
-  f32x16 acc[MI][NI];
+  f32x16 acc[kM16 ? 1 : MI][kM16 ? 1 : NI];
 #pragma unroll
-  for (int i = 0; i < MI; ++i)
+  for (int i = 0; i < (kM16 ? 1 : MI); ++i)
 #pragma unroll
-    for (int j = 0; j < NI; ++j)
+    for (int j = 0; j < (kM16 ? 1 : NI); ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  // 16x16x32 form: the wave's 32x32 blocks as four 16x16 tiles each.  acc4[2i+b][2j+a][e] = C[m = 32i + 16b + (lane & 15)]
+  // [n = 32j + 16a + 4 (lane >> 4) + e]: a lane holds TWO rows of a block (b = 0, 1) and, per row, 4 consecutive columns in each
+  // 16-column half -- again whole 16-byte fp32 / 8-byte 16-bit pieces of an output row.
+  constexpr int MI2 = 2 * MI, NI2 = 2 * NI;
+  f32x4 acc4[kM16 ? MI2 : 1][kM16 ? NI2 : 1];
+#pragma unroll
+  for (int i = 0; i < (kM16 ? MI2 : 1); ++i)
+#pragma unroll
+    for (int j = 0; j < (kM16 ? NI2 : 1); ++j) acc4[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int l16 = lane & 15, g16 = lane >> 4;
 
   // epilogue operands in the row-contiguous layout of the transposed store (16 lanes x 16 B per output row)
   // Register budget (256 per lane at two waves per SIMD): accumulators + K-loop fragments + one operand block must
@@ -536,35 +550,114 @@ void gemm_nt_kernel(const GemmParams p) {
     }
   };
 
-  // ---- hand-placed K step (SCHED 7 / 9) -------------------------------------------------------------------------
-  // MFMA n of the step (row block n / NI, column block n % NI), then fragment read n of the FOLLOWING step -- in the order the
-  // MFMAs want them: x0, w0 .. w(NI-1), x1 .. x(MI-1) -- then the step's fill requests in the first gap behind the reads; a
-  // scheduling fence closes every slot.  The wave-uniform break of an uneven tile's short wave row also skips the reads that
-  // row has no use for: they sit behind the MFMAs it does not issue.
-  constexpr int NM = MI * NI, NR = MI + NI;
-  constexpr int NM_MIN = kUneven ? (RB - (WM - 1) * MI) * NI : NM;
-  static_assert(!kPlaced || !kUneven || NI + (RB - (WM - 1) * MI) <= NM_MIN, "short wave row: reads must fit its MFMA gaps");
-  constexpr int kFillSlot = NR < NM_MIN ? NR : NM_MIN - 1;
-  u32x4 pxf[kPlaced ? 2 : 1][MI], pwf[kPlaced ? 2 : 1][NI];
-  auto placed_read = [&](const char* sb, int ks, int b, int r) __attribute__((always_inline)) {
-    if (r == 0) pxf[b][0] = *reinterpret_cast<const u32x4*>(sb + a_tile + foff[ks]);
-    else if (r <= NI) pwf[b][r - 1] = *reinterpret_cast<const u32x4*>(sb + w_tile + (r - 1) * 32 * 128 + foff[ks]);
-    else pxf[b][r - NI] = *reinterpret_cast<const u32x4*>(sb + a_tile + (r - NI) * 32 * 128 + foff[ks]);
-  };
-  auto placed_read_all = [&](const char* sb, int ks, int b) __attribute__((always_inline)) {
+  // ---- hand-placed K step, 16x16x32 form (SCHED 7 / 8) ---------------------------------------------------------
+  // A K tile is TWO steps of 32.  Per step the wave needs MI2 activation fragments (16 rows x 32 k: lane = row l16, 16-byte
+  // chunk 4s + g16 of the 128-byte LDS row; the XOR swizzle keeps every ds_read_b128 lane group on 16 distinct slots) and NI2
+  // weight fragments, and issues MI2 * NI2 MFMAs.
+  //  * two LDS stages: the operand with FEWER fragments (always 4 here) is KEPT in registers for the step (double-buffered
+  //    across steps), the other is STREAMED -- one fragment per group of 4 MFMAs (below).
+  //  * ring of three (barrier IN FRONT of the tile's last step): behind that barrier nobody may read the tile's stage any more
+  //    -- the next iteration's fill overwrites it -- so every fragment of a step is read during the step before it (both operands
+  //    double-buffered whole), one read per MFMA slot, and the last step's slots carry the NEXT tile's first fragments.
+  // A scheduling fence closes every slot.
+  constexpr bool kStream16 = NSTAGE == 2;
+  constexpr bool kKeepX = MI2 <= NI2;                 // (streamed form) keep the activation fragments, stream the weights -- or the reverse
+  constexpr int NK = kKeepX ? MI2 : NI2, NS = kKeepX ? NI2 : MI2;
+  static_assert(!kM16 || !kStream16 || (NK == 4 && NS % 2 == 0 && NS >= 4), "streamed 16x16x32 form: four kept fragments, an even number of streamed ones");
+  static_assert(!kM16 || !kStream16 || !kUneven, "uneven tiles run on the ring");
+  const int mi2_w = kUneven ? 2 * mi_w : MI2;         // 16-row blocks this wave multiplies (wave-uniform)
+  int foff16[2];
 #pragma unroll
-    for (int r = 0; r < NR; ++r) placed_read(sb, ks, b, r);
+  for (int s2 = 0; s2 < 2; ++s2) foff16[s2] = l16 * 128 + (((4 * s2 + g16) ^ (l16 >> 1)) << 4);
+  using H16 = std::conditional_t<sizeof(T) == 2, T, bf16_t>;
+  using X8h = typename half_traits<H16>::x8;
+  auto x_frag = [&](const char* sb, int s2, int ii) __attribute__((always_inline)) {
+    return *reinterpret_cast<const u32x4*>(sb + a_tile + ii * 16 * 128 + foff16[s2]);
   };
-  // ks_next < 0: no reads (the tile's last step when nothing follows); part < 0 or fill_buf < 0: no fill
-  auto placed_step = [&](int b, const char* sb_next, int ks_next, int fill_buf, int part) __attribute__((always_inline)) {
+  auto w_frag = [&](const char* sb, int s2, int jj) __attribute__((always_inline)) {
+    return *reinterpret_cast<const u32x4*>(sb + w_tile + jj * 16 * 128 + foff16[s2]);
+  };
+  auto mma16x16 = [&](int ii, int jj, const u32x4& wf, const u32x4& xf) __attribute__((always_inline)) {
+    if constexpr (kM16) acc4[ii][jj] = half_traits<H16>::mfma16(__builtin_bit_cast(X8h, wf), __builtin_bit_cast(X8h, xf), acc4[ii][jj]);
+  };
+  u32x4 kf16[(kM16 && kStream16) ? 2 : 1][4];
+  auto keep_frag = [&](const char* sb, int s2, int u) __attribute__((always_inline)) { return kKeepX ? x_frag(sb, s2, u) : w_frag(sb, s2, u); };
+  auto stream_frag = [&](const char* sb, int s2, int t) __attribute__((always_inline)) { return kKeepX ? w_frag(sb, s2, t) : x_frag(sb, s2, t); };
+  // ---- streamed form (SCHED 8).  The streamed fragments of a tile form ONE sequence g = step * NS + t over both steps, read two
+  //      groups ahead (one group = 4 MFMAs = 64 pipe cycles, 128 with the SIMD's other wave in between: one group of lookahead
+  //      does not cover an LDS round trip under load).  The tile's barrier sits IN FRONT of its last PB groups: every LDS read of
+  //      a tile still lies between the tile's two barriers, but the last PB groups' stream fragments are read early (two fragments per group over the groups
+  //      before them, then one group of slack for the LDS round trip), so behind the barrier 4 PB MFMAs run from registers while the
+  //      NEXT tile's kept fragments and first two stream fragments arrive -- barrier wait and LDS round trip under matrix work.
+  //      PB = 4 where the registers allow it (128 accumulator registers), 2 on the 160-register tiles.
+  constexpr int G16 = 2 * NS;
+  constexpr int PB16 = MI * NI * 16 > 128 ? 2 : 4;
+  constexpr int GD16 = G16 - 2 * PB16;                 // first group that reads two stream fragments
+  u32x4 sfr[(kM16 && kStream16) ? G16 : 1];
+  auto prime16 = [&](const char* sb) __attribute__((always_inline)) {
+    sfr[0] = stream_frag(sb, 0, 0);
 #pragma unroll
-    for (int n = 0; n < NM; ++n) {
-      const int i = n / NI, j = n % NI;
-      if (kUneven && i >= mi_w) break;   // wave-uniform
-      mma16<T>(acc[i][j], pwf[b][j], pxf[b][i]);
-      if (ks_next >= 0 && n < NR) placed_read(sb_next, ks_next, b ^ 1, n);
-      if (part >= 0 && part < kParts && fill_buf >= 0 && n == kFillSlot) fill_part_placed(fill_buf, part);
-      __builtin_amdgcn_sched_barrier(0);
+    for (int u = 0; u < 4; ++u) kf16[0][u] = keep_frag(sb, 0, u);
+    sfr[1] = stream_frag(sb, 0, 1);
+  };
+  // groups [g0, g1) of the tile in stage sb; sbn: the next tile's stage for the groups behind the barrier (has_next)
+  auto groups16 = [&](const char* sb, int g0, int g1, int fill_buf, int nparts, const char* sbn, bool has_next) __attribute__((always_inline)) {
+#pragma unroll
+    for (int g = 0; g < G16; ++g) {
+      if (g < g0 || g >= g1) continue;
+      const int s2 = g / NS, t = g % NS;
+      const bool post = g >= G16 - PB16;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (kKeepX) mma16x16(u, t, sfr[g], kf16[s2][u]);
+        else mma16x16(t, u, kf16[s2][u], sfr[g]);
+        if (!post) {
+          if (g < GD16) {
+            if (u == 0 && g + 2 < G16) sfr[g + 2] = stream_frag(sb, (g + 2) / NS, (g + 2) % NS);
+          } else {
+            const int f = GD16 + 2 + 2 * (g - GD16) + (u >> 1);
+            if ((u == 0 || u == 2) && f < G16) sfr[f] = stream_frag(sb, f / NS, f % NS);
+          }
+          if (s2 == 0 && u == 1 && t < 4) kf16[1][t] = keep_frag(sb, 1, t);
+          if (s2 == 0 && u == 3 && fill_buf >= 0 && t < nparts) fill_part_placed(fill_buf, t);
+        } else if (has_next && u < 3) {
+          const int r = (g - (G16 - PB16)) * 3 + u;     // 0: stream 0, 1..4: kept 0..3, 5: stream 1
+          if (r == 0) sfr[0] = stream_frag(sbn, 0, 0);
+          else if (r <= 4) kf16[0][r - 1] = keep_frag(sbn, 0, r - 1);
+          else if (r == 5) sfr[1] = stream_frag(sbn, 0, 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
+  // ---- fully double-buffered form (ring of three)
+  u32x4 xf16[(kM16 && !kStream16) ? 2 : 1][MI2], wf16[(kM16 && !kStream16) ? 2 : 1][NI2];
+  constexpr int NR16 = MI2 + NI2;                      // fragment reads of a step, in the order below
+  constexpr int MI2_MIN = kUneven ? 2 * (RB - (WM - 1) * MI) : MI2;
+  static_assert(!kM16 || kStream16 || NR16 <= MI2_MIN * NI2, "ring form: one fragment read per MFMA slot of the shortest wave row");
+  // read r of a step: the fragments every wave row needs first (x of its MI2_MIN blocks, then the w's), the long rows' extra x's last
+  auto read16 = [&](const char* sb, int s2, int b, int r) __attribute__((always_inline)) {
+    if (r < MI2_MIN) xf16[b][r] = x_frag(sb, s2, r);
+    else if (r < MI2_MIN + NI2) wf16[b][r - MI2_MIN] = w_frag(sb, s2, r - MI2_MIN);
+    else xf16[b][r - NI2] = x_frag(sb, s2, r - NI2);
+  };
+  auto read16_all = [&](const char* sb, int s2, int b) __attribute__((always_inline)) {
+#pragma unroll
+    for (int r = 0; r < NR16; ++r) read16(sb, s2, b, r);
+  };
+  // b: fragment buffer of this step; (sbn, sn): the step whose fragments are read meanwhile into b ^ 1 (sn < 0: none)
+  auto step16_full = [&](int b, const char* sbn, int sn, int fill_buf, int nparts) __attribute__((always_inline)) {
+#pragma unroll
+    for (int ii = 0; ii < MI2; ++ii) {
+      if (kUneven && ii >= mi2_w) break;   // wave-uniform
+#pragma unroll
+      for (int jj = 0; jj < NI2; ++jj) {
+        const int n = ii * NI2 + jj;
+        mma16x16(ii, jj, wf16[b][jj], xf16[b][ii]);
+        if (sn >= 0 && n < NR16) read16(sbn, sn, b ^ 1, n);
+        if (fill_buf >= 0 && jj == NI2 - 1 && ii >= 1 && ii - 1 < nparts) fill_part_placed(fill_buf, ii - 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
   };
 
@@ -658,23 +751,21 @@ void gemm_nt_kernel(const GemmParams p) {
     __syncthreads();
     if (trace && tid == 0) trace[1] = __builtin_amdgcn_s_memtime();
     int cur = 0, nxt = 1, nxt2 = 2;  // stages of tiles kt, kt+1, kt+2
-    if constexpr (kPlaced) {
-      placed_read_all(smem, 0, 0);
+    if constexpr (kM16) {
+      read16_all(smem, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
       for (int kt = 0; kt < KT - 1; ++kt) {
         const int fb = kt + 2 < KT ? nxt2 : -1;
         const char* sc = smem + cur * STAGE;
-        placed_step(0, sc, 1, fb, 0);
-        placed_step(1, sc, 2, fb, 1);
-        placed_step(0, sc, 3, fb, 2);
-        // this wave's pieces of tile kt+1 have landed and its reads of tile kt have returned: publish, then the last K
-        // step's MFMAs with the next tile's first fragment reads between them
+        step16_full(0, sc, 1, fb, kParts);            // the whole fill of tile kt+2 rides in this step (the counted wait below)
+        // this wave's pieces of tile kt+1 have landed and its last reads of tile kt have returned: publish, then the last step's
+        // MFMAs (registers only) with the next tile's first fragment reads between them
         if (fb >= 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kLeave) : "memory");
         else wait_vm0();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __syncthreads();
         __builtin_amdgcn_sched_barrier(0);
-        placed_step(1, smem + nxt * STAGE, 0, -1, -1);
+        step16_full(1, smem + nxt * STAGE, 0, -1, 0);
         cur = nxt; nxt = nxt2; nxt2 = 3 - cur - nxt;
       }
       if constexpr (kRowOperand) {
@@ -683,10 +774,8 @@ void gemm_nt_kernel(const GemmParams p) {
         __builtin_amdgcn_sched_barrier(0);
       }
       const char* sc = smem + cur * STAGE;
-      placed_step(0, sc, 1, -1, -1);
-      placed_step(1, sc, 2, -1, -1);
-      placed_step(0, sc, 3, -1, -1);
-      placed_step(1, sc, -1, -1, -1);
+      step16_full(0, sc, 1, -1, 0);
+      step16_full(1, sc, -1, -1, 0);
     } else {
     read_frags(0, 0, 0);
     for (int kt = 0; kt < KT - 1; ++kt) {
@@ -725,34 +814,32 @@ void gemm_nt_kernel(const GemmParams p) {
       __builtin_amdgcn_sched_barrier(0);
     }
     }
-  } else if constexpr (kPlaced) {
-    // two stages, hand-placed: the fill of tile kt+1 rides in the first kParts steps of tile kt; every step but the last
-    // carries the next step's fragment reads between its MFMAs; one barrier per tile, behind the last step
+  } else if constexpr (kM16) {
+    // two stages, 16x16x32 form: the fill of tile kt+1 rides in the first groups of tile kt; one barrier per tile, in front of
+    // the tile's last PB16 groups
     stage_issue(0);
     stage_ln_rows();
     wait_vm0();
     __syncthreads();
     if (trace && tid == 0) trace[1] = __builtin_amdgcn_s_memtime();
-    auto tile_placed = [&](int cur, int fb) __attribute__((always_inline)) {
-      const char* sc = smem + cur * STAGE;
-      placed_read_all(sc, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      placed_step(0, sc, 1, fb, 0);
-      placed_step(1, sc, 2, fb, 1);
-      placed_step(0, sc, 3, fb, 2);
-      placed_step(1, sc, -1, fb, 3);
-    };
+    prime16(smem);
+    __builtin_amdgcn_sched_barrier(0);
     for (int kt = 0; kt < KT - 1; ++kt) {
-      tile_placed(kt & 1, (kt & 1) ^ 1);
-      wait_vm0();
+      const char* sc = smem + (kt & 1) * STAGE;
+      const char* sn = smem + ((kt & 1) ^ 1) * STAGE;
+      groups16(sc, 0, G16 - PB16, (kt & 1) ^ 1, kParts, sn, false);
+      wait_vm0();                                       // this wave's pieces of tile kt+1 ...
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // ... and its last reads of tile kt
       __syncthreads();
+      __builtin_amdgcn_sched_barrier(0);
+      groups16(sc, G16 - PB16, G16, -1, 0, sn, true);
     }
     if constexpr (kRowOperand) {  // the residual / position rows of the first 32-row block travel during the last K tile
       load_block(0, add[0]);
       add_ready = true;
       __builtin_amdgcn_sched_barrier(0);
     }
-    tile_placed((KT - 1) & 1, -1);
+    groups16(smem + ((KT - 1) & 1) * STAGE, 0, G16, -1, 0, smem, false);
   } else {
     stage_issue(0);
     stage_ln_rows();
@@ -801,21 +888,56 @@ void gemm_nt_kernel(const GemmParams p) {
     // (SQ_LDS_BANK_CONFLICT = 0); the half swap is undone in registers, statically per store iteration.
     constexpr int HP = 128;
     using X4 = typename half_traits<OutT>::x4;
+    // bias of this lane's columns: 32x32 form 4 columns at 8q + 4 lgrp of each 32-column block, 16x16 form at 16a + 4 g16
     float4 bq[NI][4];
 #pragma unroll
     for (int j = 0; j < NI; ++j)
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
-        bq[j][q] = *reinterpret_cast<const float4*>(p.bias + n0 + wn * TN + j * 32 + 8 * q + 4 * lgrp);
+      for (int q = 0; q < (kM16 ? 2 : 4); ++q)
+        bq[j][q] = *reinterpret_cast<const float4*>(p.bias + n0 + wn * TN + j * 32 + (kM16 ? 16 * q + 4 * g16 : 8 * q + 4 * lgrp));
     const int hr_row = lane >> 3, hr_chunk = lane & 7;  // 8 lanes x 16 B = one 128-byte output row piece
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
       if (kUneven && i >= mi_w) break;   // wave-uniform
-      float ln_rs = 1.f;
-      if constexpr (epi_is_ln(EPI))  // this lane's row of the block: rstd of the LayerNorm input row (staged at kernel start)
-        ln_rs = *reinterpret_cast<const float*>(smem + NSTAGE * STAGE + (wm * TM + i * 32 + lrow) * 4);
+      float ln_rs = 1.f, ln_rs2[2] = {1.f, 1.f};
+      if constexpr (epi_is_ln(EPI)) {  // this lane's row(s) of the block: rstd of the LayerNorm input row (staged at kernel start)
+        if constexpr (kM16) {
+          ln_rs2[0] = *reinterpret_cast<const float*>(smem + NSTAGE * STAGE + (wm * TM + i * 32 + l16) * 4);
+          ln_rs2[1] = *reinterpret_cast<const float*>(smem + NSTAGE * STAGE + (wm * TM + i * 32 + 16 + l16) * 4);
+        } else {
+          ln_rs = *reinterpret_cast<const float*>(smem + NSTAGE * STAGE + (wm * TM + i * 32 + lrow) * 4);
+        }
+      }
 #pragma unroll
       for (int jp = 0; jp < NI / 2; ++jp) {
+        if constexpr (kM16) {
+          // 16x16 tiles (b = row half, a = column half) of the 32 x 64 slab: row 16b + l16, columns jj*32 + 16a + 4 g16 .. +3 ->
+          // 16-byte chunk jj*4 + 2a + (g16 >> 1), 8-byte half g16 & 1; same swizzle as below (the 16 lanes of a ds_write_b64
+          // group are again 16 consecutive rows of one column)
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+              for (int b = 0; b < 2; ++b) {
+                const int j = 2 * jp + jj;
+                const f32x4 c = acc4[2 * i + b][2 * j + a];
+                float v0, v1, v2, v3;
+                if constexpr (epi_is_ln(EPI)) {
+                  v0 = fmaf(ln_rs2[b], c[0], bq[j][a].x); v1 = fmaf(ln_rs2[b], c[1], bq[j][a].y);
+                  v2 = fmaf(ln_rs2[b], c[2], bq[j][a].z); v3 = fmaf(ln_rs2[b], c[3], bq[j][a].w);
+                } else {
+                  v0 = c[0] + bq[j][a].x; v1 = c[1] + bq[j][a].y; v2 = c[2] + bq[j][a].z; v3 = c[3] + bq[j][a].w;
+                }
+                if constexpr (EPI == EPI_BIAS_QGELU || EPI == EPI_QGELU_LN) {
+                  v0 = quick_gelu<false>(v0); v1 = quick_gelu<false>(v1);
+                  v2 = quick_gelu<false>(v2); v3 = quick_gelu<false>(v3);
+                }
+                const X4 pk = {from_f32<OutT>(v0), from_f32<OutT>(v1), from_f32<OutT>(v2), from_f32<OutT>(v3)};
+                const int row = 16 * b + l16, chunk = jj * 4 + 2 * a + (g16 >> 1), half = g16 & 1;
+                *reinterpret_cast<X4*>(slab + row * HP + ((chunk ^ (row & 7)) << 4) + ((half ^ ((row >> 3) & 1)) << 3)) = pk;
+              }
+        } else {
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
@@ -837,6 +959,7 @@ void gemm_nt_kernel(const GemmParams p) {
             *reinterpret_cast<X4*>(slab + lrow * HP + (((jj * 4 + q) ^ (lrow & 7)) << 4) +
                                    ((lgrp ^ ((lrow >> 3) & 1)) << 3)) = pk;
           }
+        }
         __builtin_amdgcn_wave_barrier();
         u32x4 o[4];
 #pragma unroll
@@ -877,6 +1000,16 @@ void gemm_nt_kernel(const GemmParams p) {
     }
 #pragma unroll
     for (int jp = 0; jp < NI / 2; ++jp) {
+      if constexpr (kM16) {   // row 16b + l16, columns jj*32 + 16a + 4 g16 .. +3 (8 consecutive lanes = 8 rows x 16 B: all 32 banks once)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+          for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+              *reinterpret_cast<f32x4*>(slab + (16 * b + l16) * SLAB_PITCH + (jj * 32 + 16 * a + 4 * g16) * 4) =
+                  acc4[2 * i + b][2 * (2 * jp + jj) + a];
+      } else {
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
@@ -885,6 +1018,7 @@ void gemm_nt_kernel(const GemmParams p) {
                            acc[i][2 * jp + jj][4 * q + 3]};
           *reinterpret_cast<f32x4*>(slab + lrow * SLAB_PITCH + (jj * 32 + 8 * q + 4 * lgrp) * 4) = v;
         }
+      }
       __builtin_amdgcn_wave_barrier();  // LDS ops of one wave execute in order; keep the compiler from reordering
       if constexpr (EPI == EPI_RESID_SPLIT) {
         // 8 columns per lane, 8 rows per pass: every global access of the two planes is a full 16-byte piece

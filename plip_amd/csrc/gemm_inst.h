@@ -40,12 +40,12 @@ int launch_naive(const GemmParams& p, hipStream_t stream) {
 // plipmi_set_gemm_variant take, names come from gemm.hip.
 //   0  128x128, 2x2 waves, two workgroups per CU, 64-bit lane addresses (operands of 4 GiB and more; small problems)
 //   1  128x128, 2x2 waves, buffer-form LDS-DMA
-//   2  256x256, 4x2 waves, hand-placed K steps (16-bit engines)
-//   3  320x256, 2x4 waves
+//   2  256x256, 4x2 waves; 16-bit engines: 16x16x32 MFMAs, hand-placed K steps, barrier in front of the tile's last groups
+//   3  320x256, 2x4 waves; 16-bit engines: as 2
 //   4  192x256, 2x4 waves
 //   5  160x256, 2x4 waves with 3 + 2 row blocks per wave row: 240 / 248 tiles on the bs=256 residual GEMMs (256 CUs)
-//   6  160x256 on a ring of three LDS stages (two K tiles of lookahead, barrier in front of the last K step's MFMAs),
-//      hand-placed K steps (16-bit engines)
+//   6  160x256 on a ring of three LDS stages (two K tiles of lookahead, barrier in front of the last K step's MFMAs);
+//      16-bit engines: 16x16x32 MFMAs, hand-placed K steps
 constexpr int kNumVariants = 7;
 
 template <typename T>
@@ -65,8 +65,8 @@ struct GemmTable {
       switch (variant) {
         case 0: return launch_tiled<T, 128, 128, 2, 2, EPI, 0, 0>;
         case 1: return launch_tiled<T, 128, 128, 2, 2, EPI, 1, 1>;
-        case 2: return launch_tiled<T, 256, 256, 4, 2, EPI, kH ? 9 : 1, 1>;
-        case 3: return launch_tiled<T, 320, 256, 2, 4, EPI, kH ? 6 : 0, 1>;
+        case 2: return launch_tiled<T, 256, 256, 4, 2, EPI, kH ? 8 : 1, 1>;
+        case 3: return launch_tiled<T, 320, 256, 2, 4, EPI, kH ? 8 : 0, 1>;
         case 4: return launch_tiled<T, 192, 256, 2, 4, EPI, kH ? 6 : 1, 1>;
         case 5: return launch_tiled<T, 160, 256, 2, 4, EPI, kH ? 6 : 1, 1>;
         case 6: return launch_tiled<T, 160, 256, 2, 4, EPI, kH ? 7 : 1, 1, 3>;

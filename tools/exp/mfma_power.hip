@@ -14,13 +14,13 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 // MODE 0: 32x32x16, 8 accumulators (4 A x 2 B fragments); 1: 16x16x32, 32 accumulators (8 A x 4 B): same FLOPs / same
 // operand bytes per "step" (8 x 32K FLOP).  LDS = number of ds_read_b128 per step (0, 6, 12) refreshing fragments.
 // AG = 1: the accumulators are pinned to the accumulation register file (AGPRs) through inline asm ("a" constraint)
-template <int MODE, int LDS, int AG = 0>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+template <int MODE, int LDS, int AG = 0, int W = 2>
+__global__ __launch_bounds__(256 * W) __attribute__((amdgpu_waves_per_eu(W, W)))
 void k(const u32x4* __restrict__ src, float* __restrict__ out, int iters, unsigned long long* clk) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   u32x4* l = reinterpret_cast<u32x4*>(smem);
-  for (int i = tid; i < 4096; i += 512) l[i] = src[(blockIdx.x * 4096 + i) % (1 << 20)];
+  for (int i = tid; i < 4096; i += 256 * W) l[i] = src[(blockIdx.x * 4096 + i) % (1 << 20)];
   __syncthreads();
   constexpr int NA = MODE == 0 ? 4 : 8, NB = MODE == 0 ? 2 : 4;
   u32x4 a[NA], b[NB];
@@ -107,20 +107,20 @@ void k(const u32x4* __restrict__ src, float* __restrict__ out, int iters, unsign
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s failed: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
-template <int MODE, int LDS, int AG = 0>
+template <int MODE, int LDS, int AG = 0, int W = 2>
 void run(const char* name, const u32x4* src, float* out, unsigned long long* clk, int iters, bool zero) {
-  auto kern = k<MODE, LDS, AG>;
+  auto kern = k<MODE, LDS, AG, W>;
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   const int blocks = 256;
-  for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), 65536, 0, src, out, iters, clk);
+  for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(kern, dim3(blocks), dim3(256 * W), 65536, 0, src, out, iters, clk);
   CK(hipDeviceSynchronize());
   float best = 1e9f, sum = 0.f;
   const int reps = 6;
   for (int r = 0; r < reps; ++r) {
     CK(hipEventRecord(e0));
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), 65536, 0, src, out, iters, clk);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256 * W), 65536, 0, src, out, iters, clk);
     CK(hipEventRecord(e1));
     CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
@@ -160,6 +160,10 @@ int main() {
     run<0, 6, 1>("32x32x16 + 6 ds_read / 8, AGPR", src, out, clk, iters, zero);
     run<1, 6, 1>("16x16x32 + 6 ds_read / 16, AGPR", src, out, clk, iters, zero);
     run<1, 3, 1>("16x16x32 + 3 ds_read / 16, AGPR", src, out, clk, iters, zero);
+    run<0, 0, 1, 1>("32x32x16 bare AGPR, ONE wave/SIMD", src, out, clk, iters, zero);
+    run<1, 0, 1, 1>("16x16x32 bare AGPR, ONE wave/SIMD", src, out, clk, iters, zero);
+    run<0, 3, 1, 1>("32x32x16 + 3 ds_read, ONE wave/SIMD", src, out, clk, iters, zero);
+    run<1, 3, 1, 1>("16x16x32 + 3 ds_read, ONE wave/SIMD", src, out, clk, iters, zero);
     run<0, 6>("32x32x16 + 6 ds_read_b128 / 8 MFMA", src, out, clk, iters, zero);
     run<1, 6>("16x16x32 + 6 ds_read_b128 / 16 MFMA", src, out, clk, iters, zero);
     run<0, 3>("32x32x16 + 3 ds_read_b128 / 8 MFMA", src, out, clk, iters, zero);
