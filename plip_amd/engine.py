@@ -19,10 +19,10 @@ _DTYPES = {"fp32": _lib.F32, "f32": _lib.F32, "float32": _lib.F32, torch.float32
            "f16": _lib.F16, "fp16": _lib.F16, "float16": _lib.F16, "half": _lib.F16, torch.float16: _lib.F16}
 # bf16 engine: leading text blocks that run on f16 operands by default.  The bf16 engine's cosine error is mostly operand
 # rounding in the FIRST text blocks (the residual stream is small there, so a block's rounding error is large against it:
-# profiles/r04_text_layer_precision.txt); two f16 blocks of 24 take the bs=256 fixture from 8.3e-4 to 6.3e-4 of the 1e-3 bar
-# (heavy-tailed checkpoint 8.4e-4 -> 4.7e-4) for 1.5 % of the step (profiles/r04_text_f16_layers.txt).
+# profiles/r04_text_layer_precision.txt); four f16 blocks of 24 take the bs=256 fixture from 8.3e-4 to 4.7e-4 of the 1e-3 bar
+# (heavy-tailed checkpoint 8.4e-4 -> 2.9e-4) for 2 % of the step (profiles/r04_text_f16_layers.txt).
 # text_f16_layers=0 is the pure bf16 engine, =t_layers the TEXT_TOWER_F16 one.
-DEFAULT_TEXT_F16_LAYERS = 2
+DEFAULT_TEXT_F16_LAYERS = 4
 
 _TORCH_DTYPE = {_lib.F32: torch.float32, _lib.BF16: torch.bfloat16, _lib.F16: torch.float16}
 

@@ -181,7 +181,7 @@ def test_the_first_text_blocks_carry_the_bf16_error(golden):
     """WHERE in the text tower bf16's operand rounding costs text_embeds, costed on the CPU: the same
     emulation with the operand type chosen per block.  f16 in the FIRST two blocks removes a third of the error, in the
     LAST two nothing -- the residual stream is small at the bottom of the tower, so a block's rounding error is large
-    against it and every later LayerNorm carries it along.  Hence plipmi_config.text_f16_layers (leading blocks), default 2."""
+    against it and every later LayerNorm carries it along.  Hence plipmi_config.text_f16_layers (leading blocks), default 4."""
     from oracle import precision_model as P
     g = golden("vitb32_b256")
     cfg, sd, px, ids, mask = case_inputs("vitb32_b256")
