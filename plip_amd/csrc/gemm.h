@@ -609,8 +609,9 @@ void gemm_nt_kernel(const GemmParams p) {
       const bool post = g >= G16 - PB16;
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        if (kKeepX) mma16x16(u, t, sfr[g], kf16[s2][u]);
-        else mma16x16(t, u, kf16[s2][u], sfr[g]);
+        const int us = (g & 1) ? 3 - u : u;             // serpentine over the kept fragments: one operand changes per MFMA
+        if (kKeepX) mma16x16(us, t, sfr[g], kf16[s2][us]);
+        else mma16x16(t, us, kf16[s2][us], sfr[g]);
         if (!post) {
           if (g < GD16) {
             if (u == 0 && g + 2 < G16) sfr[g + 2] = stream_frag(sb, (g + 2) / NS, (g + 2) % NS);
@@ -653,7 +654,8 @@ void gemm_nt_kernel(const GemmParams p) {
 #pragma unroll
       for (int jj = 0; jj < NI2; ++jj) {
         const int n = ii * NI2 + jj;
-        mma16x16(ii, jj, wf16[b][jj], xf16[b][ii]);
+        const int js = (ii & 1) ? NI2 - 1 - jj : jj;   // serpentine: one operand changes per MFMA, also at a row change (+0.5-1.5 % warm)
+        mma16x16(ii, js, wf16[b][js], xf16[b][ii]);
         if (sn >= 0 && n < NR16) read16(sbn, sn, b ^ 1, n);
         if (fill_buf >= 0 && jj == NI2 - 1 && ii >= 1 && ii - 1 < nparts) fill_part_placed(fill_buf, ii - 1);
         __builtin_amdgcn_sched_barrier(0);

@@ -130,12 +130,14 @@ void run(const char* name, const u32x4* src, float* out, unsigned long long* clk
   CK(hipMemcpy(h.data(), clk, blocks * 16, hipMemcpyDeviceToHost));
   double cyc = 0, real = 0;
   for (int i = 0; i < blocks; ++i) { cyc += h[2 * i]; real += h[2 * i + 1]; }
-  const double flop = (double)blocks * 8 /*waves*/ * iters * 8 * 32768.0 * 2 / 2;   // 8 x 32K-MAC... 32x32x16 = 32768 FLOP
-  const double fl = (double)blocks * 8 * (double)iters * 8.0 * 32768.0;
-  (void)flop;
+  // FLOPs: waves x iterations x MFMAs per iteration x FLOP per MFMA.  MODE 0 issues 8 x 32x32x16 (32768 FLOP each) per iteration,
+  // MODE 1 issues 32 x 16x16x32 (16384 FLOP each) = TWICE the FLOPs per iteration.  (Until the second half of round 4 this line
+  // priced both modes at 8 x 32768 and every 16x16x32 figure printed was half the truth.)
+  const double per_iter = MODE == 0 ? 8 * 32768.0 : 32 * 16384.0;
+  const double fl = (double)blocks * (4 * W) * (double)iters * per_iter;
   printf("%-34s %s operands: %8.3f ms (mean %8.3f)  %7.1f TFLOP/s   shader clock %.3f GHz   MFMA issue %.1f %% of cycles\n", name,
          zero ? "ZERO  " : "random", best, sum / reps, fl / (best * 1e-3) / 1e12, cyc / real / 10.0 / 1e0 / 1e0 * 1e-0 / 100.0 * 100.0 / 100.0,
-         100.0 * (double)iters * 8 * 32.0 * 2 / (cyc / blocks));
+         100.0 * (double)iters * (MODE == 0 ? 8 * 32.0 : 32 * 16.0) * 2 / (cyc / blocks));
 }
 
 int main() {
