@@ -263,6 +263,29 @@ def sec_latency():
     model.engine.close()
 
 
+def sec_latprof():
+    """For rocprofv3 --kernel-trace --stats: the B=8 towers on the latency path (argv[2] = 1) or the big tiles (0), graph replay,
+    20 calls each -- which kernels a small call spends its time in."""
+    cfg = get_config("ViT-B/32")
+    model = PlipModel(cfg, W.synthetic_state_dict(cfg, 0), dtype="bf16", max_batch=32)
+    eng = model.engine
+    B = 8
+    px = torch.from_numpy(W.synthetic_pixels(cfg, B, 1)).to(dev)
+    ids = torch.from_numpy(W.synthetic_ids(cfg, B, 2)[0]).to(dev)
+    eng.set_latency_batch(32 if (len(sys.argv) > 2 and sys.argv[2] == "1") else 0)
+    eng.set_graph_batch(32)
+    for _ in range(4):
+        eng.encode_image(px, True); eng.encode_text(ids, None, True)
+    torch.cuda.synchronize()
+    for _ in range(20):
+        eng.encode_image(px, True)
+        torch.cuda.synchronize()
+    for _ in range(20):
+        eng.encode_text(ids, None, True)
+        torch.cuda.synchronize()
+    model.engine.close()
+
+
 def sec_zeroshot():
     """PLIP.zero_shot_classification (plip.py:89-103: both encoders at the hard-coded batch_size=8) on 256 native tiles + 10
     labels: one engine call per caller batch (round 3's behaviour, PLIP.coalesce = False) vs the caller's batches handed to the
@@ -831,5 +854,5 @@ def sec_e2e():
 if __name__ == "__main__":
     t0 = time.time()
     {"gemm": sec_gemm, "attn": sec_attn, "tiny": sec_tiny, "vitb32": sec_vitb32, "gemmbench": sec_gemmbench, "lnbench": sec_lnbench, "latency": sec_latency, "libgemm": sec_libgemm, "tiles": sec_tiles, "parity": sec_parity, "sustain": sec_sustain, "power": sec_power, "cold": sec_cold, "towerswap": sec_towerswap, "e2e": sec_e2e, "gemmone": sec_gemmone, "policy": sec_policy, "ldpad": sec_ldpad, "gemmtrace": sec_gemmtrace,
-     "overlap": sec_overlap, "stepab": sec_stepab, "cumask": sec_cumask, "mixed": sec_mixed, "zeroshot": sec_zeroshot}[sys.argv[1]]()
+     "overlap": sec_overlap, "stepab": sec_stepab, "cumask": sec_cumask, "mixed": sec_mixed, "zeroshot": sec_zeroshot, "latprof": sec_latprof}[sys.argv[1]]()
     print(f"[{sys.argv[1]} done in {time.time() - t0:.1f} s]")
