@@ -589,9 +589,10 @@ void gemm_nt_kernel(const GemmParams p) {
   //      a tile still lies between the tile's two barriers, but the last PB groups' stream fragments are read early (two fragments per group over the groups
   //      before them, then one group of slack for the LDS round trip), so behind the barrier 4 PB MFMAs run from registers while the
   //      NEXT tile's kept fragments and first two stream fragments arrive -- barrier wait and LDS round trip under matrix work.
-  //      PB = 4 where the registers allow it (128 accumulator registers), 2 on the 160-register tiles.
+  //      PB = 4 on both tiles (320x256, 160 accumulator registers: 3407 -> 3249 cycles per K tile against PB = 2; its plain epilogues
+  //      spill 3-17 registers outside the loop either way, the LayerNorm-folded fc1 epilogue none).
   constexpr int G16 = 2 * NS;
-  constexpr int PB16 = MI * NI * 16 > 128 ? 2 : 4;
+  constexpr int PB16 = 4;
   constexpr int GD16 = G16 - 2 * PB16;                 // first group that reads two stream fragments
   u32x4 sfr[(kM16 && kStream16) ? G16 : 1];
   auto prime16 = [&](const char* sb) __attribute__((always_inline)) {
