@@ -7,7 +7,8 @@
 // (:148-154) and, with A = image embeds / W = text embeds, the logits (:814).
 //
 // gfx950 design
-//   * MFMA 32x32 tiles: v_mfma_f32_32x32x16_bf16 / _f16 (the two 16-bit engines) or
+//   * MFMA: v_mfma_f32_16x16x32_bf16 / _f16 in the production tiles of the two 16-bit engines (variants 2, 3, 6: less
+//     power per FLOP than 32x32x16, see the note above the kernel), v_mfma_f32_32x32x16 in the other 16-bit tiles, or
 //     v_mfma_f32_32x32x2_f32 (exact fp32, fmaf-chain numerics).  Operands are SWAPPED -- the weight
 //     fragment is the MFMA "A" operand and the activation fragment the "B"
 //     operand -- so a lane ends up with 4 CONSECUTIVE output columns of one
@@ -259,8 +260,8 @@ struct EpilogueOp {
 //           barrier sits IN FRONT of its last K step's MFMAs: behind it a wave first requests the next tile's first
 //           fragments, then issues the MFMA group it still holds in registers -- the LDS round trip every wave starts a tile
 //           with runs under matrix work instead of in front of it (1893 -> 1768 cycles per K tile).
-//           (With two stages the same move buys 0-2 % per kernel and nothing on the step: there the iteration waits for the fill --
-//           profiles/r02_experiments_not_shipped.txt item 6, re-measured in round 3.)
+//           (With two stages AND the 32x32 burst schedule the same move buys 0-2 % per kernel and nothing on the step; the
+//           streamed 16x16x32 two-stage form, SCHED 8, makes it pay: 2965 -> 2608 cycles per K tile, profiles/r04_gemm_m16.txt.)
 // ADDR 0: 64-bit per-lane global addresses (any operand size); 1: buffer resource + 32-bit lane offset (< 4 GiB).
 // waves per SIMD the kernel is built for: 2 (LDS caps residency there, so let the allocator use 256 VGPRs)
 // index sets of the staged fill: [p0, p1) without [g0, g1)

@@ -1,4 +1,4 @@
-// f16 instantiations (v_mfma_f32_32x32x16_f16, fp32 accumulate) of the NT GEMM.
+// f16 instantiations (v_mfma_f32_16x16x32_f16 / v_mfma_f32_32x32x16_f16, fp32 accumulate) of the NT GEMM.
 #include "gemm_inst.h"
 namespace plipmi {
 GemmLaunchFn gemm_get_f16(int variant, int epi) { return GemmTable<f16_t>::get(variant, epi); }
