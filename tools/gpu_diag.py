@@ -463,8 +463,8 @@ def sec_gemmtrace():
     print("  workgroups per XCC:", np.bincount(xcc, minlength=8).tolist())
 
 
-def _step_inputs(B=256):
-    cfg = get_config("ViT-B/32")
+def _step_inputs(B=256, arch="ViT-B/32"):
+    cfg = get_config(arch)
     sd = W.synthetic_state_dict(cfg, 0)
     px = torch.from_numpy(W.synthetic_pixels(cfg, B, 1000)).to(dev)
     ids_np, mask_np = W.synthetic_ids(cfg, B, 2000)
@@ -547,8 +547,8 @@ def sec_stepab():
     from plip_amd import _lib
     from plip_amd.dist import sharded_pair_logits
     lib = _lib.load()
-    B = 256
-    cfg, sd, px, ids, mask = _step_inputs(B)
+    B = int(os.environ.get("STEPAB_BATCH", "256"))            # STEPAB_ARCH / STEPAB_BATCH: the same A/B on another tower pair
+    cfg, sd, px, ids, mask = _step_inputs(B, os.environ.get("STEPAB_ARCH", "ViT-B/32"))
     model = PlipModel(cfg, sd, dtype=os.environ.get("STEPAB_DTYPE", "bf16"), max_batch=B)
     arms = sys.argv[2:] or ["base"]
     names = gemm_variants()
