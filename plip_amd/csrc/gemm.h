@@ -95,6 +95,10 @@ struct GemmParams {
   // test hook (plipmi_gemm_nt_traced): per workgroup 8 x u64 {start, prologue done, main loop done, epilogue
   // done, logical tile id, HW_ID, k tiles, 0}, s_memtime ticks.  nullptr on the product path.
   unsigned long long* trace = nullptr;
+  // test hook (plipmi_set_gemm_variant 2000 + mode; SCHED 9 tiles, two workgroups per CU): 1 = the workgroup that owns the CU's
+  // FIRST LDS allocation raises its waves' issue priority, 2 = the second one does -- the slot with priority finishes its K
+  // loop first and stores while the other slot multiplies.  0 (product path): no priorities.
+  int duo = 0;
 };
 
 // LDS-DMA (global_load_lds_dwordx4): each lane's 16 bytes at `gsrc` land at
@@ -289,16 +293,21 @@ template <typename T, int BM, int BN, int WM, int WN, int EPI, int SCHED = 0, in
 __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void gemm_nt_kernel(const GemmParams p) {
   constexpr int NT = WM * WN * 64;
+  // SCHED 9 (16x16x32 streamed form): wave rows are dealt in 16-ROW blocks -- BM / WM rows each, a multiple of 16 but not
+  // necessarily of 32 (160x128 on 2x2 waves: 80 rows = five 16-row MFMA tiles per wave row, all wave rows equal).  The
+  // epilogues still walk 32-row slabs; a wave row's last slab may then be a half slab (kHalf paths below).
+  constexpr bool kHalf = SCHED == 9;
   constexpr int RB = BM / 32;                  // 32-row blocks of the tile
-  constexpr int MI = (RB + WM - 1) / WM;       // ... per wave row (the last one may hold fewer)
-  constexpr bool kUneven = RB % WM != 0;
-  constexpr int TM = MI * 32, TN = BN / WN;
+  constexpr int MI = kHalf ? (BM / WM + 31) / 32 : (RB + WM - 1) / WM;   // ... per wave row (the last one may hold fewer)
+  constexpr bool kUneven = !kHalf && RB % WM != 0;
+  constexpr int TM = kHalf ? BM / WM : MI * 32, TN = BN / WN;
+  static_assert(!kHalf || (BM % WM == 0 && TM % 16 == 0), "SCHED 9: wave rows of whole 16-row MFMA tiles");
   constexpr int NI = TN / 32;
   constexpr int ELEMS16 = 16 / sizeof(T);  // elements per 16-byte chunk
   using OutT = std::conditional_t<sizeof(T) == 4, float, T>;
   static_assert(!(epi_is_ln(EPI) || epi_emits_stats(EPI)) || sizeof(T) == 2, "LayerNorm folding is a 16-bit-engine form");
-  static_assert(SCHED == 0 || SCHED == 1 || SCHED == 5 || SCHED == 6 || SCHED == 7 || SCHED == 8,
-                "schedules: 0, 1, 5 (fill2), 6 (fill3), 7 / 8 (16x16x32 form: ring of three / two stages)");
+  static_assert(SCHED == 0 || SCHED == 1 || SCHED == 5 || SCHED == 6 || SCHED == 7 || SCHED == 8 || SCHED == 9,
+                "schedules: 0, 1, 5 (fill2), 6 (fill3), 7 / 8 / 9 (16x16x32 form: ring of three / two stages / two stages, 16-row dealing)");
   static_assert(NSTAGE == 2 || NSTAGE == 3, "two LDS stages or a ring of three");
   constexpr bool kSpread = SCHED >= 5;
   constexpr bool kM16 = SCHED >= 7;
@@ -507,7 +516,9 @@ void gemm_nt_kernel(const GemmParams p) {
   // 16x16x32 form: the wave's 32x32 blocks as four 16x16 tiles each.  acc4[2i+b][2j+a][e] = C[m = 32i + 16b + (lane & 15)]
   // [n = 32j + 16a + 4 (lane >> 4) + e]: a lane holds TWO rows of a block (b = 0, 1) and, per row, 4 consecutive columns in each
   // 16-column half -- again whole 16-byte fp32 / 8-byte 16-bit pieces of an output row.
-  constexpr int MI2 = 2 * MI, NI2 = 2 * NI;
+  constexpr int MI2 = kHalf ? TM / 16 : 2 * MI, NI2 = 2 * NI;
+  // rows of a wave row's 32-row slab i that exist (kHalf: the last slab may be a half slab)
+  auto slab_rows = [](int i) constexpr { return kHalf ? (TM - 32 * i < 32 ? TM - 32 * i : 32) : 32; };
   f32x4 acc4[kM16 ? MI2 : 1][kM16 ? NI2 : 1];
 #pragma unroll
   for (int i = 0; i < (kM16 ? MI2 : 1); ++i)
@@ -534,6 +545,7 @@ void gemm_nt_kernel(const GemmParams p) {
       for (int jp = 0; jp < NI / 2; ++jp)
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
+          if (it * 8 >= slab_rows(i)) continue;   // half slab: rows 16.. belong to the next wave row
           int m = m0 + wm * TM + i * 32 + it * 8 + (lane >> 3);
           m = m < Mrt ? m : Mrt - 1;
           const size_t off = (size_t)m * p.ldc + n0 + wn * TN + jp * 64 + (lane & 7) * 8;
@@ -545,6 +557,7 @@ void gemm_nt_kernel(const GemmParams p) {
       for (int jp = 0; jp < NI / 2; ++jp)
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
+          if (it * 4 >= slab_rows(i)) continue;
           const int m = m0 + wm * TM + i * 32 + it * 4 + rd_row;
           dst[jp][it] = EpilogueOp<T, EPI>::load(p, m < Mrt ? m : Mrt - 1, n0 + wn * TN + jp * 64 + rd_col);
         }
@@ -564,7 +577,7 @@ void gemm_nt_kernel(const GemmParams p) {
   constexpr bool kStream16 = NSTAGE == 2;
   constexpr bool kKeepX = MI2 <= NI2;                 // (streamed form) keep the activation fragments, stream the weights -- or the reverse
   constexpr int NK = kKeepX ? MI2 : NI2, NS = kKeepX ? NI2 : MI2;
-  static_assert(!kM16 || !kStream16 || (NK == 4 && NS % 2 == 0 && NS >= 4), "streamed 16x16x32 form: four kept fragments, an even number of streamed ones");
+  static_assert(!kM16 || !kStream16 || (NK == 4 && NS >= 4), "streamed 16x16x32 form: four kept fragments, at least four streamed ones");
   static_assert(!kM16 || !kStream16 || !kUneven, "uneven tiles run on the ring");
   const int mi2_w = kUneven ? 2 * mi_w : MI2;         // 16-row blocks this wave multiplies (wave-uniform)
   int foff16[2];
@@ -723,7 +736,14 @@ void gemm_nt_kernel(const GemmParams p) {
     trace[4] = lid;
     trace[5] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4 /* HW_ID [31:0] */) |
                ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20 /* XCC_ID [3:0] */) << 32);
-    trace[6] = KT;
+    trace[6] = (unsigned long long)KT |
+               ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 6 /* LDS_ALLOC [31:0] */) << 32);
+  }
+  if constexpr (kHalf) {
+    if (p.duo) {   // wave-uniform
+      const unsigned lds_base = __builtin_amdgcn_s_getreg((7 << 11) | (0 << 6) | 6 /* LDS_ALLOC.LDS_BASE [7:0] */);
+      if ((lds_base == 0) == (p.duo == 1)) __builtin_amdgcn_s_setprio(2);
+    }
   }
   if constexpr (NSTAGE == 3) {
     // Ring of three.  Invariants at the top of iteration kt: tile kt is visible and its K-step-0 fragments are in registers;
@@ -907,7 +927,8 @@ void gemm_nt_kernel(const GemmParams p) {
       if constexpr (epi_is_ln(EPI)) {  // this lane's row(s) of the block: rstd of the LayerNorm input row (staged at kernel start)
         if constexpr (kM16) {
           ln_rs2[0] = *reinterpret_cast<const float*>(smem + NSTAGE * STAGE + (wm * TM + i * 32 + l16) * 4);
-          ln_rs2[1] = *reinterpret_cast<const float*>(smem + NSTAGE * STAGE + (wm * TM + i * 32 + 16 + l16) * 4);
+          if (slab_rows(i) > 16)
+            ln_rs2[1] = *reinterpret_cast<const float*>(smem + NSTAGE * STAGE + (wm * TM + i * 32 + 16 + l16) * 4);
         } else {
           ln_rs = *reinterpret_cast<const float*>(smem + NSTAGE * STAGE + (wm * TM + i * 32 + lrow) * 4);
         }
@@ -924,8 +945,9 @@ void gemm_nt_kernel(const GemmParams p) {
             for (int a = 0; a < 2; ++a)
 #pragma unroll
               for (int b = 0; b < 2; ++b) {
+                if (16 * b >= slab_rows(i)) continue;
                 const int j = 2 * jp + jj;
-                const f32x4 c = acc4[2 * i + b][2 * j + a];
+                const f32x4 c = acc4[2 * i + b < MI2 ? 2 * i + b : 0][2 * j + a];
                 float v0, v1, v2, v3;
                 if constexpr (epi_is_ln(EPI)) {
                   v0 = fmaf(ln_rs2[b], c[0], bq[j][a].x); v1 = fmaf(ln_rs2[b], c[1], bq[j][a].y);
@@ -968,11 +990,13 @@ void gemm_nt_kernel(const GemmParams p) {
         u32x4 o[4];
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
+          if (it * 8 >= slab_rows(i)) continue;
           const u32x4 raw = *reinterpret_cast<const u32x4*>(slab + (it * 8 + hr_row) * HP + ((hr_chunk ^ hr_row) << 4));
           o[it] = (it & 1) ? u32x4{raw[2], raw[3], raw[0], raw[1]} : raw;  // rows 8..15, 24..31: halves were swapped
         }
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
+          if (it * 8 >= slab_rows(i)) continue;
           int m = m0 + wm * TM + i * 32 + it * 8 + hr_row;
           const bool in_range = m < Mrt;
           if (in_range)
@@ -1010,9 +1034,11 @@ void gemm_nt_kernel(const GemmParams p) {
 #pragma unroll
           for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int b = 0; b < 2; ++b)
+            for (int b = 0; b < 2; ++b) {
+              if (16 * b >= slab_rows(i)) continue;
               *reinterpret_cast<f32x4*>(slab + (16 * b + l16) * SLAB_PITCH + (jj * 32 + 16 * a + 4 * g16) * 4) =
-                  acc4[2 * i + b][2 * (2 * jp + jj) + a];
+                  acc4[2 * i + b < MI2 ? 2 * i + b : 0][2 * (2 * jp + jj) + a];
+            }
       } else {
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj)
@@ -1032,11 +1058,13 @@ void gemm_nt_kernel(const GemmParams p) {
         f32x4 va[4], vb[4];
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
+          if (it * 8 >= slab_rows(i)) continue;
           va[it] = *reinterpret_cast<const f32x4*>(slab + (it * 8 + r8) * SLAB_PITCH + c8 * 4);
           vb[it] = *reinterpret_cast<const f32x4*>(slab + (it * 8 + r8) * SLAB_PITCH + c8 * 4 + 16);
         }
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
+          if (it * 8 >= slab_rows(i)) continue;
           const int m = m0 + wm * TM + i * 32 + it * 8 + r8;
           const bool in_range = m < Mrt;
           const u32x4 h = __builtin_bit_cast(u32x4, add[kAddBufs == 2 ? (i & 1) : 0][jp][2 * it]);
@@ -1081,10 +1109,13 @@ void gemm_nt_kernel(const GemmParams p) {
       const int n = n0 + wn * TN + jp * 64 + rd_col;
       f32x4 v[8];
 #pragma unroll
-      for (int it = 0; it < 8; ++it)
+      for (int it = 0; it < 8; ++it) {
+        if (it * 4 >= slab_rows(i)) continue;
         v[it] = *reinterpret_cast<const f32x4*>(slab + (it * 4 + rd_row) * SLAB_PITCH + rd_col * 4);
+      }
 #pragma unroll
       for (int it = 0; it < 8; ++it) {
+        if (it * 4 >= slab_rows(i)) continue;
         int m = m0 + wm * TM + i * 32 + it * 4 + rd_row;
         const bool in_range = m < Mrt;
         if constexpr (EPI == EPI_RESID_EMIT) {

@@ -12,7 +12,7 @@ int gemm_num_cus();
 static const GemmVariant kVariants[kNumVariants] = {
     {"128x128_w2x2_glds64", 128, 128, 256}, {"128x128_w2x2_bufdma", 128, 128, 256}, {"256x256_w4x2_bufdma", 256, 256, 512},
     {"320x256_w2x4_bufdma", 320, 256, 512}, {"192x256_w2x4_bufdma", 192, 256, 512}, {"160x256_w2x4_bufdma", 160, 256, 512},
-    {"160x256_w2x4_ring3", 160, 256, 512},
+    {"160x256_w2x4_ring3", 160, 256, 512}, {"160x128_w2x2_duo", 160, 128, 256},
 };
 
 int gemm_num_cus() {
@@ -34,15 +34,18 @@ const GemmVariant& gemm_variant(int v) { return kVariants[v]; }
 // nothing here is read from the environment.
 static int g_override = -1;    // -1 = the cost model below chooses
 static int g_remap[kNumVariants];   // A/B runs: the cost model's choice a runs as g_remap[a] - 1 (0 = itself)
-// variant >= 1000: remap the cost model's choice a = (variant - 1000) / 100 to tile b = variant % 100; -1 clears everything
+static int g_duo = 0;               // A/B runs: GemmParams.duo of every launch (issue priority per LDS slot, variant 7)
+// variant >= 2000: duo mode = variant - 2000; 1000 .. 1999: remap the cost model's choice a = (variant - 1000) / 100 to tile
+// b = variant % 100; -1 clears everything
 void gemm_set_default_override(int variant) {
+  if (variant >= 2000) { g_duo = variant - 2000; return; }
   if (variant >= 1000) {
     const int a = (variant - 1000) / 100, b = variant % 100;
     if (a < kNumVariants && b < kNumVariants) g_remap[a] = b + 1;
     return;
   }
   g_override = variant;
-  if (variant == -1) for (int& r : g_remap) r = 0;
+  if (variant == -1) { for (int& r : g_remap) r = 0; g_duo = 0; }
 }
 bool gemm_variant_is_built(int dtype, int variant) {
   return dtype == 1 ? gemm_built_bf16(variant) : dtype == 2 ? gemm_built_f16(variant) : gemm_built_f32(variant);
@@ -111,6 +114,7 @@ int gemm_launch(int dtype, int epi, int variant, const GemmParams& p, hipStream_
   GemmLaunchFn fn = dtype == 1 ? gemm_get_bf16(variant, epi) : dtype == 2 ? gemm_get_f16(variant, epi) : gemm_get_f32(variant, epi);
   if (!fn) return (int)hipErrorInvalidValue;
   GemmParams pr = p;
+  pr.duo = g_duo;
   if (variant >= 0) {
     // column-group raster: minimise A*xn + W*(8/xn) fabric bytes subject to an XCD's W share fitting its L2
     const double esz = dtype == 0 ? 4.0 : 2.0;

@@ -46,7 +46,9 @@ int launch_naive(const GemmParams& p, hipStream_t stream) {
 //   5  160x256, 2x4 waves with 3 + 2 row blocks per wave row: 240 / 248 tiles on the bs=256 residual GEMMs (256 CUs)
 //   6  160x256 on a ring of three LDS stages (two K tiles of lookahead, barrier in front of the last K step's MFMAs);
 //      16-bit engines: 16x16x32 MFMAs, hand-placed K steps
-constexpr int kNumVariants = 7;
+//   7  160x128, 2x2 waves, 72 KB of LDS: TWO workgroups per CU, each with its own barriers -- one workgroup's K loop runs under
+//      the other's epilogue.  16-bit engines: 16x16x32 streamed form with wave rows of five 16-row tiles (80 x 64 wave tile)
+constexpr int kNumVariants = 8;
 
 template <typename T>
 constexpr bool gemm_variant_built(int v) { return v == -2 || (v >= 0 && v < kNumVariants); }
@@ -70,6 +72,7 @@ struct GemmTable {
         case 4: return launch_tiled<T, 192, 256, 2, 4, EPI, kH ? 6 : 1, 1>;
         case 5: return launch_tiled<T, 160, 256, 2, 4, EPI, kH ? 6 : 1, 1>;
         case 6: return launch_tiled<T, 160, 256, 2, 4, EPI, kH ? 7 : 1, 1, 3>;
+        case 7: return launch_tiled<T, 160, 128, 2, 2, EPI, kH ? 9 : 1, 1>;
         case -2: if constexpr (!kLn) return launch_naive<T, EPI>; else return nullptr;
         default: return nullptr;
       }

@@ -25,10 +25,11 @@ def _ref(a, w, bias, epi, alpha, c0):
 
 
 # Tile variants (csrc/gemm_inst.h): 0 / 1 = 128x128 (64-bit addresses / buffer LDS-DMA), 2 = 256x256, 3 = 320x256,
-# 4 = 192x256, 5 = 160x256 (uneven wave rows: 3 + 2 row blocks), 6 = 160x256 on a ring of three LDS stages;
+# 4 = 192x256, 5 = 160x256 (uneven wave rows: 3 + 2 row blocks), 6 = 160x256 on a ring of three LDS stages,
+# 7 = 160x128 on 2x2 waves (two workgroups per CU; 16-bit: wave rows of five 16-row MFMA tiles, half slabs in the epilogues);
 # -2 = the naive checker kernel.
 HALF = {"bf16": torch.bfloat16, "f16": torch.float16}
-NVAR = 7
+NVAR = 8
 
 
 def _built(dtype):
@@ -85,6 +86,26 @@ def test_gemm_matches_naive_checker_bitwise_fp32():
     yn = gemm_nt(a, w, b, epilogue=0, variant=-2)
     assert torch.equal(y0, y1)                      # same tile shape: 64-bit global LDS-DMA vs buffer LDS-DMA + fragment pipeline
     assert (y1 - yn).abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize("hdt", list(HALF.values()), ids=list(HALF))
+@pytest.mark.parametrize("epi", [0, 1, 2, 3])
+def test_every_tile_sums_k_in_the_same_order(epi, hdt):
+    """A row's embedding must not depend on the batch it arrives in (PLIP.coalesce, the embedding caches): small problems run
+    on the 128x128 tile (v_mfma 32x32x16), large ones on the 16x16x32 tiles (2, 3, 6, 7) -- so every tile has to produce the
+    SAME bits from the same operands, i.e. the two MFMA shapes must sum K in the same order."""
+    from plip_amd.engine import gemm_nt
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(77 + epi)
+    for (M, N, K) in [(1300, 768, 768), (2100, 512, 2048), (1300, 1536, 512)]:
+        a = torch.randn(M, K, generator=g).to(dev).to(hdt)
+        w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev).to(hdt)
+        bias = torch.randn(N, generator=g).to(dev)
+        c0 = torch.randn(M, N, generator=g).to(dev)
+        run = lambda v: gemm_nt(a, w, bias, epilogue=epi, variant=v, alpha=0.37, out=c0.clone() if epi == 2 else None)
+        y0 = run(0)
+        for v in (1, 2, 3, 4, 5, 6, 7):
+            assert torch.equal(run(v), y0), f"tile {v} differs from the 128x128 tile: epi {epi} {M}x{N}x{K} {hdt}"
 
 
 def test_gemm_rejects_bad_shapes():

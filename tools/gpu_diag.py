@@ -419,6 +419,10 @@ def sec_gemmtrace():
     """In-kernel timeline of one GEMM launch: where a workgroup's lifetime goes.
     usage: gpu_diag.py gemmtrace <variant> <M> <N> <K> <epi>"""
     v, M, N, K, epi = (int(x) for x in sys.argv[2:7]) if len(sys.argv) > 6 else (5, 12800, 3072, 768, 1)
+    duo = int(sys.argv[7]) if len(sys.argv) > 7 else 0        # variant 7: issue priority per LDS slot (GemmParams.duo)
+    if duo:
+        from plip_amd import _lib
+        _lib.load().plipmi_set_gemm_variant(2000 + duo)
     g = torch.Generator().manual_seed(0)
     dtype = torch.bfloat16
     a = torch.randn(M, K, generator=g).to(dev).to(dtype)
@@ -453,7 +457,8 @@ def sec_gemmtrace():
     qc = lambda x: (f"min {x.min():8.0f}  p50 {np.median(x):8.0f}  p90 {np.percentile(x, 90):8.0f}  max {x.max():8.0f} cycles"
                     f"  = p50 {np.median(x) / np.median(clk) / 1e3:6.2f} us at that clock")
     qu = lambda x: f"min {x.min():7.2f}  p50 {np.median(x):7.2f}  p90 {np.percentile(x, 90):7.2f}  max {x.max():7.2f} us"
-    kt = max(1, int(t[0, 6]) - 1)
+    kt = max(1, int(t[0, 6] & 0xFFFFFFFF) - 1)
+    lds_alloc = (t[:, 6] >> 32) & 0xFFFFFFFF
     print("  start offset :", qu(start_us))
     print("  prologue     :", qc(pro))
     print("  main loop    :", qc(loop), f"  ({np.median(loop) / kt:.0f} cycles per k-tile, {kt} tiles)")
@@ -461,6 +466,19 @@ def sec_gemmtrace():
     print("  lifetime     :", qc(life), "  wall:", qu(real_life_us))
     print("  end          :", qu(end_us))
     print("  workgroups per XCC:", np.bincount(xcc, minlength=8).tolist())
+    # two workgroups per CU (variant 7): which LDS allocation a workgroup got (HW_REG LDS_ALLOC, LDS_BASE = bits 7:0), and when
+    # the workgroups of each slot reached their epilogue / ended -- staggered slots mean one slot's stores run under the other's K loop
+    bases = sorted(set((lds_alloc & 0xFF).tolist()))
+    print(f"  LDS_ALLOC register values: {sorted(set(hex(int(x)) for x in lds_alloc.tolist()))[:6]}  duo mode {duo}")
+    if len(bases) > 1:
+        loop_end_us = start_us + (t[:, 2] - t[:, 0]) / np.maximum(clk, 1e-9) / 1e3
+        for b in bases:
+            sel = (lds_alloc & 0xFF) == b
+            print(f"    LDS_BASE {b:3d}: {int(sel.sum()):4d} workgroups  start p50 {np.median(start_us[sel]):6.2f}  K loop done p50 {np.median(loop_end_us[sel]):6.2f}"
+                  f"  end p50 {np.median(end_us[sel]):6.2f} us   loop {np.median(loop[sel]) / kt:6.0f} cyc/tile  epilogue p50 {np.median(epi_t[sel]) / np.median(clk) / 1e3:5.2f} us")
+    if duo:
+        from plip_amd import _lib
+        _lib.load().plipmi_set_gemm_variant(2000)
 
 
 def _step_inputs(B=256, arch="ViT-B/32"):
@@ -559,6 +577,9 @@ def sec_stepab():
             lib.plipmi_set_gemm_variant(-1)
             if arm != "base":
                 for pair in arm.split(","):
+                    if pair.startswith("d"):                  # dN: GemmParams.duo = N (issue priority per LDS slot, variant 7)
+                        lib.plipmi_set_gemm_variant(2000 + int(pair[1:]))
+                        continue
                     a, b = (int(x) for x in pair.split(">"))
                     lib.plipmi_set_gemm_variant(1000 + 100 * a + b)
             for ov in (False, True):
