@@ -15,8 +15,9 @@ VISION, TEXT = 0, 1
 
 
 class Config(C.Structure):
+    # first member = sizeof(Config) as this binding knows it (plipmi_create copies that many bytes: the struct may grow)
     _fields_ = [(n, C.c_int32) for n in (
-        "image_size", "patch_size", "v_width", "v_layers", "v_heads", "v_mlp", "vocab_size",
+        "struct_size", "image_size", "patch_size", "v_width", "v_layers", "v_heads", "v_mlp", "vocab_size",
         "context_length", "t_width", "t_layers", "t_heads", "t_mlp", "projection_dim")] + [
         ("layer_norm_eps", C.c_float), ("compute_dtype", C.c_int32), ("max_batch", C.c_int32), ("flags", C.c_int32),
         ("graph_batch", C.c_int32), ("text_f16_layers", C.c_int32)]
@@ -45,8 +46,21 @@ class KernelStat(C.Structure):
                 ("flops", C.c_double), ("bytes", C.c_double)]
 
 
-# every symbol include/plipmi.h declares: (restype, argtypes)
 _vp, _i, _f = C.c_void_p, C.c_int, C.c_float
+# kernel-level test entries and A/B hooks (include/plipmi_test.h): tests/, tools/ and bench.py's side fields only
+TEST_SYMBOLS = {
+    "plipmi_debug_hidden": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp]),
+    "plipmi_gemm_nt": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _f, _vp, _vp]),
+    "plipmi_gemm_variant_name": (C.c_char_p, [_i]),
+    "plipmi_set_gemm_variant": (None, [_i]),
+    "plipmi_gemm_variant_built": (_i, [_i, _i]),
+    "plipmi_recode_planes": (_i, [_vp, _vp, C.c_size_t, _i, _i, _vp]),
+    "plipmi_gemm_nt_ln": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp]),
+    "plipmi_gemm_nt_ld": (_i, [_i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _f, _vp, _vp]),
+    "plipmi_gemm_nt_traced": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
+    "plipmi_attention": (_i, [_i, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+}
+# every symbol include/plipmi.h declares (the product interface): (restype, argtypes)
 SYMBOLS = {
     "plipmi_create": (_i, [C.POINTER(Config), C.POINTER(Weights), _vp, C.POINTER(_vp)]),
     "plipmi_destroy": (None, [_vp]),
@@ -64,17 +78,7 @@ SYMBOLS = {
     "plipmi_topk": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "plipmi_resize_crop_u8": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "plipmi_similarity_topk": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp]),
-    "plipmi_debug_hidden": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp]),
-    "plipmi_gemm_nt": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _f, _vp, _vp]),
-    "plipmi_gemm_variant_name": (C.c_char_p, [_i]),
-    "plipmi_set_gemm_variant": (None, [_i]),
-    "plipmi_gemm_variant_built": (_i, [_i, _i]),
-    "plipmi_recode_planes": (_i, [_vp, _vp, C.c_size_t, _i, _i, _vp]),
     "plipmi_set_text_packing": (_i, [_vp, _i]),
-    "plipmi_gemm_nt_ln": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp]),
-    "plipmi_gemm_nt_ld": (_i, [_i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _f, _vp, _vp]),
-    "plipmi_gemm_nt_traced": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
-    "plipmi_attention": (_i, [_i, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "plipmi_profile_enable": (_i, [_vp, _i]),
     "plipmi_profile_read": (_i, [_vp, C.POINTER(KernelStat), _i, C.POINTER(_i)]),
 }
@@ -101,7 +105,7 @@ def load():
         lib = C.CDLL(LIB_PATH)
     except OSError as e:
         raise RuntimeError(f"cannot load {LIB_PATH}: {e}") from e
-    for name, (res, args) in SYMBOLS.items():
+    for name, (res, args) in {**SYMBOLS, **TEST_SYMBOLS}.items():
         fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
         fn.restype = res
         fn.argtypes = args

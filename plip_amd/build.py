@@ -45,7 +45,8 @@ def source_digest() -> str:
     measurement was taken on.  bench.py stamps its line with it and refuses profiles/pmc_traffic.json when that file
     was collected on different sources."""
     paths = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hip"))]
-    paths.append(os.path.join(os.path.dirname(os.path.dirname(CSRC)), "include", "plipmi.h"))
+    for hdr in ("plipmi.h", "plipmi_test.h"):
+        paths.append(os.path.join(os.path.dirname(os.path.dirname(CSRC)), "include", hdr))
     h = hashlib.sha256()
     for p in sorted(paths):
         with open(p, "rb") as f:
@@ -66,7 +67,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
     hipcc = _hipcc()
     os.makedirs(BUILD, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
-    headers.append(os.path.join(os.path.dirname(os.path.dirname(CSRC)), "include", "plipmi.h"))
+    for hdr in ("plipmi.h", "plipmi_test.h"):
+        headers.append(os.path.join(os.path.dirname(os.path.dirname(CSRC)), "include", hdr))
     hdr_digest = _digest(headers)
     jobs = []
     objs = []

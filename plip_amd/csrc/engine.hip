@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "../../include/plipmi.h"
+#include "../../include/plipmi_test.h"
 #include "gemm.h"
 #include "kernels.h"
 
@@ -574,7 +575,17 @@ const char* plipmi_device_name(plipmi_handle h) { return h ? h->devname : ""; }
 int plipmi_create(const plipmi_config* cfg, const plipmi_weights* w, void* stream, plipmi_handle* out) {
   if (!cfg || !w || !out) return fail(PLIPMI_ERR_INVALID, "null argument");
   *out = nullptr;
-  const plipmi_config& g = *cfg;
+  // The caller's struct may be OLDER (shorter) than this library's: read what it has, later members are 0 = their defaults
+  // (a member appended at the tail used to be read as garbage from a caller compiled against the previous header).
+  const size_t kMinSize = offsetof(plipmi_config, max_batch) + sizeof(int32_t);   // the members every version has had
+  if (cfg->struct_size < (int)kMinSize || cfg->struct_size > (int)sizeof(plipmi_config))
+    return fail(PLIPMI_ERR_INVALID, "plipmi_config.struct_size = %d: expected sizeof(plipmi_config) of the caller's header, %zu .. %zu "
+                "(this library: version %d)", cfg->struct_size, kMinSize, sizeof(plipmi_config), PLIPMI_VERSION);
+  plipmi_config g_copy;
+  memset(&g_copy, 0, sizeof(g_copy));
+  memcpy(&g_copy, cfg, (size_t)cfg->struct_size);
+  g_copy.struct_size = (int32_t)sizeof(plipmi_config);
+  const plipmi_config& g = g_copy;
   if (g.compute_dtype != PLIPMI_F32 && g.compute_dtype != PLIPMI_BF16 && g.compute_dtype != PLIPMI_F16)
     return fail(PLIPMI_ERR_INVALID, "compute_dtype must be PLIPMI_F32, PLIPMI_BF16 or PLIPMI_F16");
   if (g.flags & ~(PLIPMI_FLAG_SEPARATE_LAYERNORM | PLIPMI_FLAG_DENSE_LAST_BLOCK | PLIPMI_FLAG_PACK_CAPTIONS | PLIPMI_FLAG_VALU_ATTENTION |

@@ -41,7 +41,8 @@ class Engine:
     def __init__(self, cfg: PlipConfig, state_dict: Mapping[str, object], device="cuda:0", dtype="bf16",
                  max_batch: int = 256, *, ln_fold: bool = True, pooled_last_block: bool = True,
                  pack_captions: bool = False, mfma_attention: bool = True, graph_batch: Optional[int] = None,
-                 text_f16: bool = False, text_f16_layers: Optional[int] = None, latency_batch: int = 0):
+                 text_f16: bool = False, text_f16_layers: Optional[int] = None, latency_batch: int = 0,
+                 _config_struct_size: Optional[int] = None):
         """``ln_fold`` / ``pooled_last_block`` / ``mfma_attention`` = False select the A/B forms of the 16-bit engines
         (separate LayerNorm kernels, the last block on every token, the exact VALU attention kernel);
         ``text_f16`` (bf16 engine only): the text tower runs on IEEE-half operands, the image tower stays bf16;
@@ -50,7 +51,9 @@ class Engine:
         ``graph_batch``: None = default small-batch hipGraph replay (<= 32 samples), 0 = never, n = up to n samples.
         ``latency_batch``: batches of at most that many samples run on the split-K small-M GEMMs (plipmi_set_latency_batch;
         faster up to batch 8, embeddings then differ from the big-batch path's by up to 6e-4 -- off by default).
-        All of it is per-handle configuration (include/plipmi.h plipmi_config.flags): no environment variables."""
+        All of it is per-handle configuration (include/plipmi.h plipmi_config.flags): no environment variables.
+        (``_config_struct_size``: ABI tests only -- announce a plipmi_config of that many bytes, as a caller compiled against
+        an older, shorter header would.)"""
         cfg.validate()
         if not torch.cuda.is_available():
             raise RuntimeError("plip_amd needs a ROCm GPU (MI355X / gfx950): torch.cuda.is_available() is False "
@@ -84,10 +87,12 @@ class Engine:
                     continue
                 t = v if torch.is_tensor(v) else torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32))
                 dev[k] = t.detach().to(device=self.device, dtype=torch.float32).contiguous()
-            c = _lib.Config(cfg.image_size, cfg.patch_size, cfg.v_width, cfg.v_layers, cfg.v_heads, cfg.v_mlp,
+            c = _lib.Config(C.sizeof(_lib.Config), cfg.image_size, cfg.patch_size, cfg.v_width, cfg.v_layers, cfg.v_heads, cfg.v_mlp,
                             cfg.vocab_size, cfg.context_length, cfg.t_width, cfg.t_layers, cfg.t_heads, cfg.t_mlp,
                             cfg.projection_dim, cfg.layer_norm_eps, self.dtype_code, self.max_batch, self.flags, gb,
                             self.text_f16_layers)
+            if _config_struct_size is not None:
+                c.struct_size = int(_config_struct_size)
             w = _lib.Weights()
 
             def layers(prefix, n):

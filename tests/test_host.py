@@ -18,12 +18,20 @@ def test_library_exports_every_declared_symbol():
     from plip_amd.build import build
     build(verbose=False)
     lib = _lib.load()
-    header = open(os.path.join(ROOT, "include", "plipmi.h")).read()
-    declared = set(re.findall(r"\b(plipmi_[a-z0-9_]+)\s*\(", header))
-    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
-    for name in declared:
-        assert hasattr(lib, name), name
-    assert lib.plipmi_version() == 310
+    # the product header (the drop-in boundary) and the test header (kernel-level entries, A/B hooks): each lists exactly
+    # what the binding binds from it, and the library exports all of it
+    for hdr, table in (("plipmi.h", _lib.SYMBOLS), ("plipmi_test.h", _lib.TEST_SYMBOLS)):
+        header = open(os.path.join(ROOT, "include", hdr)).read()
+        declared = set(re.findall(r"\b(plipmi_[a-z0-9_]+)\s*\(", header))
+        assert declared == set(table), (hdr, declared ^ set(table))
+        for name in declared:
+            assert hasattr(lib, name), name
+    assert not set(_lib.SYMBOLS) & set(_lib.TEST_SYMBOLS)
+    # nothing test-only in the product header: no kernel-level GEMM / attention entry, no process-wide switch
+    product = open(os.path.join(ROOT, "include", "plipmi.h")).read()
+    for hook in ("plipmi_gemm_nt", "plipmi_attention", "plipmi_set_gemm_variant", "plipmi_recode_planes", "plipmi_debug_hidden"):
+        assert not re.search(r"\b%s\s*\(" % hook, product), hook
+    assert lib.plipmi_version() == 400
     names = []
     i = 0
     while lib.plipmi_gemm_variant_name(i):
@@ -50,7 +58,8 @@ def test_struct_layouts_match_header():
     import ctypes as C
 
     from plip_amd import _lib
-    assert C.sizeof(_lib.Config) == 19 * 4
+    assert C.sizeof(_lib.Config) == 20 * 4
+    assert _lib.Config._fields_[0][0] == "struct_size"      # plipmi_create reads that many bytes of the caller's struct
     assert C.sizeof(_lib.LayerWeights) == 16 * 8
     assert C.sizeof(_lib.Weights) == 15 * 8
     assert C.sizeof(_lib.KernelStat) == 96 + 8 + 3 * 8
