@@ -261,6 +261,15 @@ def main(argv=None, model_factory=None):
     B = args.batch
     sd = W.synthetic_state_dict(cfg, seed=0)                   # same weights on every rank
     model = (model_factory or PlipModel)(cfg, sd, device=dev, dtype=args.dtype, max_batch=B)
+    # which ranks are REALLY in the job (the driver's SCALE record can check N ranks on N devices were seen): the group's own
+    # world size and every rank's device, gathered over the group -- not an echo of --gpus
+    my_device = f"rank {rank}: {getattr(model.engine, 'device_name', 'stub')} (cuda:{local_rank})"
+    if world > 1:
+        rank_devices = [None] * world
+        dist.all_gather_object(rank_devices, my_device)
+        rccl_ranks = dist.get_world_size()
+    else:
+        rank_devices, rccl_ranks = [my_device], 1
     px = torch.from_numpy(W.synthetic_pixels(cfg, B, seed=1000 + rank)).to(dev)
     ids_np, mask_np = W.synthetic_ids(cfg, B, seed=2000 + rank)
     ids, mask = torch.from_numpy(ids_np).to(dev), torch.from_numpy(mask_np).to(dev)
@@ -395,6 +404,9 @@ def main(argv=None, model_factory=None):
         "value": round(value, 1), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": args.dtype,
+        # structured beside `dtype`: how many LEADING text blocks of the bf16 engine run on f16 MFMA operands
+        "text_f16_layers": int(getattr(model.engine, "text_f16_layers", 0)),
+        "rccl_ranks": rccl_ranks, "rank_devices": rank_devices,
         "data": "synthetic" if not rehearsal else "synthetic; gloo REHEARSAL with a stub engine -- control flow only, not a measurement",
         "config": {"workload": f"full dual encoder (image tower + text tower + L2 normalise + logits_per_image), "
                                f"{args.arch}, bs={B} pairs per GPU, {cfg.image_size}px, {cfg.context_length} tokens, "
@@ -520,7 +532,8 @@ def main(argv=None, model_factory=None):
         # one GPU's share of BASELINE.json configs[4] (ViT-L/14@336, bs=512 over 8 GPUs = 64 pairs per GPU), same dtype
         try:
             cl = get_config("ViT-L/14@336px")
-            ml = PlipModel(cl, W.synthetic_state_dict(cl, seed=3), device=dev, dtype=args.dtype, max_batch=64)
+            sdl = W.synthetic_state_dict(cl, seed=3)
+            ml = PlipModel(cl, sdl, device=dev, dtype=args.dtype, max_batch=64)
             g = torch.Generator(device=dev).manual_seed(6)
             pxl = torch.randn((64, 3, cl.image_size, cl.image_size), generator=g, device=dev)
             il, mk = W.synthetic_ids(cl, 64, seed=42)
@@ -532,6 +545,9 @@ def main(argv=None, model_factory=None):
                 "pairs_per_s": round(64 / dtl, 1), "ms_per_step": round(dtl * 1e3, 3),
                 "dense_equivalent_tflops": round(64 * cl.pair_flops() / dtl / 1e12, 1),
                 "dense_equivalent_frac_of_mfma_peak": round(64 * cl.pair_flops() / dtl / 1e12 / PEAK_TFLOPS[args.dtype], 4)}
+            if not args.no_cpu_baseline:
+                # this very batch's first pairs against the CPU oracle (batch-invariant engine: the same bits as inside the 64)
+                res["vitl14_336_b64"]["logits_max_abs_err"] = logits_error_vs_hf_golden(ml, cl, sdl, pxl, il, mk, 64, "ViT-L/14@336px")
             ml.engine.close()
             del ml, pxl
         except Exception as e:  # pragma: no cover
@@ -566,6 +582,32 @@ def main(argv=None, model_factory=None):
             del m32
         except Exception as e:  # pragma: no cover
             res["config1_fp32_image_tower"] = {"error": repr(e)}
+    if extras:
+        # The step's ONE collective on this box's single GPU: a one-rank RCCL group (communicator on this device, the stacked
+        # [1, 2, B, P] all_gather_into_tensor enqueued behind the two tower streams every step).  Not a scaling number -- the cost
+        # of issuing the collective, which is what an N-rank step adds before any wire time.
+        try:
+            import socket
+            with socket.socket() as so:
+                so.bind(("127.0.0.1", 0))
+                port = so.getsockname()[1]
+            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+            try:
+                run = lambda ac: sharded_pair_logits(model, px, ids, mask, overlap=bool(args.overlap), equal_shards=True,
+                                                     always_collective=ac)
+                o1 = run(True)
+                same = bool(torch.equal(o1[0], run(False)[0]))
+                t_c, _ = timed_steps(lambda: run(True), args.steps, dev, 3)
+                t_p, _ = timed_steps(lambda: run(False), args.steps, dev, 3)
+                res["rccl_one_rank"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                                        "ms_per_step_with_all_gather": round(t_c * 1e3, 3), "ms_per_step_without": round(t_p * 1e3, 3),
+                                        "all_gather_cost_us": round((t_c - t_p) * 1e6, 1), "logits_bit_identical": same,
+                                        "collective": f"all_gather_into_tensor of [1, 2, {B}, {cfg.projection_dim}] fp32 "
+                                                      f"({2 * B * cfg.projection_dim * 4 // 1024} KiB per rank)"}
+            finally:
+                dist.destroy_process_group()
+        except Exception as e:  # pragma: no cover
+            res["rccl_one_rank"] = {"error": repr(e)}
     res["cpu_baseline"] = cpu_baseline(cfg, sd, args.cpu_seconds) if (world == 1 and not args.no_cpu_baseline) else None
     print(json.dumps(res), flush=True)
     if world > 1:

@@ -64,7 +64,9 @@ int plipmi_gemm_nt_traced(int dtype, int epilogue, int variant, int M, int N, in
  *           C = lo (int16 remainder; bf16: bits(x) == (hi << 16) + lo, f16: x == hi + lo * 2^(E(hi) - 24)), an EXACT
  *           fp32 value either way (plip_amd/csrc/common.h split_f32): both read and written in place;
  *           st_out as in mode 2.  This is the form the engine runs (an fp32 stream at 8 bytes per element of epilogue
- *           traffic, whose hi plane is the next GEMM's A operand) */
+ *           traffic, whose hi plane is the next GEMM's A operand)
+ *   mode 4: mode 3 that READS the planes in dtype's split format and WRITES them in the other 16-bit type's (the last f16
+ *           block of a bf16 text tower with plipmi_config.text_f16_layers hands the stream over without a re-coding pass) */
 int plipmi_gemm_nt_ln(int dtype, int mode, int variant, int M, int N, int K, const void* A, const void* W, const float* bias,
                       const float* stats, int ns, float eps, void* C, void* xb_out, float* st_out, void* stream);
 

@@ -377,8 +377,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       const float m_new = fmaxf(m_run, cmax);
       const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
       const float m2 = m_use * kLog2e;
-      const float scale = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(fmaf(m_run, kLog2e, -m2));  // acc, l_run are 0 while m_run = -inf
       const bool moved = m_new != m_run;    // (NaN-free: -inf != -inf is false, a first finite maximum is a move)
+      // a lane whose maximum did not move rescales by EXACTLY 1 -- exp2 of the FMA's rounding residual is 1 +- 3e-6, and l_run
+      // (always rescaled) would otherwise drift against acc (rescaled only when some lane moved): ADVICE r4
+      const float scale = !moved ? 1.f : (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(fmaf(m_run, kLog2e, -m2));  // acc, l_run are 0 while m_run = -inf
       m_run = m_new;
       if (__ballot(moved) != 0ull) {        // wave-uniform: once the running maxima have settled the 32 rescaling multiplies go
 #pragma unroll

@@ -93,6 +93,7 @@ struct Tower {
 struct LnArgs {         // the LayerNorm side of a folded GEMM (gemm.h EPI_*_LN / EPI_RESID_EMIT)
   const float* stats = nullptr; int ns = 0; float inv_d = 0.f, eps = 0.f;   // consumer
   void* xb_out = nullptr; float* st_out = nullptr; void* lo_io = nullptr;     // producer (lo_io: EPI_RESID_SPLIT's lo plane)
+  int planes_other = 0;                                                         // producer: write the planes in the other 16-bit format
 };
 // One captured tower forward (hipGraph) per (tower, input kind, batch, normalise, pooling rule, mask?): the ~170 launches
 // of a small-batch encode are replayed with ONE host call instead of being issued one by one (launch-bound at the
@@ -311,7 +312,7 @@ int run_gemm(plipmi_engine* e, const Tower& t, int epi, const void* A, const voi
   p.M = M; p.N = N; p.K = K; p.lda = K; p.ldw = K; p.ldc = ldc; p.alpha = 1.f; p.np = np;
   if (ln) {
     p.ln_stats = ln->stats; p.ln_ns = ln->ns; p.ln_inv_d = ln->inv_d; p.ln_eps = ln->eps;
-    p.xb_out = ln->xb_out; p.st_out = ln->st_out; p.lo_io = ln->lo_io;
+    p.xb_out = ln->xb_out; p.st_out = ln->st_out; p.lo_io = ln->lo_io; p.planes_other = ln->planes_other;
   }
   bool skinny = role[0] == '~';     // '~role': pooled-row GEMM of the last block -> the small-M split-K kernel when it fits
   if (skinny) ++role;
@@ -374,7 +375,14 @@ int run_layers(plipmi_engine* e, Tower& t, int B, int n_layers, int causal, cons
       RUN(attention());
       RUN(run_gemm(e, t, EPI_RESID_SPLIT, t.att, w.wo, nullptr, w.bo, M, D, D, D, 0, s, "out_proj", &emit, md));
       RUN(run_gemm(e, t, EPI_QGELU_LN, t.h, w.w1, t.mlp, w.b1, M, F, D, F, 0, s, "fc1", &use, md));
-      RUN(run_gemm(e, t, EPI_RESID_SPLIT, t.mlp, w.w2, nullptr, w.b2, M, D, F, D, 0, s, "fc2", &emit, md));
+      // a block whose successor runs on the other 16-bit operand type (the last f16 block of a mixed text tower) writes its
+      // planes in the successor's format from fc2's epilogue -- no re-coding pass over the stream (the tiled kernels only:
+      // the small-M kernel of the latency path keeps the separate pass, enter_block)
+      const int next_dt = l + 1 < t.L ? t.layer_dtype(l + 1) : t.cur;
+      LnArgs emit2 = emit;
+      emit2.planes_other = (next_dt != t.cur && !(t.small && !md)) ? 1 : 0;
+      RUN(run_gemm(e, t, EPI_RESID_SPLIT, t.mlp, w.w2, nullptr, w.b2, M, D, F, D, 0, s, "fc2", &emit2, md));
+      if (emit2.planes_other) t.planes = next_dt;
     }
     if (!more_follow) {
       if (t.packed) return fail(PLIPMI_ERR_INVALID, "packed rows have no every-token form");   // a consumer of plain fp32 rows follows (the every-token head, plipmi_debug_hidden)
@@ -922,15 +930,15 @@ int plipmi_gemm_nt_traced(int dtype, int epilogue, int variant, int M, int N, in
 int plipmi_gemm_nt_ln(int dtype, int mode, int variant, int M, int N, int K, const void* A, const void* W, const float* bias,
                       const float* stats, int ns, float eps, void* C, void* xb_out, float* st_out, void* stream) {
   if (dtype != PLIPMI_BF16 && dtype != PLIPMI_F16) return fail(PLIPMI_ERR_INVALID, "LayerNorm-folded epilogues are 16-bit-engine forms");
-  if (mode < 0 || mode > 3 || M < 0 || N <= 0 || K <= 0 || !A || !W || !C || !bias) return fail(PLIPMI_ERR_INVALID, "bad argument");
+  if (mode < 0 || mode > 4 || M < 0 || N <= 0 || K <= 0 || !A || !W || !C || !bias) return fail(PLIPMI_ERR_INVALID, "bad argument");
   if (mode < 2 && (!stats || ns <= 0)) return fail(PLIPMI_ERR_INVALID, "mode 0/1 need the row statistics");
   if (mode >= 2 && (!xb_out || !st_out || N % kLnSlice)) return fail(PLIPMI_ERR_INVALID, "mode 2/3 need xb_out, st_out and N % 64 == 0");
-  if (mode == 3 && variant == -3) return fail(PLIPMI_ERR_INVALID, "the small-M kernel has no split-plane epilogue");
+  if (mode >= 3 && variant == -3) return fail(PLIPMI_ERR_INVALID, "the small-M kernel has no split-plane epilogue");
   GemmParams p;
   p.A = A; p.W = W; p.C = C; p.bias = bias; p.M = M; p.N = N; p.K = K; p.lda = K; p.ldw = K; p.ldc = N; p.alpha = 1.f; p.np = 1;
   p.ln_stats = stats; p.ln_ns = ns; p.ln_inv_d = ns > 0 ? 1.0f / (float)(ns * kLnSlice) : 0.f; p.ln_eps = eps;
   p.xb_out = xb_out; p.st_out = st_out;
-  if (mode == 3) { p.lo_io = C; p.C = nullptr; }
+  if (mode >= 3) { p.lo_io = C; p.C = nullptr; p.planes_other = mode == 4; }
   const int epi = mode == 0 ? EPI_BIAS_LN : mode == 1 ? EPI_QGELU_LN : mode == 2 ? EPI_RESID_EMIT : EPI_RESID_SPLIT;
   const int rc = variant == -3 ? gemm_launch_skinny(dtype, epi, p, reinterpret_cast<hipStream_t>(stream), nullptr)
                                : gemm_launch(dtype, epi, variant, p, reinterpret_cast<hipStream_t>(stream), nullptr);

@@ -84,6 +84,10 @@ struct GemmParams {
   void* xb_out = nullptr;
   float* st_out = nullptr;
   void* lo_io = nullptr;
+  // EPI_RESID_SPLIT: write the updated planes in the OTHER 16-bit type's split format (read them in T's): the last f16 block
+  // of a mixed text tower (plipmi_config.text_f16_layers) hands the stream to the bf16 blocks without a re-coding pass.
+  // Exact: both formats hold the fp32 value bit for bit (|x| < 65504), common.h split_f32.
+  int planes_other = 0;
   // Row count known only on the device (packed captions, kernels.h launch_text_pack): when set, the kernel processes
   // min(*m_dev, M) rows -- M then only sizes the grid; workgroups whose tile starts past the live rows exit at once
   const int* m_dev = nullptr;
@@ -1087,6 +1091,17 @@ void gemm_nt_kernel(const GemmParams p) {
           const float m2 = row8_sum(q2);
           if (in_range) {
             u32x4 ho, lo4;
+            using TO = std::conditional_t<std::is_same_v<T, bf16_t>, f16_t, bf16_t>;   // the other 16-bit type
+            if (p.planes_other) {   // wave-uniform
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                unsigned ha, la, hb, lb;
+                split_f32<TO>(o[2 * e], ha, la);
+                split_f32<TO>(o[2 * e + 1], hb, lb);
+                ho[e] = ha | (hb << 16);
+                lo4[e] = la | (lb << 16);
+              }
+            } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               unsigned ha, la, hb, lb;
@@ -1094,6 +1109,7 @@ void gemm_nt_kernel(const GemmParams p) {
               split_f32<T>(o[2 * e + 1], hb, lb);
               ho[e] = ha | (hb << 16);
               lo4[e] = la | (lb << 16);
+            }
             }
             const size_t off = (size_t)m * p.ldc + nn;
             store16(reinterpret_cast<unsigned short*>(p.xb_out) + off, ho);

@@ -23,15 +23,20 @@ def shard_bounds(n: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def all_gather_rows(local: torch.Tensor, group=None, equal_shards: bool = False) -> torch.Tensor:
+def all_gather_rows(local: torch.Tensor, group=None, equal_shards: bool = False, always_collective: bool = False) -> torch.Tensor:
     """Concatenate every rank's ``[n_r, ...]`` rows in rank order -> ``[sum n_r, ...]``.
 
     Equal shards go through one ``all_gather_into_tensor`` (a single RCCL collective on
     contiguous buffers); ragged shards are padded to the longest one first.  ``equal_shards=True``
     (the caller guarantees n_r is the same on every rank, e.g. a fixed per-GPU batch) skips the
     size exchange and its host synchronisation: the step then contains exactly ONE collective per matrix.
+    ``always_collective=True`` issues the collective in a ONE-rank group too (where the result is the input): the way to run
+    communicator creation, the collective's stream ordering against the tower streams and the gathered views on a single
+    GPU (tests/test_gpu_dist.py, bench.py's ``rccl_one_rank`` field) -- a one-GPU box cannot run two ranks.
     """
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_available() or not dist.is_initialized():
+        return local
+    if dist.get_world_size(group) == 1 and not always_collective:
         return local
     world = dist.get_world_size(group)
     if equal_shards:
@@ -58,7 +63,7 @@ def all_gather_rows(local: torch.Tensor, group=None, equal_shards: bool = False)
 
 def sharded_pair_logits(model, pixels_local: torch.Tensor, ids_local: torch.Tensor,
                         attention_mask_local: Optional[torch.Tensor] = None, group=None, overlap: bool = True,
-                        equal_shards: bool = False):
+                        equal_shards: bool = False, always_collective: bool = False):
     """One data-parallel step of CLIPModel.forward: this rank embeds ITS images and captions,
     the normalised embeddings are all-gathered, and the rank computes its row block of
     ``logits_per_image`` ([n_local, N_text]) against every caption of the global batch.
@@ -71,36 +76,38 @@ def sharded_pair_logits(model, pixels_local: torch.Tensor, ids_local: torch.Tens
     else:
         img = eng.encode_image(pixels_local, normalize=True)
         txt = eng.encode_text(ids_local, attention_mask_local, normalize=True)
-    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
-    if equal_shards and world > 1 and img.shape == txt.shape:
+    grouped = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size(group) if grouped else 1
+    if equal_shards and (world > 1 or (always_collective and grouped)) and img.shape == txt.shape:
         # fixed per-rank batch: both embedding matrices travel in ONE all-gather ([2, n, P] per rank)
-        both = all_gather_rows(torch.stack((img, txt)).unsqueeze(0), group, True)     # [W, 2, n, P]
+        both = all_gather_rows(torch.stack((img, txt)).unsqueeze(0), group, True, always_collective)     # [W, 2, n, P]
         img_all = both[:, 0].reshape(-1, img.shape[1])
         txt_all = both[:, 1].reshape(-1, txt.shape[1])
     else:
-        txt_all = all_gather_rows(txt, group, equal_shards)
-        img_all = all_gather_rows(img, group, equal_shards)
+        txt_all = all_gather_rows(txt, group, equal_shards, always_collective)
+        img_all = all_gather_rows(img, group, equal_shards, always_collective)
     lpi, _, _ = eng.logits(img, txt_all, scale=eng.logit_scale_exp, want_text=False)
     return lpi, img_all, txt_all
 
 
-def sharded_zero_shot(model, pixels_local: torch.Tensor, class_text_embeds: torch.Tensor, group=None):
+def sharded_zero_shot(model, pixels_local: torch.Tensor, class_text_embeds: torch.Tensor, group=None,
+                      always_collective: bool = False):
     """Config-4 style zero-shot: class prompts ([C,P], tiny) are replicated, every rank
     classifies its image shard and only the int32 predictions are gathered."""
     eng = model.engine
     img = eng.encode_image(pixels_local, normalize=True)
     _, _, pred = eng.logits(img, class_text_embeds, scale=1.0, want_text=False, want_argmax=True)
-    return all_gather_rows(pred, group)
+    return all_gather_rows(pred, group, always_collective=always_collective)
 
 
 def sharded_retrieval_topk(model, text_embeds_local: torch.Tensor, image_embeds_local: torch.Tensor, k: int = 50,
-                           group=None):
+                           group=None, always_collective: bool = False):
     """Text-to-image retrieval over a corpus sharded by rank (reproducibility/evaluation/retrieval/retrieval.py:13-18
     at corpus scale): the image embeddings are all-gathered once, every rank ranks ITS captions against the whole
     corpus with the fused similarity + top-k head (no [N, N] matrix anywhere) and the [n_r, k] index blocks are
     gathered in rank order.  Returns int64 [N_text, k] global image indices."""
     eng = model.engine
-    img_all = all_gather_rows(image_embeds_local, group)
+    img_all = all_gather_rows(image_embeds_local, group, always_collective=always_collective)
     k = min(int(k), int(img_all.shape[0]))
     best = eng.similarity_topk(text_embeds_local, img_all, k)
-    return all_gather_rows(best, group)
+    return all_gather_rows(best, group, always_collective=always_collective)

@@ -439,10 +439,10 @@ def gemm_nt_ln(mode: int, a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, 
                                              stats.shape[1], float(eps), _ptr(out), None, None, stream), "plipmi_gemm_nt_ln")
             return out
         st = torch.empty((M, N // 64, 2), dtype=torch.float32, device=a.device)
-        if mode == 3:
+        if mode in (3, 4):           # 4: planes read in a's format, written in the other 16-bit type's (hi is then to be VIEWED as that type)
             hi, lo = out
             assert hi.dtype == hdt and lo.dtype == torch.int16 and hi.is_contiguous() and lo.is_contiguous()
-            _lib.check(lib.plipmi_gemm_nt_ln(code, 3, variant, M, N, K, _ptr(a), _ptr(w), _ptr(bias), None, 0, float(eps),
+            _lib.check(lib.plipmi_gemm_nt_ln(code, mode, variant, M, N, K, _ptr(a), _ptr(w), _ptr(bias), None, 0, float(eps),
                                              _ptr(lo), _ptr(hi), _ptr(st), stream), "plipmi_gemm_nt_ln")
             return hi, lo, st
         xb = torch.empty((M, N), dtype=hdt, device=a.device)

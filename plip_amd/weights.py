@@ -392,9 +392,14 @@ def load_checkpoint(path: str, arch: str | None = None, trust_pickle: bool = Fal
             sd = torch.load(path, map_location="cpu", weights_only=True)
         except (OSError, TypeError):
             raise                                     # missing / unreadable file, or a torch without weights_only: not a pickle question
-        except (pickle.UnpicklingError, RuntimeError, EOFError, AttributeError, ImportError, KeyError, zipfile.BadZipFile) as e:
-            # what weights_only=True raises on a code-carrying pickle -- and what old / odd checkpoints (legacy pickles naming
-            # modules that are gone, truncated archives) raise on their way there: all of them get the guidance below
+        except (EOFError, zipfile.BadZipFile) as e:
+            # a damaged file is not a trust question: do not steer the user towards arbitrary-code unpickling for it
+            raise RuntimeError(f"{path} is truncated or corrupt ({type(e).__name__}: {e}); re-download or re-save it") from e
+        except (pickle.UnpicklingError, RuntimeError, AttributeError, ImportError, KeyError) as e:
+            # what weights_only=True raises on a code-carrying pickle ("Unsupported global / class", UnpicklingError) -- and what
+            # legacy pickles naming modules that are gone raise on their way there: these get the trust guidance below
+            if isinstance(e, RuntimeError) and not any(k in str(e) for k in ("Unsupported", "weights_only", "pickle", "GLOBAL", "global")):
+                raise                                 # some other runtime failure of torch.load: not a pickle-trust question
             if not (trust_pickle or os.environ.get("PLIPMI_TRUST_PICKLE") == "1"):
                 raise RuntimeError(
                     f"{path} is not a plain tensor state dict ({type(e).__name__}: {str(e)[:200]}). Loading it needs full "

@@ -78,6 +78,26 @@ def test_plip_host_loops_coalesce_engine_calls_bit_identically(engines, dtype):
     assert got[True][4] == got[False][4]
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_coalesced_host_loops_cross_the_tile_boundary_on_vitb32(engines, dtype):
+    """The same invariant where it is NOT trivially one tile: on ViT-B/32 a caller batch of 8 images (400 rows) runs on the
+    128x128 tile (v_mfma 32x32x16), the coalesced 40 images / 30 captions (2000 / 2310 rows) on the 16x16x32 tiles the cost
+    model picks above 1024 rows -- the embeddings must still be the same bits."""
+    from plip_amd.plip import PLIP
+    model, cfg, sd, *_ = engines("vitb32_b4", dtype, 256)
+    plip = PLIP(model=model, tokenizer=fake_tokenizer(cfg))
+    rs = np.random.RandomState(21)
+    tiles = [rs.randint(0, 256, size=(cfg.image_size, cfg.image_size, 3), dtype=np.uint8) for _ in range(40)]
+    labels = [f"an h&e image of tissue class {i} " + "x " * (i % 9) for i in range(30)]
+    got = {}
+    for co in (True, False):
+        plip.coalesce = co
+        got[co] = (plip.encode_images(tiles, batch_size=8), plip.encode_text(labels, batch_size=8))
+    del plip.coalesce
+    for a, b in zip(got[True], got[False]):
+        assert a.shape == b.shape and np.array_equal(a, b)
+
+
 @pytest.mark.parametrize("h,w", [(300, 500), (512, 512), (64, 200), (96, 96), (71, 64), (1000, 700)])
 def test_gpu_resize_crop_is_pillow_exact(engines, h, w):
     """plipmi_resize_crop_u8 == Image.resize(BICUBIC) + centre crop, bit for bit, and PLIP.encode_images takes that
@@ -303,6 +323,31 @@ def test_error_behaviour(engines):
     with pytest.raises(ValueError):
         model.get_image_features()
     assert model.get_image_features(pixel_values=torch.zeros(0, 3, cfg.image_size, cfg.image_size)).shape == (0, cfg.projection_dim)
+
+
+def test_config_struct_size_lets_the_struct_grow(engines):
+    """plipmi_config starts with its own size: a caller compiled against an OLDER, shorter header -- one that
+    ends at max_batch -- gets every later member as 0 (the product defaults), not whatever lies behind its struct; sizes
+    that cannot be a plipmi_config are rejected."""
+    import ctypes as C
+    from plip_amd import _lib
+    from plip_amd._lib import PlipmiError
+    from plip_amd.model import PlipModel
+    model, cfg, sd, px, ids, mask = engines("tiny_b6", "bf16")
+    short = _lib.Config.max_batch.offset + 4
+    assert short < C.sizeof(_lib.Config)
+    # flags = 0, graph_batch = 0 (default replay), text_f16_layers = 0 (pure bf16) is what the short struct must mean --
+    # although the binding FILLS the tail with other values (text_f16_layers = 2), which the library must not read
+    old_caller = PlipModel(cfg, sd, dtype="bf16", max_batch=32, text_f16_layers=2, _config_struct_size=short)
+    same = PlipModel(cfg, sd, dtype="bf16", max_batch=32, text_f16_layers=0)
+    mixed = PlipModel(cfg, sd, dtype="bf16", max_batch=32, text_f16_layers=2)
+    t = [m.get_text_features(input_ids=torch.from_numpy(ids), attention_mask=torch.from_numpy(mask)) for m in (old_caller, same, mixed)]
+    assert torch.equal(t[0], t[1]) and not torch.equal(t[0], t[2])
+    for m in (old_caller, same, mixed):
+        m.engine.close()
+    for bad in (0, 8, short - 4, C.sizeof(_lib.Config) + 4):
+        with pytest.raises(PlipmiError, match="struct_size"):
+            PlipModel(cfg, sd, dtype="bf16", max_batch=32, _config_struct_size=bad)
 
 
 def test_native_library_is_what_runs():

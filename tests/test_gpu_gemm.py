@@ -265,6 +265,32 @@ def test_split_plane_residual_epilogue(variant, hdt):
 
 
 @pytest.mark.parametrize("hdt", list(HALF.values()), ids=list(HALF))
+@pytest.mark.parametrize("variant", [2, 6, 7, -1])
+def test_split_plane_epilogue_hands_the_stream_to_the_other_operand_type(variant, hdt):
+    """Mode 4 = mode 3 writing the planes in the OTHER 16-bit type's split format: what the last f16 block of a mixed text tower
+    (plipmi_config.text_f16_layers) does instead of a re-coding pass.  Must equal mode 3 followed by plipmi_recode_planes bit
+    for bit, planes and statistics, and the joined stream must be the same fp32 values."""
+    from plip_amd.engine import gemm_nt_ln, join_planes, recode_planes, split_planes
+    dev = torch.device("cuda:0")
+    other = torch.float16 if hdt == torch.bfloat16 else torch.bfloat16
+    g0 = torch.Generator().manual_seed(400 + variant)
+    for (M, N, K) in [(50, 512, 512), (1300, 512, 2048)]:
+        a = torch.randn(M, K, generator=g0).to(dev).to(hdt)
+        w = (torch.randn(N, K, generator=g0) / K ** 0.5).to(dev).to(hdt)
+        bias = torch.randn(N, generator=g0).to(dev)
+        x0 = (torch.randn(M, N, generator=g0) * 3.0 + 1.0).to(dev)
+        hi0, lo0 = split_planes(x0, hdt)
+        hi3, lo3, st3 = gemm_nt_ln(3, a, w, bias, variant=variant, out=(hi0.clone(), lo0.clone()))
+        x3 = join_planes(hi3, lo3).clone()
+        hi3r, lo3r = recode_planes(hi3, lo3, other)
+        hi4, lo4, st4 = gemm_nt_ln(4, a, w, bias, variant=variant, out=(hi0.clone(), lo0.clone()))
+        hi4 = hi4.view(other)
+        torch.cuda.synchronize()
+        assert torch.equal(hi4.view(torch.int16), hi3r.view(torch.int16)) and torch.equal(lo4, lo3r) and torch.equal(st4, st3)
+        assert torch.equal(join_planes(hi4, lo4).view(torch.int32), x3.view(torch.int32))
+
+
+@pytest.mark.parametrize("hdt", list(HALF.values()), ids=list(HALF))
 @pytest.mark.parametrize("epi", [0, 1, 2])
 def test_small_m_split_k_gemm(epi, hdt):
     """gemm_skinny.hip (variant -3): 32 x 64 tile per workgroup, K split over its four waves with a k permutation shared by

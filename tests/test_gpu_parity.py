@@ -21,7 +21,7 @@ pytestmark = pytest.mark.gpu
 # f16 engine (11 significand bits against 8): a quarter of the bar.
 TOL = {
     "f32": dict(feat=2e-4, cos=1e-5, emb=1e-5, hidden=5e-4),
-    "bf16": dict(feat=6e-2, cos=1e-3, emb=1.0e-3, hidden=1.5e-1),
+    "bf16": dict(feat=6e-2, cos=1e-3, emb=8.5e-4, hidden=1.5e-1),      # emb: 1.2x the measured 7.0e-4 (round 4: 1.0e-3)
     "f16": dict(feat=1.5e-2, cos=2.5e-4, emb=4e-4, hidden=4e-2),
 }
 TINY = {"bf16": dict(feat=6e-2, cos=3e-3, emb=4e-3, hidden=1.5e-1), "f16": dict(feat=1.5e-2, cos=7.5e-4, emb=1e-3, hidden=4e-2)}

@@ -308,6 +308,13 @@ def test_load_checkpoint_refuses_code_carrying_pickles(tmp_path, monkeypatch):
         W.load_checkpoint(str(whole))
     got2, _ = W.load_checkpoint(str(whole), trust_pickle=True)
     np.testing.assert_array_equal(got2["visual_projection.weight"], sd["visual_projection.weight"])
+    # a DAMAGED file is reported as damaged -- no nudge towards arbitrary-code unpickling
+    cut = tmp_path / "cut.pt"
+    cut.write_bytes(plain.read_bytes()[: plain.stat().st_size // 2])
+    with pytest.raises(RuntimeError) as ei:
+        W.load_checkpoint(str(cut))
+    assert "trust_pickle" not in str(ei.value) and ("truncated" in str(ei.value) or "corrupt" in str(ei.value)
+                                                    or "PytorchStreamReader" in str(ei.value)), str(ei.value)
 
 
 def test_split_plane_host_mirror_is_exact():
