@@ -224,6 +224,11 @@ def main(argv=None, model_factory=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # The contract is ONE JSON line on stdout.  Native libraries write there too (RCCL prints a version banner to fd 1 when a
+    # communicator comes up): everything this process emits goes to stderr at the file-descriptor level, except the line itself.
+    sys.stdout.flush()
+    real_stdout_fd = os.dup(1)
+    os.dup2(2, 1)
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit(f"--gpus {args.gpus} needs one process per GPU: launch with\n  python -m torch.distributed.run "
@@ -405,7 +410,7 @@ def main(argv=None, model_factory=None):
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": args.dtype,
         # structured beside `dtype`: how many LEADING text blocks of the bf16 engine run on f16 MFMA operands
-        "text_f16_layers": int(getattr(model.engine, "text_f16_layers", 0)),
+        "text_f16_lead_blocks": int(getattr(model.engine, "text_f16_layers", 0)),
         "rccl_ranks": rccl_ranks, "rank_devices": rank_devices,
         "data": "synthetic" if not rehearsal else "synthetic; gloo REHEARSAL with a stub engine -- control flow only, not a measurement",
         "config": {"workload": f"full dual encoder (image tower + text tower + L2 normalise + logits_per_image), "
@@ -609,7 +614,10 @@ def main(argv=None, model_factory=None):
         except Exception as e:  # pragma: no cover
             res["rccl_one_rank"] = {"error": repr(e)}
     res["cpu_baseline"] = cpu_baseline(cfg, sd, args.cpu_seconds) if (world == 1 and not args.no_cpu_baseline) else None
+    sys.stdout.flush()
+    os.dup2(real_stdout_fd, 1)
     print(json.dumps(res), flush=True)
+    os.dup2(2, 1)                       # whatever teardown prints is not part of the line either
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

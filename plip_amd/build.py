@@ -19,7 +19,7 @@ CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 BUILD = os.path.join(CSRC, "build")
 LIB = os.path.join(CSRC, "libplipmi.so")
 SOURCES = ["engine.hip", "gemm.hip", "gemm_f32.hip", "gemm_bf16.hip", "gemm_f16.hip", "gemm_skinny.hip", "kernels.hip",
-           "attention.hip", "attention_mfma.hip"]
+           "attention.hip", "attention_mfma.hip", "qkv_attention.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-Wno-unused-result", "-Wno-unused-value"]
 

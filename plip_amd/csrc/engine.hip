@@ -38,6 +38,9 @@ static constexpr int kLatencyBatch = 0;
 using namespace plipmi;
 
 static thread_local char g_err[512] = "";
+// TEST / A-B hook (plipmi_set_gemm_variant 3000 + on; plipmi_test.h): 0 = the text tower's q/k/v projection and its attention run
+// as two kernels even where the fused kernel (qkv_attention.hip) applies.  The product path never writes it.
+static int g_fuse_qkv_attention = 1;
 
 static int fail(int code, const char* fmt, ...) {
   va_list ap;
@@ -347,6 +350,27 @@ int enter_block(plipmi_engine* e, Tower& t, int l, int M, hipStream_t s) {
   return PLIPMI_OK;
 }
 
+// LayerNorm-folded q/k/v projection + attention of one block: ONE kernel where the sequence fits the fused tile (77-token
+// captions: qkv_attention.hip, the `qkv` activation never reaches memory), else the GEMM and the attention kernel.
+// Either way t.att holds the attention output afterwards, the same bits.
+int run_qkv_attention(plipmi_engine* e, Tower& t, const LayerW& w, int B, int causal, const int64_t* key_mask, hipStream_t s,
+                      const LnArgs& use) {
+  const int M = B * t.S, D = t.D;
+  const int impl = (&t == &e->vis) ? e->attn_impl_vis : e->attn_impl_txt;
+  const int* cu = t.packed ? t.cu : nullptr;
+  const int* md = t.packed ? t.mdev : nullptr;
+  const double att_flops = 4.0 * B * t.H * (double)t.S * t.S * 64;
+  if (g_fuse_qkv_attention && impl == 1 && !t.packed && !t.small && qkv_attention_supports(t.cur, B, t.S, t.H, D)) {
+    Scope sc(e, s, "qkv_attention", 2.0 * M * 3.0 * D * (double)D + att_flops, ((double)M * D * 2 + 3.0 * D * D) * e->esz);
+    HIP_TRY(launch_qkv_attention(t.cur, t.h, w.wqkv, w.bqkv, use.stats, use.inv_d, use.eps, t.att, B, t.S, t.H, causal, key_mask, s));
+    return PLIPMI_OK;
+  }
+  RUN(run_gemm(e, t, EPI_BIAS_LN, t.h, w.wqkv, t.qkv, w.bqkv, M, 3 * D, D, 3 * D, 0, s, "qkv", &use, md));
+  Scope sc(e, s, impl ? "attention_mfma" : "attention_valu", att_flops, (double)M * 4 * D * e->esz);
+  HIP_TRY(launch_attention(t.qkv, t.att, t.cur, B, t.S, t.H, causal, key_mask, impl, s, cu));
+  return PLIPMI_OK;
+}
+
 // n_layers pre-LN residual blocks over the tower's residual stream x (CLIPEncoderLayer, modeling_clip.py:362-383)
 int run_layers(plipmi_engine* e, Tower& t, int B, int n_layers, int causal, const int64_t* key_mask, hipStream_t s,
                bool more_follow = false) {
@@ -371,8 +395,7 @@ int run_layers(plipmi_engine* e, Tower& t, int B, int n_layers, int causal, cons
     for (int l = 0; l < n_layers; ++l) {
       const LayerW& w = t.layers[l];
       RUN(enter_block(e, t, l, M, s));
-      RUN(run_gemm(e, t, EPI_BIAS_LN, t.h, w.wqkv, t.qkv, w.bqkv, M, 3 * D, D, 3 * D, 0, s, "qkv", &use, md));
-      RUN(attention());
+      RUN(run_qkv_attention(e, t, w, B, causal, key_mask, s, use));
       RUN(run_gemm(e, t, EPI_RESID_SPLIT, t.att, w.wo, nullptr, w.bo, M, D, D, D, 0, s, "out_proj", &emit, md));
       RUN(run_gemm(e, t, EPI_QGELU_LN, t.h, w.w1, t.mlp, w.b1, M, F, D, F, 0, s, "fc1", &use, md));
       // a block whose successor runs on the other 16-bit operand type (the last f16 block of a mixed text tower) writes its
@@ -417,13 +440,10 @@ int run_last_block_pooled(plipmi_engine* e, Tower& t, int B, int causal, const i
                           int eos_id, hipStream_t s) {
   const int M = B * t.S, D = t.D, F = t.F;
   const LayerW& w = t.layers[t.L - 1];
-  const int impl = (&t == &e->vis) ? e->attn_impl_vis : e->attn_impl_txt;
   LnArgs use; use.stats = t.st; use.ns = D / kLnSlice; use.inv_d = 1.0f / (float)D; use.eps = e->cfg.layer_norm_eps;
   const int* cu = t.packed ? t.cu : nullptr;
   RUN(enter_block(e, t, t.L - 1, M, s));
-  RUN(run_gemm(e, t, EPI_BIAS_LN, t.h, w.wqkv, t.qkv, w.bqkv, M, 3 * D, D, 3 * D, 0, s, "qkv", &use, t.packed ? t.mdev : nullptr));
-  { Scope sc(e, s, impl ? "attention_mfma" : "attention_valu", 4.0 * B * t.H * (double)t.S * t.S * 64, (double)M * 4 * D * e->esz);
-    HIP_TRY(launch_attention(t.qkv, t.att, t.cur, B, t.S, t.H, causal, key_mask, impl, s, cu)); }
+  RUN(run_qkv_attention(e, t, w, B, causal, key_mask, s, use));
   { Scope sc(e, s, "pool_gather", 0, (double)B * D * (2 * e->esz + 8));
     HIP_TRY(launch_pool_gather(t.att, t.h, t.lo, t.S, D, ids, eos_id, t.attp, t.xp, B, t.cur, s, cu)); }
   LnArgs emit; emit.xb_out = t.hp; emit.st_out = t.stp;
@@ -973,7 +993,20 @@ int plipmi_gemm_nt_ld(int dtype, int epilogue, int variant, int M, int N, int K,
   return PLIPMI_OK;
 }
 
-void plipmi_set_gemm_variant(int variant) { gemm_set_default_override(variant); }
+void plipmi_set_gemm_variant(int variant) {
+  if (variant >= 3000 && variant < 4000) { g_fuse_qkv_attention = variant - 3000; return; }
+  if (variant == -1) g_fuse_qkv_attention = 1;
+  gemm_set_default_override(variant);
+}
+int plipmi_qkv_attention(int dtype, const void* A, const void* W, const float* c2, const float* stats, int ns, float eps, void* out,
+                         int B, int S, int H, int causal, const int64_t* key_mask, void* stream) {
+  if (!A || !W || !c2 || !stats || !out || ns <= 0 || ns * kLnSlice != H * 64) return fail(PLIPMI_ERR_INVALID, "bad argument");
+  if (!qkv_attention_supports(dtype, B, S, H, H * 64))
+    return fail(PLIPMI_ERR_INVALID, "the fused q/k/v + attention kernel takes 16-bit operands, 65 .. 80 tokens, widths of 64 H (a multiple of 128)");
+  HIP_TRY(launch_qkv_attention(dtype, A, W, c2, stats, 1.0f / (float)(ns * kLnSlice), eps, out, B, S, H, causal, key_mask,
+                               reinterpret_cast<hipStream_t>(stream)));
+  return PLIPMI_OK;
+}
 int plipmi_check_async(plipmi_handle h) {
   if (!h) return fail(PLIPMI_ERR_INVALID, "null handle");
   return check_async(h);

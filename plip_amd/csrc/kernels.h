@@ -105,6 +105,14 @@ hipError_t launch_scale_copy(const float* src, float* dst, int n, float scale, h
 hipError_t launch_attention(const void* qkv, void* out, int dtype, int B, int S, int H, int causal,
                             const int64_t* key_mask, int impl, hipStream_t s, const int* cu = nullptr);
 
+// The text tower's LayerNorm-folded q/k/v projection with the attention in its epilogue (qkv_attention.hip): one launch, no
+// `qkv` tensor in memory.  A = the residual stream's operand plane [B*S, D], W / c2 = the folded q | k | v weights [3D, D] and
+// biases, stats = the rows' LayerNorm partials [B*S, D/64, 2]; out = attention output [B*S, D], bit-identical to
+// gemm.h EPI_BIAS_LN followed by launch_attention(impl 1).  16-bit dtypes, 65 .. 80 tokens, D = 64 H.
+bool qkv_attention_supports(int dtype, int B, int S, int H, int D);
+hipError_t launch_qkv_attention(int dtype, const void* A, const void* W, const float* c2, const float* stats, float ln_inv_d,
+                                float ln_eps, void* out, int B, int S, int H, int causal, const int64_t* key_mask, hipStream_t s);
+
 // Packed captions (text tower, opt-in): a causal tower's pooled output depends on rows 0 .. EOS only, so the rows past a
 // caption's EOS token need not exist.  One workgroup: len[b] = eos_position(ids[b]) + 1, cu = exclusive prefix sums
 // [B+1], rowmap[r] = (b << 8) | t for packed row r (S <= 256), *m_dev = cu[B] = live rows.

@@ -54,6 +54,68 @@ def test_attention_kernels(B, S, H, causal, use_mask, mode):
     assert err < tol, f"{mode} B{B} S{S} H{H} causal={causal} mask={use_mask}: max err {err:.3e}"
 
 
+FUSED = [(256, 77, 8, True, True), (5, 77, 8, True, False), (7, 65, 2, True, True), (9, 80, 4, True, True),
+         (6, 77, 12, True, True), (4, 72, 2, False, True), (1, 77, 8, True, False)]
+
+
+@pytest.mark.parametrize("B,S,H,causal,use_mask", FUSED)
+@pytest.mark.parametrize("hdt", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+def test_fused_qkv_attention_matches_the_two_kernels(B, S, H, causal, use_mask, hdt):
+    """csrc/qkv_attention.hip -- the text tower's LayerNorm-folded q/k/v GEMM with the attention in its epilogue -- against
+    the two kernels it replaces (plipmi_gemm_nt_ln mode 0 on the engine's own tile + plipmi_attention impl 1): the SAME
+    BITS, for whole and partial caption groups, with and without the tokenizer mask; and against fp64."""
+    from plip_amd.engine import attention, gemm_nt_ln, qkv_attention
+    dev = torch.device("cuda:0")
+    D = H * 64
+    g = torch.Generator().manual_seed(1000 * S + 10 * H + B)
+    x = torch.randn(B * S, D, generator=g) * 2.0 + 0.3                       # the LayerNorm input rows
+    a = x.to(dev).to(hdt)
+    xs = x.to(dev).reshape(B * S, H, 64)
+    st = torch.stack((xs.sum(-1), ((xs - xs.mean(-1, keepdim=True)) ** 2).sum(-1)), dim=-1).contiguous()
+    w = torch.randn(3 * D, D, generator=g) / D ** 0.5
+    w = w - w.mean(-1, keepdim=True)                                         # folded weights have centred rows
+    w[:D] *= 0.125 * 3.0                                                     # q pre-scaled; x3 sharpens the softmax
+    w = w.to(dev).to(hdt)
+    c2 = (torch.randn(3 * D, generator=g) * 0.2).to(dev)
+    mask = None
+    if use_mask:
+        lens = torch.randint(1, S + 1, (B,), generator=g)
+        mask = (torch.arange(S)[None, :] < lens[:, None]).long().to(dev)
+    qkv = gemm_nt_ln(0, a, w, c2, st, eps=1e-5, variant=-1)
+    want = attention(qkv, B, S, H, causal, mask, impl=1)
+    got = qkv_attention(a, w, c2, st, B, S, H, causal, mask, eps=1e-5)
+    torch.cuda.synchronize()
+    assert torch.isfinite(got).all()
+    assert torch.equal(got, want), f"max |diff| {(got.float() - want.float()).abs().max().item():.3e}"
+    ref = _ref(qkv, B, S, H, causal, mask)
+    assert (got.double() - ref).abs().max().item() < (3e-2 if hdt == torch.bfloat16 else 4e-3)
+
+
+def test_engine_runs_the_fused_text_kernel_and_the_two_kernels_to_the_same_bits(engines):
+    """The bf16 engine's text tower (77 tokens) takes the fused kernel; the test hook that splits it back into GEMM + attention
+    must not move a single bit of text_embeds, nor of the hidden states."""
+    from plip_amd import _lib
+    lib = _lib.load()
+    for dtype in ("bf16", "f16"):
+        model, cfg, sd, px, ids, mask = engines("vitb32_b4", dtype)
+        ids_t, mask_t = torch.from_numpy(ids), torch.from_numpy(mask)
+        try:
+            lib.plipmi_set_gemm_variant(3000)
+            two = model.get_text_features(input_ids=ids_t, attention_mask=mask_t)
+            h_two = model.engine.hidden("text", 3, ids_t)
+            lib.plipmi_set_gemm_variant(3001)
+            one = model.get_text_features(input_ids=ids_t, attention_mask=mask_t)
+            h_one = model.engine.hidden("text", 3, ids_t)
+        finally:
+            lib.plipmi_set_gemm_variant(-1)
+        assert torch.equal(one, two) and torch.equal(h_one, h_two)
+        rows = []
+        with model.engine.profile(rows):
+            model.get_text_features(input_ids=ids_t, attention_mask=mask_t)
+        names = {r["name"].split("|")[0] for r in rows}
+        assert "qkv_attention" in names and not any(n.startswith("attention") for n in names), names
+
+
 def test_attention_argument_checks():
     from plip_amd._lib import PlipmiError
     from plip_amd.engine import attention
