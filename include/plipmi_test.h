@@ -76,7 +76,10 @@ int plipmi_gemm_nt_ln(int dtype, int mode, int variant, int M, int N, int K, con
  * plipmi_gemm_nt_ln(mode 0) followed by plipmi_attention(impl 1).  dtype PLIPMI_BF16 | PLIPMI_F16, 65 <= S <= 80, ns = H.
  * (plipmi_set_gemm_variant(3000) makes the ENGINE run the two kernels instead, 3001 / -1 the fused one again.) */
 int plipmi_qkv_attention(int dtype, const void* A, const void* W, const float* c2, const float* stats, int ns, float eps, void* out,
-                         int B, int S, int H, int causal, const int64_t* key_mask, void* stream);
+                         int B, int S, int H, int causal, const int64_t* key_mask,
+                         uint64_t* trace /* NULL, or 8 x uint64 per workgroup: {start, prologue done, K loop done, Q/K/V images
+                                            written, end (s_memtime), tile id, 0, start | lifetime << 32 (s_memrealtime)} */,
+                         void* stream);
 
 /* Kernel-level entry for the attention kernels: out[B*S, H*64] = softmax(q k^T + masks) v over the fused
  * activation qkv [B*S, 3*H*64] (q | k | v, 1/sqrt(64) already folded into q).

@@ -59,7 +59,7 @@ TEST_SYMBOLS = {
     "plipmi_gemm_nt_ld": (_i, [_i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _f, _vp, _vp]),
     "plipmi_gemm_nt_traced": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
     "plipmi_attention": (_i, [_i, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
-    "plipmi_qkv_attention": (_i, [_i, _vp, _vp, _vp, _vp, _i, _f, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "plipmi_qkv_attention": (_i, [_i, _vp, _vp, _vp, _vp, _i, _f, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
 }
 # every symbol include/plipmi.h declares (the product interface): (restype, argtypes)
 SYMBOLS = {

@@ -999,12 +999,12 @@ void plipmi_set_gemm_variant(int variant) {
   gemm_set_default_override(variant);
 }
 int plipmi_qkv_attention(int dtype, const void* A, const void* W, const float* c2, const float* stats, int ns, float eps, void* out,
-                         int B, int S, int H, int causal, const int64_t* key_mask, void* stream) {
+                         int B, int S, int H, int causal, const int64_t* key_mask, uint64_t* trace, void* stream) {
   if (!A || !W || !c2 || !stats || !out || ns <= 0 || ns * kLnSlice != H * 64) return fail(PLIPMI_ERR_INVALID, "bad argument");
   if (!qkv_attention_supports(dtype, B, S, H, H * 64))
     return fail(PLIPMI_ERR_INVALID, "the fused q/k/v + attention kernel takes 16-bit operands, 65 .. 80 tokens, widths of 64 H (a multiple of 128)");
   HIP_TRY(launch_qkv_attention(dtype, A, W, c2, stats, 1.0f / (float)(ns * kLnSlice), eps, out, B, S, H, causal, key_mask,
-                               reinterpret_cast<hipStream_t>(stream)));
+                               reinterpret_cast<hipStream_t>(stream), reinterpret_cast<unsigned long long*>(trace)));
   return PLIPMI_OK;
 }
 int plipmi_check_async(plipmi_handle h) {

@@ -111,7 +111,8 @@ hipError_t launch_attention(const void* qkv, void* out, int dtype, int B, int S,
 // gemm.h EPI_BIAS_LN followed by launch_attention(impl 1).  16-bit dtypes, 65 .. 80 tokens, D = 64 H.
 bool qkv_attention_supports(int dtype, int B, int S, int H, int D);
 hipError_t launch_qkv_attention(int dtype, const void* A, const void* W, const float* c2, const float* stats, float ln_inv_d,
-                                float ln_eps, void* out, int B, int S, int H, int causal, const int64_t* key_mask, hipStream_t s);
+                                float ln_eps, void* out, int B, int S, int H, int causal, const int64_t* key_mask, hipStream_t s,
+                                unsigned long long* trace = nullptr /* test hook: in-kernel timeline, 8 x u64 per workgroup */);
 
 // Packed captions (text tower, opt-in): a causal tower's pooled output depends on rows 0 .. EOS only, so the rows past a
 // caption's EOS token need not exist.  One workgroup: len[b] = eos_position(ids[b]) + 1, cu = exclusive prefix sums

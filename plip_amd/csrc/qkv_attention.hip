@@ -41,7 +41,8 @@ constexpr int kImgBytes = kVs + 2 * kVImg;
 static_assert(kImgBytes <= 2 * kStage, "the Q / K / V images reuse the staging LDS");
 constexpr int kLnRows = 2 * kStage;                     // rstd of the tile's rows, 320 floats
 constexpr int kMaskWords = kLnRows + kBM * 4;           // key validity: 4 captions x 4 x 32 bits
-constexpr int kLdsBytes = kMaskWords + kCPT * 4 * 4;
+constexpr int kC2 = kMaskWords + kCPT * 4 * 4;           // the head's 192 biases (c2 of q_h | k_h | v_h)
+constexpr int kLdsBytes = kC2 + kBN * 4;
 
 struct QkvAttnParams {
   const void* A;        // [B*S, D] operand plane of the residual stream (LayerNorm input, rounded)
@@ -52,6 +53,9 @@ struct QkvAttnParams {
   const int64_t* key_mask;   // [B, S] or nullptr
   int B, S, H, D, causal;
   float ln_inv_d, ln_eps;
+  // test hook (plipmi_qkv_attention): 8 x u64 per workgroup {start, prologue done, K loop done, images written, end (s_memtime),
+  // tile id, 0, start | lifetime << 32 (s_memrealtime, 100 MHz)}; nullptr on the product path
+  unsigned long long* trace = nullptr;
 };
 
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
@@ -156,9 +160,18 @@ __global__ __launch_bounds__(kNT) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       }
   };
 
-  // ---- prologue: tile 0 on its way, rstd of the tile's rows and the captions' key-validity words parked in LDS meanwhile
+  // ---- prologue: tiles 0 and 1 on their way, rstd of the tile's rows and the captions' key-validity words parked in LDS meanwhile
+  const int KT = D / 64;
+  unsigned long long* trace = p.trace ? p.trace + (size_t)bid * 8 : nullptr;
+  unsigned long long trace_real0 = 0;
+  if (trace && tid == 0) {
+    trace[0] = __builtin_amdgcn_s_memtime();
+    trace_real0 = __builtin_amdgcn_s_memrealtime();
+    trace[5] = lid;
+  }
   fill_a(0);
   fill_w(0);
+  if (KT > 1) { fill_a(1); fill_w(1); }
   {
     float* ln_rows = reinterpret_cast<float*>(smem + kLnRows);
     const int ns = D / kLnSlice;
@@ -170,6 +183,8 @@ __global__ __launch_bounds__(kNT) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       ln_combine(p.stats + (size_t)(c * S + pos) * ns * 2, ns, p.ln_inv_d, p.ln_eps, mu, rs);
       ln_rows[r] = rs;
     }
+    // the head's biases: epilogue 1 reads them from LDS (six dependent L2 round trips per wave otherwise: 5.1 -> us of its time)
+    if (tid < kBN) reinterpret_cast<float*>(smem + kC2)[tid] = p.c2[(tid >> 6) * D + head * 64 + (tid & 63)];
     // key validity bits (sequence padding and the tokenizer's attention_mask), 32 keys per word: wave w covers caption w >> 1,
     // keys 64 (w & 1) + lane
     unsigned* mkw = reinterpret_cast<unsigned*>(smem + kMaskWords);
@@ -181,27 +196,30 @@ __global__ __launch_bounds__(kNT) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       mkw[(wave >> 1) * 4 + 2 * (wave & 1) + 1] = (unsigned)(bits >> 32);
     }
   }
-  wait_vm0();
+  if (KT > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PA + PW) : "memory");   // tile 0 has landed (in-order retirement), tile 1 may still fly
+  else wait_vm0();
   __syncthreads();
+  if (trace && tid == 0) trace[1] = __builtin_amdgcn_s_memtime();
 
-  // ---- K loop
-  const int KT = D / 64;
+  // ---- K loop.  Two stages, and the fill of tile kt+2 goes out right BEHIND the barrier of iteration kt -- every wave's reads of
+  // tile kt's stage have returned by then -- so a tile has a whole iteration to arrive, not half of one (the A rows were just written
+  // by the previous kernel and come from HBM / the Infinity Cache, ~2 us away).
 #pragma unroll
   for (int r = 0; r < MI2 + NI2; ++r) read_frag(smem, 0, 0, r);
   __builtin_amdgcn_sched_barrier(0);
   for (int kt = 0; kt < KT; ++kt) {
     const char* sc = smem + (kt & 1) * kStage;
     const char* sn = smem + ((kt & 1) ^ 1) * kStage;
-    const bool more = kt + 1 < KT;
-    step(0, sc, 1, more ? ((kt & 1) ^ 1) : -1);
-    // this wave's pieces of tile kt+1 have landed and its last reads of tile kt have returned: publish, then the second step's
-    // MFMAs (registers only) with the next tile's first fragments read between them
+    step(0, sc, 1, -1);
+    // this wave's pieces of tile kt+1 have landed (the only requests outstanding) and its last reads of tile kt have returned:
+    // publish, then the second step's MFMAs (registers only) with the next tile's first fragments read between them
     wait_vm0();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();
     __builtin_amdgcn_sched_barrier(0);
-    step(1, sn, more ? 0 : -1, -1);
+    step(1, sn, kt + 1 < KT ? 0 : -1, kt + 2 < KT ? (kt & 1) : -1);
   }
+  if (trace && tid == 0) trace[2] = __builtin_amdgcn_s_memtime();
 
   // ---- epilogue 1: q / k / v of the four captions -> LDS images in the operand type
   __syncthreads();   // every wave is past its last fragment read: the staging LDS is free
@@ -214,7 +232,7 @@ __global__ __launch_bounds__(kNT) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int jj = 0; jj < NI2; ++jj) {
       const int n = wn * 96 + jj * 16 + 4 * g16;          // column of the tile: segment n / 64 (q, k, v), head dim d = n % 64
       const int seg = n >> 6, d = n & 63;
-      const float4 cb = *reinterpret_cast<const float4*>(p.c2 + seg * D + head * 64 + d);
+      const float4 cb = *reinterpret_cast<const float4*>(smem + kC2 + (seg * 64 + d) * 4);
       const int chunk = d >> 3, half = (d >> 2) & 1;
 #pragma unroll
       for (int ii = 0; ii < MI2; ++ii) {
@@ -237,120 +255,164 @@ __global__ __launch_bounds__(kNT) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
   }
   __syncthreads();
+  if (trace && tid == 0) trace[3] = __builtin_amdgcn_s_memtime();
 
   // ---- epilogue 2: attention, two waves per caption
   const int cl = wave >> 1, whalf = wave & 1;             // caption of the tile, which of its two waves
   const int cap = cap0 + cl;
-  if (cap >= p.B) return;                                 // wave-uniform (no barrier follows)
-  const int nqb = (S + 31) >> 5;                          // 32-query blocks of a caption: 3 for 65 .. 80 tokens
-  const int blk0 = whalf == 0 ? 0 : (nqb >= 3 ? 2 : 1);
-  const int blk1 = whalf == 0 ? (nqb >= 3 ? 2 : 1) : nqb; // [blk0, blk1)
+  if (cap >= p.B && !trace) return;                       // wave-uniform (no barrier follows on the product path)
+  if (cap < p.B) {
   const int lrow = lane & 31, hi = lane >> 5;
+  const int lsw = (lrow >> 1) & 7;                        // query / key tiles start at multiples of 32: the rows' swizzle term
   const unsigned* mkw = reinterpret_cast<const unsigned*>(smem + kMaskWords) + cl * 4;
   const unsigned vw[3] = {(unsigned)__builtin_amdgcn_readfirstlane((int)mkw[0]), (unsigned)__builtin_amdgcn_readfirstlane((int)mkw[1]),
                           (unsigned)__builtin_amdgcn_readfirstlane((int)mkw[2])};
-  const char* Qs = smem + kQs + cl * kSPad * 128;         // caption-relative images (80 rows per caption: (row >> 1) & 7 keeps its
+  char* Qs = smem + kQs + cl * kSPad * 128;               // caption-relative images (80 rows per caption: (row >> 1) & 7 keeps its
   const char* Ks = smem + kKs + cl * kSPad * 128;         // meaning, 80 is a multiple of 16)
   const char* Vs = smem + kVs + cl * kSPad * 64;
-  constexpr int KTL = 3;                                  // 32-key tiles
-  for (int blk = blk0; blk < blk1; ++blk) {
-    const int q0 = 32 * blk;
-    const int qidx = q0 + lrow;
-    const int lsw = (lrow >> 1) & 7;                      // q0 is a multiple of 32: the swizzle term of row q0 + lrow / 32 t + lrow
-    u32x4 qf[4];
+  constexpr int KTL = 3;                                  // 32-key tiles (65 .. 80 tokens: three query blocks, three key tiles)
+  // NB query blocks of 32, starting at block `first`, worked through TOGETHER: their MFMA chains and softmax passes are
+  // independent, and with two waves per SIMD that interleaving is what covers the LDS and MFMA latencies.  Per block the
+  // arithmetic is attention_mfma_kernel's, operation for operation.
+  auto attend = [&](auto nb_c, int first) __attribute__((always_inline)) {
+    constexpr int NB = decltype(nb_c)::value;
+    u32x4 qf[NB][4];
+    f32x16 sc[NB][KTL];
+    float rmax[NB], m2[NB], rsum[NB];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-      qf[ks] = *reinterpret_cast<const u32x4*>(Qs + qidx * 128 + (((ks * 2 + hi) ^ lsw) << 4));
-    f32x16 sc[KTL];
-    float rmax = -INFINITY;
+    for (int b = 0; b < NB; ++b) {
+      const int qidx = 32 * (first + b) + lrow;
 #pragma unroll
-    for (int t = 0; t < KTL; ++t) {
-      const bool live = !(p.causal && 32 * t > q0 + 31);  // wave-uniform: tile entirely above the diagonal
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sc[t][r] = 0.f;
-      if (live) {
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          const u32x4 kf = *reinterpret_cast<const u32x4*>(Ks + (32 * t + lrow) * 128 + (((ks * 2 + hi) ^ lsw) << 4));
-          sc[t] = half_traits<T>::mfma32(__builtin_bit_cast(X8, kf), __builtin_bit_cast(X8, qf[ks]), sc[t]);
-        }
-      }
-      unsigned bits = live ? vw[t] : 0u;
-      if (p.causal) {
-        const int d = qidx - 32 * t;
-        bits &= d < 0 ? 0u : (d >= 31 ? 0xffffffffu : (2u << d) - 1u);
-      }
-      const unsigned nbits = ~(bits >> (4 * hi));        // 1 = masked
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const unsigned m = (unsigned)__builtin_amdgcn_sbfe((int)nbits, (r & 3) + 8 * (r >> 2), 1);   // masked ? 0xffffffff : 0
-        sc[t][r] += __builtin_bit_cast(float, m & 0xff800000u);                                       // + (-inf) or + 0
-        rmax = fmaxf(rmax, sc[t][r]);
-      }
+      for (int ks = 0; ks < 4; ++ks)
+        qf[b][ks] = *reinterpret_cast<const u32x4*>(Qs + qidx * 128 + (((ks * 2 + hi) ^ lsw) << 4));
+      rmax[b] = -INFINITY;
     }
-    rmax = fmaxf(rmax, __shfl_xor(rmax, 32, 64));
-    const float m_use = (rmax == -INFINITY) ? 0.f : rmax;
-    const float m2 = m_use * 1.4426950408889634f;
-    float rsum = 0.f;
 #pragma unroll
     for (int t = 0; t < KTL; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        sc[t][r] = __builtin_amdgcn_exp2f(fmaf(sc[t][r], 1.4426950408889634f, -m2));
-        rsum += sc[t][r];
-      }
-    rsum += __shfl_xor(rsum, 32, 64);
-    f32x16 oacc[2];
+      for (int b = 0; b < NB; ++b) {
+        const int q0 = 32 * (first + b);
+        const bool live = !(p.causal && 32 * t > q0 + 31);  // wave-uniform: tile entirely above the diagonal
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
+        for (int r = 0; r < 16; ++r) sc[b][t][r] = 0.f;
+        if (live) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
-    const char* vlane = Vs + vtr_lane_offset(lrow, hi);
-#pragma unroll
-    for (int t = 0; t < KTL; ++t) {
-      if (p.causal && 32 * t > q0 + 31) continue;
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        X8 pf;
-#pragma unroll
-        for (int jj = 0; jj < 8; ++jj) pf[jj] = (T)sc[t][8 * s2 + jj];
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-          const X8 vf = vtr_fragment<T>(vlane, dt * kVImg + (32 * t + 16 * s2) * 64);
-          oacc[dt] = half_traits<T>::mfma32(vf, pf, oacc[dt]);
+          for (int ks = 0; ks < 4; ++ks) {
+            const u32x4 kf = *reinterpret_cast<const u32x4*>(Ks + (32 * t + lrow) * 128 + (((ks * 2 + hi) ^ lsw) << 4));
+            sc[b][t] = half_traits<T>::mfma32(__builtin_bit_cast(X8, kf), __builtin_bit_cast(X8, qf[b][ks]), sc[b][t]);
+          }
         }
       }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const int q0 = 32 * (first + b), qidx = q0 + lrow;
+#pragma unroll
+      for (int t = 0; t < KTL; ++t) {
+        const bool live = !(p.causal && 32 * t > q0 + 31);
+        unsigned bits = live ? vw[t] : 0u;
+        if (p.causal) {
+          const int d = qidx - 32 * t;
+          bits &= d < 0 ? 0u : (d >= 31 ? 0xffffffffu : (2u << d) - 1u);
+        }
+        const unsigned nbits = ~(bits >> (4 * hi));        // 1 = masked
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const unsigned m = (unsigned)__builtin_amdgcn_sbfe((int)nbits, (r & 3) + 8 * (r >> 2), 1);   // masked ? 0xffffffff : 0
+          sc[b][t][r] += __builtin_bit_cast(float, m & 0xff800000u);                                    // + (-inf) or + 0
+          rmax[b] = fmaxf(rmax[b], sc[b][t][r]);
+        }
+      }
+      rmax[b] = fmaxf(rmax[b], __shfl_xor(rmax[b], 32, 64));
+      const float m_use = (rmax[b] == -INFINITY) ? 0.f : rmax[b];
+      m2[b] = m_use * 1.4426950408889634f;
+      rsum[b] = 0.f;
+#pragma unroll
+      for (int t = 0; t < KTL; ++t) {
+        const bool live = !(p.causal && 32 * t > q0 + 31);
+        if (!live) {                                       // every score of the tile is -inf: exp gives exact zeros
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sc[b][t][r] = 0.f;
+          continue;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          sc[b][t][r] = __builtin_amdgcn_exp2f(fmaf(sc[b][t][r], 1.4426950408889634f, -m2[b]));
+          rsum[b] += sc[b][t][r];
+        }
+      }
+      rsum[b] += __shfl_xor(rsum[b], 32, 64);
     }
-    // normalised 32 x 64 output tile -> this wave's OWN Q rows (it holds their fragments in registers, nobody else reads
-    // them), then whole 128-byte rows to memory.  Odd rows keep their two 8-byte halves exchanged (bank spread of the
-    // transposing ds_write_b64, attention_mfma.hip).
-    const float inv = 1.0f / rsum;
-    char* orow_lds = const_cast<char*>(Qs) + (q0 + lrow) * 128;
-    __builtin_amdgcn_wave_barrier();
-    // (rows 80 .. 95 of the third block are the NEXT caption's first Q rows, which its own wave may not have read yet: the
-    //  queries there do not exist, their lanes write nothing)
-    if (qidx < kSPad) {
+    f32x16 oacc[NB][2];
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) {
-          const int d = dt * 32 + 8 * q4 + 4 * hi;
-          const int c = d >> 3;
-          const X4 v = {from_f32<T>(oacc[dt][4 * q4 + 0] * inv), from_f32<T>(oacc[dt][4 * q4 + 1] * inv),
-                        from_f32<T>(oacc[dt][4 * q4 + 2] * inv), from_f32<T>(oacc[dt][4 * q4 + 3] * inv)};
-          *reinterpret_cast<X4*>(orow_lds + ((c ^ lsw) << 4) + ((((d >> 2) ^ lrow) & 1) << 3)) = v;
+        for (int r = 0; r < 16; ++r) oacc[b][dt][r] = 0.f;
+    const char* vlane = Vs + vtr_lane_offset(lrow, hi);
+#pragma unroll
+    for (int t = 0; t < KTL; ++t)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          if (p.causal && 32 * t > 32 * (first + b) + 31) continue;
+          X8 pf;
+#pragma unroll
+          for (int jj = 0; jj < 8; ++jj) pf[jj] = (T)sc[b][t][8 * s2 + jj];
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) {
+            const X8 vf = vtr_fragment<T>(vlane, dt * kVImg + (32 * t + 16 * s2) * 64);
+            oacc[b][dt] = half_traits<T>::mfma32(vf, pf, oacc[b][dt]);
+          }
         }
+    // normalised 32 x 64 output tiles -> this wave's OWN Q rows (it holds their fragments in registers, nobody else reads
+    // them), then whole 128-byte rows to memory.  Odd rows keep their two 8-byte halves exchanged (bank spread of the
+    // transposing ds_write_b64, attention_mfma.hip).
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const int q0 = 32 * (first + b), qidx = q0 + lrow;
+      const float inv = 1.0f / rsum[b];
+      char* orow_lds = Qs + qidx * 128;
+      // (rows 80 .. 95 of the third block are the NEXT caption's first Q rows, which its own wave may not have read yet: the
+      //  queries there do not exist, their lanes write nothing)
+      if (qidx < kSPad) {
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4) {
+            const int d = dt * 32 + 8 * q4 + 4 * hi;
+            const int c = d >> 3;
+            const X4 v = {from_f32<T>(oacc[b][dt][4 * q4 + 0] * inv), from_f32<T>(oacc[b][dt][4 * q4 + 1] * inv),
+                          from_f32<T>(oacc[b][dt][4 * q4 + 2] * inv), from_f32<T>(oacc[b][dt][4 * q4 + 3] * inv)};
+            *reinterpret_cast<X4*>(orow_lds + ((c ^ lsw) << 4) + ((((d >> 2) ^ lrow) & 1) << 3)) = v;
+          }
+      }
     }
     __builtin_amdgcn_wave_barrier();
     const int c = lane & 7;
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int r = q0 + it * 8 + (lane >> 3);
-      const u32x4 raw = *reinterpret_cast<const u32x4*>(Qs + r * 128 + ((c ^ ((r >> 1) & 7)) << 4));
-      const u32x4 v = (r & 1) ? u32x4{raw[2], raw[3], raw[0], raw[1]} : raw;
-      if (r < S) *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(p.out) + ((size_t)cap * S + r) * D + head * 64 + c * 8) = v;
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int r = 32 * (first + b) + it * 8 + (lane >> 3);
+        const u32x4 raw = *reinterpret_cast<const u32x4*>(Qs + r * 128 + ((c ^ ((r >> 1) & 7)) << 4));
+        const u32x4 v = (r & 1) ? u32x4{raw[2], raw[3], raw[0], raw[1]} : raw;
+        if (r < S) *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(p.out) + ((size_t)cap * S + r) * D + head * 64 + c * 8) = v;
+      }
+  };
+  // 65 .. 80 tokens = three query blocks; under the causal mask block 0 needs one key tile, block 1 two, block 2 three
+  if (whalf == 0) attend(std::integral_constant<int, 2>{}, 0);
+  else attend(std::integral_constant<int, 1>{}, 2);
+  }
+  if (trace) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      trace[4] = __builtin_amdgcn_s_memtime();
+      trace[7] = (trace_real0 & 0xffffffffull) | ((__builtin_amdgcn_s_memrealtime() - trace_real0) << 32);
     }
-    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -377,12 +439,13 @@ bool qkv_attention_supports(int dtype, int B, int S, int H, int D) {
 }
 
 hipError_t launch_qkv_attention(int dtype, const void* A, const void* W, const float* c2, const float* stats, float ln_inv_d,
-                                float ln_eps, void* out, int B, int S, int H, int causal, const int64_t* key_mask, hipStream_t s) {
+                                float ln_eps, void* out, int B, int S, int H, int causal, const int64_t* key_mask, hipStream_t s,
+                                unsigned long long* trace) {
   const int D = H * 64;
   if (!qkv_attention_supports(dtype, B, S, H, D)) return hipErrorInvalidValue;
   QkvAttnParams p;
   p.A = A; p.W = W; p.c2 = c2; p.stats = stats; p.out = out; p.key_mask = key_mask;
-  p.B = B; p.S = S; p.H = H; p.D = D; p.causal = causal; p.ln_inv_d = ln_inv_d; p.ln_eps = ln_eps;
+  p.B = B; p.S = S; p.H = H; p.D = D; p.causal = causal; p.ln_inv_d = ln_inv_d; p.ln_eps = ln_eps; p.trace = trace;
   return dtype == 1 ? launch_t<bf16_t>(p, s) : launch_t<f16_t>(p, s);
 }
 

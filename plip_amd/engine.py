@@ -420,7 +420,8 @@ def attention(qkv: torch.Tensor, B: int, S: int, H: int, causal: bool = False, k
 
 
 def qkv_attention(a: torch.Tensor, w: torch.Tensor, c2: torch.Tensor, stats: torch.Tensor, B: int, S: int, H: int,
-                  causal: bool = True, key_mask: Optional[torch.Tensor] = None, eps: float = 1e-5) -> torch.Tensor:
+                  causal: bool = True, key_mask: Optional[torch.Tensor] = None, eps: float = 1e-5,
+                  trace: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Kernel-level entry (tests) of the fused LayerNorm-folded q/k/v projection + attention (plipmi_qkv_attention):
     a [B*S, 64H], w [3*64H, 64H] (16-bit), c2 [3*64H], stats [B*S, H, 2] -> attention output [B*S, 64H]."""
     lib = _lib.load()
@@ -430,7 +431,7 @@ def qkv_attention(a: torch.Tensor, w: torch.Tensor, c2: torch.Tensor, stats: tor
     out = torch.empty((B * S, D), dtype=a.dtype, device=a.device)
     with torch.cuda.device(a.device):
         _lib.check(lib.plipmi_qkv_attention(_code(a.dtype), _ptr(a), _ptr(w), _ptr(c2), _ptr(stats), H, float(eps), _ptr(out),
-                                            B, S, H, int(causal), _ptr(key_mask),
+                                            B, S, H, int(causal), _ptr(key_mask), _ptr(trace),
                                             C.c_void_p(torch.cuda.current_stream(a.device).cuda_stream)), "plipmi_qkv_attention")
     return out
 

@@ -481,6 +481,64 @@ def sec_gemmtrace():
         _lib.load().plipmi_set_gemm_variant(2000)
 
 
+def sec_qkvattn():
+    """The text tower's fused q/k/v + attention kernel on the bs=256 production shape: us per launch against the two kernels it
+    replaces (warm, and with the A operand cycling through buffer sets larger than the Infinity Cache), and its in-kernel
+    timeline.  usage: gpu_diag.py qkvattn [B S H]"""
+    from plip_amd.engine import attention, gemm_nt_ln, qkv_attention
+    B, S, H = (int(x) for x in sys.argv[2:5]) if len(sys.argv) > 4 else (256, 77, 8)
+    D = H * 64
+    g = torch.Generator().manual_seed(0)
+    hdt = torch.bfloat16
+    nb = max(2, int(600e6 // (B * S * D * 2 * 5)) + 1)
+    xs = [torch.randn(B * S, D, generator=g) for _ in range(nb)]
+    a = [x.to(dev).to(hdt) for x in xs]
+    st = []
+    for x in xs:
+        r = x.to(dev).reshape(B * S, H, 64)
+        st.append(torch.stack((r.sum(-1), ((r - r.mean(-1, keepdim=True)) ** 2).sum(-1)), dim=-1).contiguous())
+    w = torch.randn(3 * D, D, generator=g) / D ** 0.5
+    w = (w - w.mean(-1, keepdim=True)).to(dev).to(hdt)
+    c2 = (torch.randn(3 * D, generator=g) * 0.2).to(dev)
+    mask = (torch.arange(S)[None, :] < torch.randint(8, S + 1, (B,), generator=g)[:, None]).long().to(dev)
+    qkvs = [torch.empty(B * S, 3 * D, device=dev, dtype=hdt) for _ in range(nb)]
+    state = {"i": 0}
+
+    def two(cold):
+        i = state["i"] % nb if cold else 0
+        state["i"] += 1
+        gemm_nt_ln(0, a[i], w, c2, st[i], variant=-1, out=qkvs[i])
+        return attention(qkvs[i], B, S, H, True, mask, impl=1)
+
+    def one(cold):
+        i = state["i"] % nb if cold else 0
+        state["i"] += 1
+        return qkv_attention(a[i], w, c2, st[i], B, S, H, True, mask)
+
+    assert torch.equal(one(False), two(False))
+    for cold in (False, True):
+        t2 = min(_time(lambda: two(cold), iters=3 * nb if cold else 30, warm=nb) for _ in range(2)) * 1e3
+        t1 = min(_time(lambda: one(cold), iters=3 * nb if cold else 30, warm=nb) for _ in range(2)) * 1e3
+        print(f"B={B} S={S} H={H} {'cold' if cold else 'warm'} ({nb} buffer sets): q/k/v GEMM + attention_mfma {t2:6.1f} us   fused qkv_attention {t1:6.1f} us")
+    ngrp = (B + 3) // 4
+    nblk = ngrp * H
+    tr = torch.zeros(nblk * 8, dtype=torch.int64, device=dev)
+    qkv_attention(a[0], w, c2, st[0], B, S, H, True, mask, trace=tr)
+    torch.cuda.synchronize()
+    t = tr.cpu().numpy().reshape(nblk, 8).astype(np.int64)
+    real0 = (t[:, 7] & 0xFFFFFFFF).astype(np.int64)
+    life_us = ((t[:, 7] >> 32) & 0xFFFFFFFF).astype(np.float64) / 100.0
+    start_us = ((real0 - real0.min()) & 0xFFFFFFFF).astype(np.float64) / 100.0
+    clk = (t[:, 4] - t[:, 0]) / np.maximum(life_us, 1e-9) / 1e3
+    q = lambda x: f"p50 {np.median(x):8.0f} cycles = {np.median(x) / np.median(clk) / 1e3:6.2f} us (min {x.min() / np.median(clk) / 1e3:5.2f}, p90 {np.percentile(x, 90) / np.median(clk) / 1e3:5.2f})"
+    print(f"  {nblk} workgroups; first start -> last end {np.max(start_us + life_us):.1f} us; clock median {np.median(clk):.2f} GHz; start offset p50 {np.median(start_us):.2f} p90 {np.percentile(start_us, 90):.2f} us")
+    print("  prologue (2 tiles requested, rstd rows, first tile landed):", q(t[:, 1] - t[:, 0]))
+    print(f"  K loop ({D // 64} tiles):", q(t[:, 2] - t[:, 1]), f" {np.median(t[:, 2] - t[:, 1]) / (D // 64):.0f} cycles per K tile (MFMA issue 1920)")
+    print("  q/k/v -> LDS images :", q(t[:, 3] - t[:, 2]))
+    print("  attention + stores  :", q(t[:, 4] - t[:, 3]))
+    print("  lifetime            :", q(t[:, 4] - t[:, 0]))
+
+
 def _step_inputs(B=256, arch="ViT-B/32"):
     cfg = get_config(arch)
     sd = W.synthetic_state_dict(cfg, 0)
@@ -878,5 +936,5 @@ def sec_e2e():
 if __name__ == "__main__":
     t0 = time.time()
     {"gemm": sec_gemm, "attn": sec_attn, "tiny": sec_tiny, "vitb32": sec_vitb32, "gemmbench": sec_gemmbench, "lnbench": sec_lnbench, "latency": sec_latency, "libgemm": sec_libgemm, "tiles": sec_tiles, "parity": sec_parity, "sustain": sec_sustain, "power": sec_power, "cold": sec_cold, "towerswap": sec_towerswap, "e2e": sec_e2e, "gemmone": sec_gemmone, "policy": sec_policy, "ldpad": sec_ldpad, "gemmtrace": sec_gemmtrace,
-     "overlap": sec_overlap, "stepab": sec_stepab, "cumask": sec_cumask, "mixed": sec_mixed, "zeroshot": sec_zeroshot, "latprof": sec_latprof}[sys.argv[1]]()
+     "overlap": sec_overlap, "qkvattn": sec_qkvattn, "stepab": sec_stepab, "cumask": sec_cumask, "mixed": sec_mixed, "zeroshot": sec_zeroshot, "latprof": sec_latprof}[sys.argv[1]]()
     print(f"[{sys.argv[1]} done in {time.time() - t0:.1f} s]")
