@@ -510,10 +510,10 @@ def sec_qkvattn():
         gemm_nt_ln(0, a[i], w, c2, st[i], variant=-1, out=qkvs[i])
         return attention(qkvs[i], B, S, H, True, mask, impl=1)
 
-    def one(cold):
+    def one(cold, mode=1):
         i = state["i"] % nb if cold else 0
         state["i"] += 1
-        return qkv_attention(a[i], w, c2, st[i], B, S, H, True, mask)
+        return qkv_attention(a[i], w, c2, st[i], B, S, H, mode, mask)
 
     assert torch.equal(one(False), two(False))
     for cold in (False, True):
