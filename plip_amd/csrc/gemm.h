@@ -297,10 +297,13 @@ template <typename T, int BM, int BN, int WM, int WN, int EPI, int SCHED = 0, in
 __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void gemm_nt_kernel(const GemmParams p) {
   constexpr int NT = WM * WN * 64;
-  // SCHED 9 (16x16x32 streamed form): wave rows are dealt in 16-ROW blocks -- BM / WM rows each, a multiple of 16 but not
-  // necessarily of 32 (160x128 on 2x2 waves: 80 rows = five 16-row MFMA tiles per wave row, all wave rows equal).  The
-  // epilogues still walk 32-row slabs; a wave row's last slab may then be a half slab (kHalf paths below).
-  constexpr bool kHalf = SCHED == 9;
+  // SCHED 7 / 9 (16x16x32 forms: ring of three / streamed two-stage): wave rows are dealt in 16-ROW blocks -- BM / WM rows each, a
+  // multiple of 16 but not necessarily of 32 (160 rows on two wave rows: 80 rows = five 16-row MFMA tiles per wave row, all wave
+  // rows equal).  The epilogues still walk 32-row slabs; a wave row's last slab may then be a half slab (kHalf paths below).
+  // Round 5: the ring tile used to deal 32-row blocks 3 + 2 (96 x 64 and 64 x 64 wave tiles; the short waves read a block nobody
+  // multiplied and waited at every barrier); 80 x 64 everywhere: 1876 -> 1825 cycles per K tile on fc2, 9 fragment reads per 20
+  // MFMAs instead of 10 per 20, cold-operand launches -6 ... -12 %, the step -0.4 % / -0.9 % (profiles/r05_ring_even_dealing.txt).
+  constexpr bool kHalf = SCHED == 9 || SCHED == 7;
   constexpr int RB = BM / 32;                  // 32-row blocks of the tile
   constexpr int MI = kHalf ? (BM / WM + 31) / 32 : (RB + WM - 1) / WM;   // ... per wave row (the last one may hold fewer)
   constexpr bool kUneven = !kHalf && RB % WM != 0;
