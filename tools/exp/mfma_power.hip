@@ -135,6 +135,19 @@ void run(const char* name, const u32x4* src, float* out, unsigned long long* clk
   // priced both modes at 8 x 32768 and every 16x16x32 figure printed was half the truth.)
   const double per_iter = MODE == 0 ? 8 * 32768.0 : 32 * 16384.0;
   const double fl = (double)blocks * (4 * W) * (double)iters * per_iter;
+  // Two sanity checks so that a mis-scaled probe cannot steer a round again:
+  //  (1) the FLOP count is instructions x shape: FLOP per MFMA = 2 M N K, and the issue-share column below prices the same
+  //      instruction count in pipe cycles (32 per 32x32x16, 16 per 16x16x32) -- the two must describe the same number of MFMAs;
+  //  (2) bare MFMAs on ZERO operands run at the quoted peak (no data-dependent power): below 2.3 PFLOP/s the accounting, not the
+  //      chip, is wrong.
+  const double n_mfma = (double)iters * (MODE == 0 ? 8.0 : 32.0);
+  const double flop_per_mfma = MODE == 0 ? 2.0 * 32 * 32 * 16 : 2.0 * 16 * 16 * 32;
+  if (per_iter * iters != n_mfma * flop_per_mfma) { printf("PROBE ERROR: FLOP count != instructions x shape (%s)\n", name); exit(2); }
+  if (zero && LDS == 0 && W == 2 && fl / (best * 1e-3) / 1e12 < 2300.0) {
+    printf("PROBE ERROR: %s on zero operands gives %.0f TFLOP/s, below 2300: the probe's accounting (or the box) is off\n", name,
+           fl / (best * 1e-3) / 1e12);
+    exit(3);
+  }
   printf("%-34s %s operands: %8.3f ms (mean %8.3f)  %7.1f TFLOP/s   shader clock %.3f GHz   MFMA issue %.1f %% of cycles\n", name,
          zero ? "ZERO  " : "random", best, sum / reps, fl / (best * 1e-3) / 1e12, cyc / real / 10.0 / 1e0 / 1e0 * 1e-0 / 100.0 * 100.0 / 100.0,
          100.0 * (double)iters * (MODE == 0 ? 8 * 32.0 : 32 * 16.0) * 2 / (cyc / blocks));
