@@ -38,7 +38,8 @@ int plipmi_gemm_variant_built(int dtype, int variant);
 /* TEST / A-B HOOK, process-wide, not used by the product path: force every GEMM onto one tile variant (>= 0), or back
  * to the engine's own choice (-1); 1000 + 100 a + b re-maps the engine's choice a to tile b (A/B runs of the step);
  * 2000 + m sets GemmParams.duo = m (tile 7: issue priority of the workgroup in the CU's first / second LDS slot);
- * 3000 / 3001: the engines run the text tower's q/k/v projection and attention as two kernels / as the fused kernel (default);
+ * 3000 / 3001 / 3002: the engines run the text tower's q/k/v projection and attention as two kernels / as the fused kernel where
+ * it applies and the batch fills the chip (default) / as the fused kernel wherever it applies;
  * -1 clears all of it.  (The library reads no environment variables.) */
 void plipmi_set_gemm_variant(int variant);
 /* Test hook: the residual-stream planes {hi, lo} (n values, n % 4 == 0) from `from_dtype`'s split format to `to_dtype`'s
@@ -74,7 +75,7 @@ int plipmi_gemm_nt_ln(int dtype, int mode, int variant, int M, int N, int K, con
 /* Kernel-level entry for the text tower's fused kernel (csrc/qkv_attention.hip): LayerNorm-folded q/k/v projection (mode 0 of
  * plipmi_gemm_nt_ln with N = 3 * 64 H) with the attention in its epilogue, out [B*S, 64 H] -- bit-identical to
  * plipmi_gemm_nt_ln(mode 0) followed by plipmi_attention(impl 1).  dtype PLIPMI_BF16 | PLIPMI_F16, 65 <= S <= 80, ns = H.
- * (plipmi_set_gemm_variant(3000) makes the ENGINE run the two kernels instead, 3001 / -1 the fused one again.) */
+ * (plipmi_set_gemm_variant(3000) makes the ENGINE run the two kernels instead, 3001 / -1 the product rule, 3002 the fused one at every batch.) */
 int plipmi_qkv_attention(int dtype, const void* A, const void* W, const float* c2, const float* stats, int ns, float eps, void* out,
                          int B, int S, int H, int causal, const int64_t* key_mask,
                          uint64_t* trace /* NULL, or 8 x uint64 per workgroup: {start, prologue done, K loop done, Q/K/V images

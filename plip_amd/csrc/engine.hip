@@ -38,8 +38,9 @@ static constexpr int kLatencyBatch = 0;
 using namespace plipmi;
 
 static thread_local char g_err[512] = "";
-// TEST / A-B hook (plipmi_set_gemm_variant 3000 + on; plipmi_test.h): 0 = the text tower's q/k/v projection and its attention run
-// as two kernels even where the fused kernel (qkv_attention.hip) applies.  The product path never writes it.
+// TEST / A-B hook (plipmi_set_gemm_variant 3000 + mode; plipmi_test.h): 0 = the text tower's q/k/v projection and its attention run
+// as two kernels even where the fused kernel (qkv_attention.hip) applies, 1 = the product rule (fused where it applies AND the batch
+// fills the chip), 2 = fused wherever it applies, small batches too.  The product path never writes it.
 static int g_fuse_qkv_attention = 1;
 
 static int fail(int code, const char* fmt, ...) {
@@ -360,7 +361,8 @@ int run_qkv_attention(plipmi_engine* e, Tower& t, const LayerW& w, int B, int ca
   const int* cu = t.packed ? t.cu : nullptr;
   const int* md = t.packed ? t.mdev : nullptr;
   const double att_flops = 4.0 * B * t.H * (double)t.S * t.S * 64;
-  if (g_fuse_qkv_attention && impl == 1 && !t.packed && !t.small && qkv_attention_supports(t.cur, B, t.S, t.H, D)) {
+  if (g_fuse_qkv_attention && impl == 1 && !t.packed && !t.small && qkv_attention_supports(t.cur, B, t.S, t.H, D) &&
+      (g_fuse_qkv_attention == 2 || qkv_attention_pays(B, t.H, gemm_num_cus()))) {
     Scope sc(e, s, "qkv_attention", 2.0 * M * 3.0 * D * (double)D + att_flops, ((double)M * D * 2 + 3.0 * D * D) * e->esz);
     HIP_TRY(launch_qkv_attention(t.cur, t.h, w.wqkv, w.bqkv, use.stats, use.inv_d, use.eps, t.att, B, t.S, t.H, causal, key_mask, s));
     return PLIPMI_OK;

@@ -110,6 +110,7 @@ hipError_t launch_attention(const void* qkv, void* out, int dtype, int B, int S,
 // biases, stats = the rows' LayerNorm partials [B*S, D/64, 2]; out = attention output [B*S, D], bit-identical to
 // gemm.h EPI_BIAS_LN followed by launch_attention(impl 1).  16-bit dtypes, 65 .. 80 tokens, D = 64 H.
 bool qkv_attention_supports(int dtype, int B, int S, int H, int D);
+bool qkv_attention_pays(int B, int H, int num_cus);   // enough workgroups to fill the chip: below, the two kernels are faster
 hipError_t launch_qkv_attention(int dtype, const void* A, const void* W, const float* c2, const float* stats, float ln_inv_d,
                                 float ln_eps, void* out, int B, int S, int H, int causal, const int64_t* key_mask, hipStream_t s,
                                 unsigned long long* trace = nullptr /* test hook: in-kernel timeline, 8 x u64 per workgroup */);

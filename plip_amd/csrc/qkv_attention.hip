@@ -439,6 +439,12 @@ bool qkv_attention_supports(int dtype, int B, int S, int H, int D) {
          (size_t)B * S * D * 2 < (1ull << 32) && (size_t)3 * D * D * 2 < (1ull << 32);
 }
 
+// Whether the fused kernel is the faster form at this batch: its 4-caption x 1-head workgroups walk K loop, image writes and
+// attention one after the other, alone on their CU -- below ~0.6 workgroups per CU the two-kernel path (many small attention
+// workgroups, 128x128 GEMM tiles) wins (ViT-B/32 text tower, bf16: B = 64: +4.4 %, B = 96: -3.9 %, B = 256: -10.5 % --
+// tools/exp/r05_fuse_small_batches.py, profiles/r05_fused_text_attention.txt).  Same bits either way.
+bool qkv_attention_pays(int B, int H, int num_cus) { return ((B + kCPT - 1) / kCPT) * H * 5 >= num_cus * 3; }
+
 hipError_t launch_qkv_attention(int dtype, const void* A, const void* W, const float* c2, const float* stats, float ln_inv_d,
                                 float ln_eps, void* out, int B, int S, int H, int causal, const int64_t* key_mask, hipStream_t s,
                                 unsigned long long* trace) {

@@ -94,10 +94,11 @@ def test_fused_qkv_attention_matches_the_two_kernels(B, S, H, causal, use_mask, 
 def test_engine_runs_the_fused_text_kernel_and_the_two_kernels_to_the_same_bits(engines):
     """The bf16 engine's text tower (77 tokens) takes the fused kernel; the test hook that splits it back into GEMM + attention
     must not move a single bit of text_embeds, nor of the hidden states."""
-    from plip_amd import _lib
+    from plip_amd import _lib, weights as W
     lib = _lib.load()
     for dtype in ("bf16", "f16"):
-        model, cfg, sd, px, ids, mask = engines("vitb32_b4", dtype)
+        model, cfg, sd, *_ = engines("vitb32_b4", dtype, 256)
+        ids, mask = W.synthetic_ids(cfg, 100, seed=77)
         ids_t, mask_t = torch.from_numpy(ids), torch.from_numpy(mask)
         try:
             lib.plipmi_set_gemm_variant(3000)
@@ -106,14 +107,21 @@ def test_engine_runs_the_fused_text_kernel_and_the_two_kernels_to_the_same_bits(
             lib.plipmi_set_gemm_variant(3001)
             one = model.get_text_features(input_ids=ids_t, attention_mask=mask_t)
             h_one = model.engine.hidden("text", 3, ids_t)
+            lib.plipmi_set_gemm_variant(3002)                       # fused at a batch the product rule leaves to the two kernels
+            small = model.get_text_features(input_ids=ids_t[:6], attention_mask=mask_t[:6])
         finally:
             lib.plipmi_set_gemm_variant(-1)
-        assert torch.equal(one, two) and torch.equal(h_one, h_two)
-        rows = []
-        with model.engine.profile(rows):
-            model.get_text_features(input_ids=ids_t, attention_mask=mask_t)
-        names = {r["name"].split("|")[0] for r in rows}
-        assert "qkv_attention" in names and not any(n.startswith("attention") for n in names), names
+        assert torch.equal(one, two) and torch.equal(h_one, h_two) and torch.equal(small, two[:6])
+
+        def kernels(n):
+            rows = []
+            with model.engine.profile(rows):
+                model.get_text_features(input_ids=ids_t[:n], attention_mask=mask_t[:n])
+            return {r["name"].split("|")[0] for r in rows}
+        big, few = kernels(100), kernels(40)
+        # 100 captions x 8 heads = 200 workgroups: fused; 40 captions = 80 workgroups: the two kernels are the faster form there
+        assert "qkv_attention" in big and not any(n.startswith("attention") for n in big), big
+        assert "qkv_attention" not in few and any(n.startswith("attention") for n in few), few
 
 
 def test_attention_argument_checks():
