@@ -490,7 +490,7 @@ def sec_qkvattn():
     D = H * 64
     g = torch.Generator().manual_seed(0)
     hdt = torch.bfloat16
-    nb = max(2, int(600e6 // (B * S * D * 2 * 5)) + 1)
+    nb = min(8, max(2, int(600e6 // (B * S * D * 2 * 5)) + 1))
     xs = [torch.randn(B * S, D, generator=g) for _ in range(nb)]
     a = [x.to(dev).to(hdt) for x in xs]
     st = []
