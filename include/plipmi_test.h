@@ -40,6 +40,7 @@ int plipmi_gemm_variant_built(int dtype, int variant);
  * 2000 + m sets GemmParams.duo = m (tile 7: issue priority of the workgroup in the CU's first / second LDS slot);
  * 3000 / 3001 / 3002: the engines run the text tower's q/k/v projection and attention as two kernels / as the fused kernel where
  * it applies and the batch fills the chip (default) / as the fused kernel wherever it applies;
+ * 4000 / 4001: fp32 pixels go through the unfold pass + the plain patch GEMM / the patch GEMM gathers them itself where it can (default);
  * -1 clears all of it.  (The library reads no environment variables.) */
 void plipmi_set_gemm_variant(int variant);
 /* Test hook: the residual-stream planes {hi, lo} (n values, n % 4 == 0) from `from_dtype`'s split format to `to_dtype`'s

@@ -42,6 +42,9 @@ static thread_local char g_err[512] = "";
 // as two kernels even where the fused kernel (qkv_attention.hip) applies, 1 = the product rule (fused where it applies AND the batch
 // fills the chip), 2 = fused wherever it applies, small batches too.  The product path never writes it.
 static int g_fuse_qkv_attention = 1;
+// TEST / A-B hook (plipmi_set_gemm_variant 4000 + on): 0 = fp32 pixels always go through the unfold pass + the plain patch GEMM,
+// 1 (default) = the patch GEMM gathers them itself where gemm_gather_supports() says so.
+static int g_patch_gather = 1;
 
 static int fail(int code, const char* fmt, ...) {
   va_list ap;
@@ -461,15 +464,34 @@ int vision_embed(plipmi_engine* e, const float* pixels, const uint8_t* tiles_u8,
   const plipmi_config& g = e->cfg;
   Tower& t = e->vis;
   t.cur = t.planes = t.layer_dtype(0);
-  if (tiles_u8) {
+  // fp32 pixels, 16-bit engine, 16- / 32-pixel patches: the patch GEMM reads the pixels itself (im2col on load -- four pixels per lane
+  // into registers, rounded to the operand type, written to its A stage), no unfold pass and no `patches` round trip.  Same operand
+  // bits as the unfold kernel's, hence the same embedding rows.
+  const bool gather = g_patch_gather && !tiles_u8 && e->half() && !t.small && e->kpad == 3 * g.patch_size * g.patch_size &&
+                      gemm_gather_supports(t.dtype, B, g.image_size, g.patch_size, t.D);
+  if (gather) {
+    { Scope sc(e, s, "cls_rows", 0, (double)B * t.D * 4);
+      HIP_TRY(launch_cls_rows(e->cls, e->vpos, t.x, B, t.S, t.D, s)); }
+    GemmParams p;
+    p.A = nullptr; p.W = e->patch_w; p.C = t.x; p.bias = e->vpos;
+    p.M = B * e->np; p.N = t.D; p.K = e->kpad; p.lda = e->kpad; p.ldw = e->kpad; p.ldc = t.D; p.alpha = 1.f; p.np = e->np;
+    p.pix = pixels; p.img_hw = g.image_size; p.patch_log2 = g.patch_size == 32 ? 5 : 4;
+    const char* name = "gemm_nt";
+    Scope sc(e, s, name, 2.0 * p.M * p.N * (double)p.K, (double)B * 3 * g.image_size * g.image_size * 4 + (double)p.N * p.K * e->esz + (double)p.M * p.N * 4);
+    const int rc = gemm_launch_gather(t.dtype, p, s, &name);
+    if (e->prof) sc.rename(name_with_role(name, "patch_embed"));
+    if (rc != 0) return fail(PLIPMI_ERR_HIP, "patch GEMM (im2col on load) failed: %s", hipGetErrorString((hipError_t)rc));
+  } else if (tiles_u8) {
     Scope sc(e, s, "unfold_patches_u8", 0, (double)B * 3 * g.image_size * g.image_size + (double)B * e->np * e->kpad * e->esz);
     HIP_TRY(launch_unfold_patches_u8(tiles_u8, e->patches, t.dtype, B, g.image_size, g.patch_size, e->kpad, s));
   } else {
     Scope sc(e, s, "unfold_patches", 0, (double)B * 3 * g.image_size * g.image_size * 4 + (double)B * e->np * e->kpad * e->esz);
     HIP_TRY(launch_unfold_patches(pixels, e->patches, t.dtype, B, g.image_size, g.patch_size, e->kpad, s)); }
+  if (!gather) {
   { Scope sc(e, s, "cls_rows", 0, (double)B * t.D * 4);
     HIP_TRY(launch_cls_rows(e->cls, e->vpos, t.x, B, t.S, t.D, s)); }
   RUN(run_gemm(e, t, EPI_PATCH, e->patches, e->patch_w, t.x, e->vpos, B * e->np, t.D, e->kpad, t.D, e->np, s, "patch_embed"));
+  }
   if (e->ln_fold) {   // the tower's one LayerNorm pass: fp32 embedding rows in, the split residual stream + row statistics out
     Scope sc(e, s, "layernorm", 0, (double)B * t.S * t.D * 8.2);
     HIP_TRY(launch_layernorm_emit(t.x, e->pre_w, e->pre_b, t.h, t.lo, t.st, B * t.S, t.D, g.layer_norm_eps, t.dtype, s));
@@ -996,8 +1018,9 @@ int plipmi_gemm_nt_ld(int dtype, int epilogue, int variant, int M, int N, int K,
 }
 
 void plipmi_set_gemm_variant(int variant) {
+  if (variant >= 4000 && variant < 5000) { g_patch_gather = variant - 4000; return; }
   if (variant >= 3000 && variant < 4000) { g_fuse_qkv_attention = variant - 3000; return; }
-  if (variant == -1) g_fuse_qkv_attention = 1;
+  if (variant == -1) { g_fuse_qkv_attention = 1; g_patch_gather = 1; }
   gemm_set_default_override(variant);
 }
 int plipmi_qkv_attention(int dtype, const void* A, const void* W, const float* c2, const float* stats, int ns, float eps, void* out,

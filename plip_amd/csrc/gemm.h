@@ -88,6 +88,12 @@ struct GemmParams {
   // of a mixed text tower (plipmi_config.text_f16_layers) hands the stream to the bf16 blocks without a re-coding pass.
   // Exact: both formats hold the fp32 value bit for bit (|x| < 65504), common.h split_f32.
   int planes_other = 0;
+  // ADDR 2 (the patch GEMM, im2col ON LOAD; modeling_clip.py:148-154,209-210): A is not read as [M, K] rows -- row m = patch (img, gi, gj)
+  // and column k = (c, u, v) are GATHERED from the fp32 NCHW pixels while a K tile is staged: four consecutive pixels of one image row
+  // per lane into registers, rounded to the operand type, written to the A stage (LDS-DMA copies bytes, it cannot convert: this is the
+  // register-staged converting A path).  pix = the pixels, img_hw = image side, patch_log2 = log2 of the patch side (4 or 5).
+  const float* pix = nullptr;
+  int img_hw = 0, patch_log2 = 0;
   // Row count known only on the device (packed captions, kernels.h launch_text_pack): when set, the kernel processes
   // min(*m_dev, M) rows -- M then only sizes the grid; workgroups whose tile starts past the live rows exit at once
   const int* m_dev = nullptr;
@@ -254,6 +260,19 @@ struct EpilogueOp {
   }
 };
 
+// ADDR 2 helpers (im2col on load): a 16-byte pixel load into registers that hipcc does not count, and the wait that hands the
+// registers back to it -- they pass THROUGH the wait statement, so no use of them is scheduled above it (cdna_hip_programming.md
+// 5.7 item 1, VGPR destinations, form ii).  s_nop 4: the scalar offset may come straight from SALU arithmetic.
+__device__ __forceinline__ void pix_load16(u32x4& dst, unsigned voff, const i32x4 rsrc, unsigned soff) {
+  asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+// (the count is chosen by a wave-uniform branch around OPERAND-FREE wait statements; the registers then pass through ONE
+//  unconditional empty statement behind them -- a register-tied statement on each side of a branch makes hipcc merge the two
+//  register sets with v_mov copies in FRONT of the waits, i.e. it reads the destinations before the data has landed)
+__device__ __forceinline__ void tie_regs5(u32x4& a, u32x4& b, u32x4& c, u32x4& d, u32x4& e) {
+  asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e) : : "memory");
+}
+
 // BM x BN block tile, WM x WN waves.  A wave owns (BN / WN) columns and a run of the tile's rows.  32x32 MFMA forms (fp32
 // engine, SCHED 0 .. 6): BM / 32 blocks are dealt to the WM wave rows MI = ceil(BM / 32 / WM) at a time, so the LAST wave row may
 // hold fewer (160 x 256 on 2 x 4 waves: 3 + 2 blocks; waves w and w + 4 of a workgroup share a SIMD -- MI355X_MICROARCH.md, LDS
@@ -321,14 +340,18 @@ void gemm_nt_kernel(const GemmParams p) {
   constexpr bool kM16 = SCHED >= 7;
   static_assert(!kM16 || sizeof(T) == 2, "the 16x16x32 form: 16-bit operands");
   static_assert(!kM16 || NSTAGE == (SCHED == 7 ? 3 : 2), "schedule 7 runs on the ring, 8 on two stages");
-  static_assert(!kSpread || ADDR == 1, "the spread fill batches buffer-form requests");
+  static_assert(!kSpread || ADDR >= 1, "the spread fill batches buffer-form requests");
+  constexpr bool kGather = ADDR == 2;      // A gathered from fp32 pixels through registers (W: buffer-form LDS-DMA as ADDR 1)
+  static_assert(!kGather || (SCHED == 7 && EPI == EPI_PATCH), "im2col on load: the ring tile's patch epilogue only");
   constexpr int BK = 8 * ELEMS16;          // 128-byte rows
   constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, STAGE = A_BYTES + W_BYTES;
   static_assert(NSTAGE * STAGE + (epi_is_ln(EPI) ? BM * 4 : 0) <= 160 * 1024, "LDS stages exceed the CU's 160 KB");
   // 16-byte chunks per thread per tile.  A piece = one wave instruction = 8 rows; when BM * 8 is not a multiple of the
   // thread count the last A piece exists for the first waves only (wave-uniform test a_piece(i))
-  constexpr int PA = (BM * 8 + NT - 1) / NT, PW = BN * 8 / NT;
-  constexpr int PA_MIN = BM * 8 / NT;      // pieces every wave issues (counted vmcnt of the three-stage ring)
+  constexpr int PA = kGather ? 0 : (BM * 8 + NT - 1) / NT, PW = BN * 8 / NT;   // (gathered A: no A pieces in the LDS-DMA fill)
+  constexpr int PA_MIN = kGather ? 0 : BM * 8 / NT;      // pieces every wave issues (counted vmcnt of the three-stage ring)
+  constexpr int NAL = BM * 16 / NT;        // kGather: 16-byte pixel loads (4 fp32) per thread and K tile
+  static_assert(!kGather || (BM * 16) % NT == 0, "gathered A: whole passes of four-pixel loads");
   static_assert(BM % 32 == 0 && TN % 32 == 0, "wave tile must be a multiple of the 32x32 MFMA tile");
   static_assert((BM * 8) % 64 == 0 && (BN * 8) % NT == 0, "staging passes must be whole wave pieces");
   static_assert((NT / 8) % 16 == 0, "swizzle term must not depend on the staging pass");
@@ -367,7 +390,7 @@ void gemm_nt_kernel(const GemmParams p) {
   // K chunk that belongs in that slot is slot ^ ((row>>1)&7) (pass-independent).
   const int srow = tid >> 3;
   const int schunk = (tid & 7) ^ ((srow >> 1) & 7);
-  const char* a_src[PA];
+  const char* a_src[PA ? PA : 1];
   const char* w_src[PW];
 #pragma unroll
   for (int i = 0; i < PA; ++i) {
@@ -383,8 +406,8 @@ void gemm_nt_kernel(const GemmParams p) {
   const unsigned lds0 =
       __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem);
   i32x4 rs_a, rs_w;
-  unsigned a_off[PA], w_off[PW];
-  if constexpr (ADDR == 1) {
+  unsigned a_off[PA ? PA : 1], w_off[PW];
+  if constexpr (ADDR >= 1) {
     rs_a = make_buffer_rsrc(p.A);
     rs_w = make_buffer_rsrc(p.W);
 #pragma unroll
@@ -395,13 +418,13 @@ void gemm_nt_kernel(const GemmParams p) {
   unsigned koff = 0;  // ADDR 1: K byte offset of the tile being fetched (SGPR); advanced when its last piece is out
   auto dma_a = [&](int i, unsigned lds) {
     if (!a_piece(i)) return;
-    if constexpr (ADDR == 1) glds16_buf(rs_a, a_off[i], koff, lds);
+    if constexpr (ADDR >= 1) glds16_buf(rs_a, a_off[i], koff, lds);
     else { glds16(a_src[i], lds); a_src[i] += 128; }
   };
   auto dma_w = [&](int i, unsigned lds) {
-    if constexpr (ADDR == 1) glds16_buf(rs_w, w_off[i], koff, lds);
+    if constexpr (ADDR >= 1) glds16_buf(rs_w, w_off[i], koff, lds);
     else { glds16(w_src[i], lds); w_src[i] += 128; }
-    if constexpr (ADDR == 1) { if (i == PW - 1) koff += 128; }  // W pieces follow the A pieces: PW-1 is a tile's last
+    if constexpr (ADDR >= 1) { if (i == PW - 1) koff += 128; }  // W pieces follow the A pieces: PW-1 is a tile's last
   };
 
   auto stage_issue = [&](int buf) {  // the whole tile at once; reads a_src/w_src (koff), then advances them by one K tile
@@ -418,7 +441,7 @@ void gemm_nt_kernel(const GemmParams p) {
     const unsigned base = lds0 + buf * STAGE + wave * 1024;
     if constexpr (kM16) {
       return;   // the hand-placed schedules issue through fill_part_placed below
-    } else if constexpr (ADDR == 1 && PA == PA_MIN) {
+    } else if constexpr (ADDR >= 1 && PA == PA_MIN) {
       constexpr int PER = (PA + PW + kFillParts - 1) / kFillParts;
       // piece idx of the tile: resource, lane offset and (compile-time) LDS offset
       auto RS = [&](int idx) -> const i32x4& { return idx < PA ? rs_a : rs_w; };
@@ -439,7 +462,7 @@ void gemm_nt_kernel(const GemmParams p) {
       else if (part == 1) go(std::integral_constant<int, 1>{});
       else if (part == 2) go(std::integral_constant<int, 2>{});
       return;
-    } else if constexpr (ADDR == 1) {
+    } else if constexpr (ADDR >= 1) {
       // partial last A pass: part 0 = this wave's A pieces (2 or 3 single requests), the W pieces split over the other parts
       static_assert(PW % 2 == 0 && PW <= 8, "W pieces are batched in two halves");
       constexpr int HW = PW / 2;
@@ -468,12 +491,12 @@ void gemm_nt_kernel(const GemmParams p) {
   // statement of up to four requests (A pieces that not every wave owns go singly behind their wave-uniform test).
   constexpr int kParts = kFillParts;
   constexpr int PER = (PA + PW + kParts - 1) / kParts;
-  static_assert(!kM16 || ADDR == 1, "hand-placed schedules use the buffer-form LDS-DMA");
+  static_assert(!kM16 || ADDR >= 1, "hand-placed schedules use the buffer-form LDS-DMA");
   auto piece_lds = [](int idx) constexpr { return idx < PA ? idx * NT * 16 : A_BYTES + (idx - PA) * NT * 16; };
   auto fill_batched = [&](int buf, auto part_c) __attribute__((always_inline)) {
     constexpr int part = decltype(part_c)::value;
     constexpr int P0 = part * PER, P1 = (P0 + PER < PA + PW) ? P0 + PER : PA + PW;
-    if constexpr (ADDR == 1 && P0 < P1) {
+    if constexpr (ADDR >= 1 && P0 < P1) {
       const unsigned base = lds0 + buf * STAGE + wave * 1024;
       constexpr int G0 = PA_MIN, G1 = PA;   // [G0, G1): A pieces only the first waves own
 #pragma unroll
@@ -503,6 +526,67 @@ void gemm_nt_kernel(const GemmParams p) {
     if (part == 0) fill_batched(buf, std::integral_constant<int, 0>{});
     else if (part == 1) fill_batched(buf, std::integral_constant<int, 1>{});
     else if (part == 2) fill_batched(buf, std::integral_constant<int, 2>{});
+  };
+
+  // ---- ADDR 2: the A tile gathered from fp32 pixels (im2col on load) ------------------------------------------------
+  // A K tile of 64 columns = 64 / P patch rows u of one channel c (P = 32: two rows, P = 16: four), 64 consecutive k = (c, u, v).
+  // Thread -> load q = pass * NT + tid: tile row q >> 4, four-pixel group q & 15 of the row's 64 columns.  The per-lane byte offset
+  // into the pixels never changes inside the K loop; the tile's (c, u0) is a wave-uniform scalar offset.  Two register sets: the
+  // loads of tile kt+2 travel while tile kt+1's values are converted and written to its LDS stage (K loop unrolled by two, so
+  // the sets are compile-time).
+  i32x4 rs_p;
+  unsigned pix_off[kGather ? NAL : 1];
+  int ga_dst[kGather ? NAL : 1];
+  u32x4 ga[2][kGather ? NAL : 1];
+  if constexpr (kGather) {
+    rs_p = make_buffer_rsrc(p.pix);
+    const int P = 1 << p.patch_log2, g = p.img_hw >> p.patch_log2, f4_per_row = P >> 2;   // patch side, patches per image side
+#pragma unroll
+    for (int i = 0; i < NAL; ++i) {
+      const int q = i * NT + tid, row = q >> 4, f4 = q & 15;
+      int r = m0 + row;
+      r = r < Mrt ? r : Mrt - 1;
+      const int img = r / p.np, pp = r - img * p.np, gi = pp / g, gj = pp - gi * g;
+      const int j = f4 / f4_per_row, gq = f4 - j * f4_per_row;        // patch row inside the K tile, four-pixel group inside it
+      pix_off[i] = (unsigned)((((size_t)img * 3 * p.img_hw + gi * P + j) * p.img_hw + gj * P + gq * 4) * 4);
+      const int kl = j * P + gq * 4;                                   // column inside the K tile: 16-byte chunk kl >> 3, half (kl >> 2) & 1
+      ga_dst[i] = row * 128 + ((((kl >> 3) ^ ((row >> 1) & 7))) << 4) + ((kl >> 2) & 1) * 8;
+    }
+  }
+  // scalar byte offset of K tile t inside an image: channel c = t / (P * P / 64), first patch row u0 = (t % (P * P / 64)) * (64 / P)
+  auto gather_soff = [&](int t) __attribute__((always_inline)) -> unsigned {
+    const int tpc_log2 = 2 * p.patch_log2 - 6;
+    const int c = t >> tpc_log2, u0 = (t & ((1 << tpc_log2) - 1)) << (6 - p.patch_log2);
+    return (unsigned)((c * p.img_hw + u0) * p.img_hw * 4);
+  };
+  constexpr int NALX = kGather ? NAL : 1;
+  auto gather_load = [&](u32x4 (&set)[NALX], int t) __attribute__((always_inline)) {
+    if constexpr (kGather) {
+      const unsigned soff = gather_soff(t);
+#pragma unroll
+      for (int i = 0; i < NAL; ++i) pix_load16(set[i], pix_off[i], rs_p, soff);
+    }
+  };
+  // (leave: how many of this wave's vector-memory requests may still be outstanding -- one tile's, or none)
+  auto gather_wait = [&](u32x4 (&set)[NALX], bool one_tile) __attribute__((always_inline)) {
+    if constexpr (kGather) {
+      static_assert(NAL == 5, "the wait statement names five register sets");
+      if (one_tile) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NAL + PW) : "memory");
+      else wait_vm0();
+      tie_regs5(set[0], set[1], set[2], set[3], set[4]);
+    }
+  };
+  auto gather_store = [&](u32x4 (&set)[NALX], int stage) __attribute__((always_inline)) {   // fp32 -> operand type (the unfold kernel's rounding), into the A stage
+    if constexpr (kGather && sizeof(T) == 2) {
+      using Th = std::conditional_t<sizeof(T) == 2, T, bf16_t>;
+      using X4h = typename half_traits<Th>::x4;
+#pragma unroll
+      for (int i = 0; i < NAL; ++i) {
+        const f32x4 v = __builtin_bit_cast(f32x4, set[i]);
+        const X4h pk = {from_f32<Th>(v[0]), from_f32<Th>(v[1]), from_f32<Th>(v[2]), from_f32<Th>(v[3])};
+        *reinterpret_cast<X4h*>(smem + stage * STAGE + ga_dst[i]) = pk;
+      }
+    }
   };
 
   // ---- fragment read offsets (lane-constant) -----------------------------------
@@ -771,15 +855,58 @@ void gemm_nt_kernel(const GemmParams p) {
         for (int j = 0; j < NI; ++j) mma16<T>(acc[i][j], wf[b][j], xf[b][i]);
       }
     };
+    if constexpr (kGather) {
+      // tile 0 -> set 0 / stage 0, tile 1 -> set 1 / stage 1; tile 0's pixels are rounded and written before the first barrier
+      gather_load(ga[0], 0);
+      stage_issue(0);
+      if (KT > 1) { gather_load(ga[1], 1); stage_issue(1); }
+      gather_wait(ga[0], KT > 1);
+      gather_store(ga[0], 0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    } else {
     stage_issue(0);
     if (KT > 1) stage_issue(1);
     stage_ln_rows();
     if (KT > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kLeave) : "memory");  // tile 0 landed, tile 1 may be in flight
     else wait_vm0();
+    }
     __syncthreads();
     if (trace && tid == 0) trace[1] = __builtin_amdgcn_s_memtime();
     int cur = 0, nxt = 1, nxt2 = 2;  // stages of tiles kt, kt+1, kt+2
-    if constexpr (kM16) {
+    if constexpr (kM16 && kGather) {
+      // (this branch replaces the prologue above: see the `if constexpr (!kGather)` around it)
+      using C0 = std::integral_constant<int, 0>; using C1 = std::integral_constant<int, 1>;
+      // iteration kt (tile kt in stage cur, set S = kt & 1 free: tile kt's values were written to LDS an iteration ago)
+      auto iter = [&](auto s_c, int kt) __attribute__((always_inline)) {
+        constexpr int S = decltype(s_c)::value;
+        const int fb = kt + 2 < KT ? nxt2 : -1;
+        if (fb >= 0) gather_load(ga[S], kt + 2);
+        const char* sc = smem + cur * STAGE;
+        step16_full(0, sc, 1, fb, kParts);            // W pieces of tile kt+2 ride in this step
+        // tile kt+1: its pixels (set S ^ 1) and this wave's W pieces have arrived -- only tile kt+2's requests may be outstanding;
+        // round and write its A rows, publish, then the last step's MFMAs with the next tile's first fragment reads
+        gather_wait(ga[S ^ 1], fb >= 0);
+        gather_store(ga[S ^ 1], nxt);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+        step16_full(1, smem + nxt * STAGE, 0, -1, 0);
+        cur = nxt; nxt = nxt2; nxt2 = 3 - cur - nxt;
+      };
+      read16_all(smem, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      int kt = 0;
+      for (; kt + 1 < KT - 1; kt += 2) { iter(C0{}, kt); iter(C1{}, kt + 1); }
+      if (kt < KT - 1) iter(C0{}, kt);
+      if constexpr (kRowOperand) {
+        load_block(0, add[0]);
+        add_ready = true;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      const char* sc = smem + cur * STAGE;
+      step16_full(0, sc, 1, -1, 0);
+      step16_full(1, sc, -1, -1, 0);
+    } else if constexpr (kM16) {
       read16_all(smem, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
       for (int kt = 0; kt < KT - 1; ++kt) {
@@ -1204,5 +1331,8 @@ bool gemm_variant_is_built(int dtype, int variant);
 bool gemm_skinny_supports(int epi, int M, int N, int K);
 int gemm_launch_skinny(int dtype, int epi, const GemmParams& p, hipStream_t stream, const char** kernel_name);
 void gemm_set_default_override(int variant);  // tests / A-B runs (process-wide hook, not a product knob)
+// the patch GEMM with its A operand gathered from fp32 pixels while it is staged (ADDR 2: im2col on load, no unfold pass)
+bool gemm_gather_supports(int dtype, int B, int image, int patch, int N);
+int gemm_launch_gather(int dtype, const GemmParams& p, hipStream_t stream, const char** kernel_name);
 
 }  // namespace plipmi

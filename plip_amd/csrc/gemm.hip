@@ -143,4 +143,25 @@ int gemm_launch(int dtype, int epi, int variant, const GemmParams& p, hipStream_
   return fn(pr, stream);
 }
 
+// The patch GEMM with im2col on load (gemm.h ADDR 2): C rows = patches, A gathered from the fp32 NCHW pixels.  Applies to 16-bit
+// engines, patch sides 16 / 32 (whole 64-column K tiles of 4 / 2 patch rows), widths of whole 256-column tiles, and batches the cost
+// model gives the ring tile anyway; everything else keeps the unfold pass + the plain patch GEMM.
+bool gemm_gather_supports(int dtype, int B, int image, int patch, int N) {
+  if (dtype != 1 && dtype != 2) return false;
+  if (patch != 16 && patch != 32) return false;
+  if (image % patch || N % 256) return false;
+  const int g = image / patch, M = B * g * g, K = 3 * patch * patch;
+  if (K / 64 < 2 || (size_t)B * 3 * image * image * 4 >= (1ull << 32)) return false;
+  return gemm_default_variant(dtype, M, N, K) == 6;
+}
+int gemm_launch_gather(int dtype, const GemmParams& p, hipStream_t stream, const char** kernel_name) {
+  if (p.M <= 0) return 0;
+  if (!p.pix || (dtype != 1 && dtype != 2) || p.N % 256 || p.K % 64 || p.K / 64 < 2) return (int)hipErrorInvalidValue;
+  GemmParams pr = p;
+  pr.gw = 0;    // N-major sweep: the three or four column tiles of a row panel read the same pixels back to back
+  if (kernel_name) *kernel_name = dtype == 1 ? "gemm_nt<bf16,160x256_w2x4_ring3,patch_gather>" : "gemm_nt<f16,160x256_w2x4_ring3,patch_gather>";
+  GemmLaunchFn fn = dtype == 1 ? gemm_get_gather_bf16() : gemm_get_gather_f16();
+  return fn(pr, stream);
+}
+
 }  // namespace plipmi

@@ -29,6 +29,11 @@ int launch_tiled(const GemmParams& p, hipStream_t stream) {
 
 int gemm_num_cus();  // gemm.hip
 
+// The patch GEMM with im2col on load (gemm.h ADDR 2): the ring tile's EPI_PATCH kernel whose A operand is gathered from the fp32
+// pixels (GemmParams.pix); 16-bit types only.
+GemmLaunchFn gemm_get_gather_bf16();
+GemmLaunchFn gemm_get_gather_f16();
+
 template <typename T, int EPI>
 int launch_naive(const GemmParams& p, hipStream_t stream) {
   dim3 grid((p.N / 4 + 63) / 64, p.M);

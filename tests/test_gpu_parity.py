@@ -392,3 +392,44 @@ def _profile(model, tpx):
     with model.engine.profile(rows):
         model.get_image_features(pixel_values=tpx)
     return rows
+
+
+@pytest.mark.parametrize("arch,B", [("ViT-B/32", 256), ("ViT-B/16", 64), ("ViT-B/32", 230)])
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_patch_gemm_im2col_on_load_is_bit_identical(arch, B, dtype):
+    """Round 5: where the ring tile runs the patch GEMM (16-bit engines, 16- / 32-pixel patches, bs ~ 200 and more) it gathers its A
+    operand from the fp32 pixels while staging it (gemm.h ADDR 2: four pixels per lane into registers, rounded, written to LDS) --
+    no unfold pass, no `patches` round trip.  The operand bits are the unfold kernel's, so the embedding rows (after pre_layrnorm:
+    hidden state 0) and the image features must be the SAME BITS with the path on and off; and the step must really take it."""
+    from plip_amd import _lib, weights as W
+    from plip_amd.config import get_config
+    from plip_amd.model import PlipModel
+    lib = _lib.load()
+    cfg = get_config(arch)
+    model = PlipModel(cfg, W.synthetic_state_dict(cfg, 5), dtype=dtype, max_batch=B)
+    px = torch.from_numpy(W.synthetic_pixels(cfg, B, seed=77))
+    px[3] *= 40.0                                             # large pixels in one image: the rounding of big values is the unfold kernel's too
+    try:
+        lib.plipmi_set_gemm_variant(4000)
+        h0 = model.engine.hidden("vision", 0, px)
+        f0 = model.get_image_features(pixel_values=px)
+        rows0 = []
+        with model.engine.profile(rows0):
+            model.get_image_features(pixel_values=px)
+        lib.plipmi_set_gemm_variant(4001)
+        h1 = model.engine.hidden("vision", 0, px)
+        f1 = model.get_image_features(pixel_values=px)
+        rows1 = []
+        with model.engine.profile(rows1):
+            model.get_image_features(pixel_values=px)
+    finally:
+        lib.plipmi_set_gemm_variant(-1)
+    assert torch.isfinite(h1).all() and torch.equal(h0, h1) and torch.equal(f0, f1)
+    n0 = {r["name"].split("|")[0] for r in rows0}
+    n1 = {r["name"].split("|")[0] for r in rows1}
+    assert "unfold_patches" in n0 and not any("patch_gather" in n for n in n0), n0
+    assert "unfold_patches" not in n1 and any("patch_gather" in n for n in n1), n1
+    # small batches keep the unfold pass (the cost model gives their patch GEMM another tile)
+    small = model.get_image_features(pixel_values=px[:8])
+    assert torch.equal(small, f1[:8])
+    model.engine.close()

@@ -638,6 +638,9 @@ def sec_stepab():
                     if pair.startswith("d"):                  # dN: GemmParams.duo = N (issue priority per LDS slot, variant 7)
                         lib.plipmi_set_gemm_variant(2000 + int(pair[1:]))
                         continue
+                    if pair.startswith("g"):                  # g0 / g1: unfold pass + plain patch GEMM / im2col on load (default)
+                        lib.plipmi_set_gemm_variant(4000 + int(pair[1:]))
+                        continue
                     if pair.startswith("f"):                  # f0 / f1: text q/k/v + attention as two kernels / fused (default)
                         lib.plipmi_set_gemm_variant(3000 + int(pair[1:]))
                         continue
