@@ -472,7 +472,7 @@ def main(argv=None, model_factory=None):
         # The headline engine uses the default; 0 = pure bf16, t_layers = the whole text tower (PLIPMI_FLAG_TEXT_TOWER_F16's engine)
         if args.dtype == "bf16":
             dial = {}
-            for n in sorted({0, 2, 4, cfg.t_layers} - {model.engine.text_f16_layers}):
+            for n in sorted({0, 4, 8, cfg.t_layers} - {model.engine.text_f16_layers}):
                 try:
                     mm = side_engine("bf16", text_f16_layers=n)
                     dtm, _ = timed_steps(lambda: sharded_pair_logits(mm, px, ids, mask, overlap=bool(args.overlap), equal_shards=True),

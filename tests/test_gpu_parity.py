@@ -16,12 +16,13 @@ pytestmark = pytest.mark.gpu
 # ("cos" is the stated bar and is applied to the cosine-similarity logits; single embedding components
 # of the 512-d unit vectors get the same -- a PURE bf16 engine's operand rounding alone, everything else exact, puts
 # text_embeds of the bs=256 fixture at 1.2e-3, tests/test_oracle.py::test_operand_rounding_floor_of_the_text_tower; the default
-# engine runs its first four text blocks on f16 operands (engine.DEFAULT_TEXT_F16_LAYERS) and lands at 7.0e-4 --; the 64-d toy
+# engine runs its first eight text blocks on f16 operands (engine.DEFAULT_TEXT_F16_LAYERS) and lands at 4.2e-4 (round 4, four blocks:
+# 7.0e-4) --; the 64-d toy
 # model has 3x larger components, hence the TINY rows.)
 # f16 engine (11 significand bits against 8): a quarter of the bar.
 TOL = {
     "f32": dict(feat=2e-4, cos=1e-5, emb=1e-5, hidden=5e-4),
-    "bf16": dict(feat=6e-2, cos=1e-3, emb=8.5e-4, hidden=1.5e-1),      # emb: 1.2x the measured 7.0e-4 (round 4: 1.0e-3)
+    "bf16": dict(feat=6e-2, cos=1e-3, emb=6e-4, hidden=1.5e-1),        # emb: VERDICT r4's 6e-4 = 1.4x the measured 4.2e-4 (round 4: 1.0e-3 on 7.0e-4)
     "f16": dict(feat=1.5e-2, cos=2.5e-4, emb=4e-4, hidden=4e-2),
 }
 TINY = {"bf16": dict(feat=6e-2, cos=3e-3, emb=4e-3, hidden=1.5e-1), "f16": dict(feat=1.5e-2, cos=7.5e-4, emb=1e-3, hidden=4e-2)}
@@ -93,7 +94,7 @@ def test_text_tower_f16_flag_bs256(engines, golden):
         mm.engine.close()
 
 
-@pytest.mark.parametrize("n_lead", [4, 12])
+@pytest.mark.parametrize("n_lead", [4, 8, 12])
 def test_leading_text_blocks_on_f16_bs256(n_lead, engines, golden):
     """plipmi_config.text_f16_layers: a bf16 engine whose FIRST n text blocks run on f16 operands (where bf16's operand
     rounding costs text_embeds most: profiles/r04_text_layer_precision.txt).  Image side = the bf16 engine's bit for bit; the
@@ -121,7 +122,9 @@ def test_leading_text_blocks_on_f16_bs256(n_lead, engines, golden):
         print(f"bs=256 bf16 engine, first {n_lead} text blocks on f16: max |cos err| = {errs['mixed'][0]:.2e} (pure bf16 {errs['pure bf16'][0]:.2e}), "
               f"text_embeds {errs['mixed'][1]:.2e} (pure bf16 {errs['pure bf16'][1]:.2e})")
         assert errs["mixed"][0] < errs["pure bf16"][0] and errs["mixed"][1] < errs["pure bf16"][1]
-        assert errs["mixed"][0] < (7e-4 if n_lead < cfg.t_layers else 5e-4) and errs["mixed"][1] < (9e-4 if n_lead < cfg.t_layers else 4e-4)
+        # (cosine, text_embeds) bounds per dial setting; 8 = the engine default: VERDICT r4's "cosine <= 4.7e-4 and text_embeds <= 6e-4"
+        bound = {4: (7e-4, 9e-4), 8: (4.7e-4, 6e-4), cfg.t_layers: (5e-4, 4e-4)}[n_lead]
+        assert errs["mixed"][0] < bound[0] and errs["mixed"][1] < bound[1], (errs, bound)
         if n_lead == cfg.t_layers:
             oh = mh(input_ids=ids, pixel_values=px, attention_mask=mask)
             assert torch.equal(out.text_embeds, oh.text_embeds)
