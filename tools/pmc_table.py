@@ -21,7 +21,7 @@ def short(sym):
     s = pretty(sym, VARIANTS)
     if s != sym:
         return s
-    for key in ("attention_mfma_kernel", "attention_flash_kernel", "attention_valu_kernel", "layernorm_emit_kernel",
+    for key in ("qkv_attention_kernel", "gemm_skinny_kernel", "pool_gather_kernel", "attention_mfma_kernel", "attention_flash_kernel", "attention_valu_kernel", "layernorm_emit_kernel",
                 "layernorm_fixed_kernel", "layernorm_kernel", "text_embed_emit_kernel", "text_embed_kernel", "unfold_kernel",
                 "unfold_u8_kernel", "head_gemm_kernel", "pool_layernorm_kernel", "l2_normalize_kernel", "cls_rows_kernel",
                 "logits_kernel", "row_argmax_kernel"):
