@@ -33,7 +33,7 @@ CASES = [(3, 50, 12, False, False), (4, 77, 8, True, True), (2, 77, 8, True, Fal
 @pytest.mark.parametrize("B,S,H,causal,use_mask", CASES)
 @pytest.mark.parametrize("mode", ["valu_f32", "valu_bf16", "mfma_bf16", "valu_f16", "mfma_f16"])
 def test_attention_kernels(B, S, H, causal, use_mask, mode):
-    from plip_amd.engine import attention
+    from plip_amd.kernel_entries import attention
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(100 * S + H)
     qkv = torch.randn(B * S, 3 * H * 64, generator=g)
@@ -64,7 +64,7 @@ def test_fused_qkv_attention_matches_the_two_kernels(B, S, H, causal, use_mask, 
     """csrc/qkv_attention.hip -- the text tower's LayerNorm-folded q/k/v GEMM with the attention in its epilogue -- against
     the two kernels it replaces (plipmi_gemm_nt_ln mode 0 on the engine's own tile + plipmi_attention impl 1): the SAME
     BITS, for whole and partial caption groups, with and without the tokenizer mask; and against fp64."""
-    from plip_amd.engine import attention, gemm_nt_ln, qkv_attention
+    from plip_amd.kernel_entries import attention, gemm_nt_ln, qkv_attention
     dev = torch.device("cuda:0")
     D = H * 64
     g = torch.Generator().manual_seed(1000 * S + 10 * H + B)
@@ -126,7 +126,7 @@ def test_engine_runs_the_fused_text_kernel_and_the_two_kernels_to_the_same_bits(
 
 def test_attention_argument_checks():
     from plip_amd._lib import PlipmiError
-    from plip_amd.engine import attention
+    from plip_amd.kernel_entries import attention
     qkv = torch.zeros(200, 3 * 64, device="cuda:0", dtype=torch.float32)
     with pytest.raises(PlipmiError):
         attention(qkv, 1, 200, 1, impl=1)            # the MFMA kernels take the 16-bit types only
@@ -140,7 +140,7 @@ def test_attention_argument_checks():
 
 def test_fully_masked_tail_chunks_do_not_disturb_the_running_softmax():
     """Keys 0..9 valid, everything after (two whole chunks) masked: the online softmax must equal the 10-key one."""
-    from plip_amd.engine import attention
+    from plip_amd.kernel_entries import attention
     g = torch.Generator().manual_seed(9)
     S, H = 300, 2
     qkv = torch.randn(S, 3 * H * 64, generator=g).to("cuda:0").to(torch.bfloat16)
@@ -162,7 +162,7 @@ def test_masked_key_rows_contribute_nothing_and_a_non_finite_one_poisons_like_hf
     (a) whatever FINITE values sit in masked key / value rows -- padding rows hold real embeddings, never zeros -- cannot
     reach any query; (b) a NaN in a masked KEY row does reach the queries that would have multiplied it (NaN + -inf = NaN
     -> the row maximum), exactly as in HF; it never appears in the engine, whose masked rows are finite activations."""
-    from plip_amd.engine import attention
+    from plip_amd.kernel_entries import attention
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(S)
     B, n_valid = 2, S // 2

@@ -33,12 +33,12 @@ NVAR = 8
 
 
 def _built(dtype):
-    from plip_amd.engine import gemm_variant_built, gemm_variants
+    from plip_amd.kernel_entries import gemm_variant_built, gemm_variants
     return [v for v in list(range(len(gemm_variants()))) + [-2] if gemm_variant_built(dtype, v)]
 
 
 def test_every_listed_variant_is_built():
-    from plip_amd.engine import gemm_variants
+    from plip_amd.kernel_entries import gemm_variants
     assert len(gemm_variants()) == NVAR
     for dt in (torch.float32, *HALF.values()):
         assert _built(dt) == list(range(NVAR)) + [-2]
@@ -55,7 +55,7 @@ def _half_tol(y, ref):
 @pytest.mark.parametrize("variant", list(range(NVAR)) + [-2])
 @pytest.mark.parametrize("epi", [0, 1, 2, 3])
 def test_gemm_variants(dtype, variant, epi):
-    from plip_amd.engine import gemm_nt, gemm_variant_built
+    from plip_amd.kernel_entries import gemm_nt, gemm_variant_built
     assert gemm_variant_built(dtype, variant)
     dev = torch.device("cuda:0")
     g = torch.Generator(device="cpu").manual_seed(1234 + 10 * epi + variant)
@@ -75,7 +75,7 @@ def test_gemm_variants(dtype, variant, epi):
 
 def test_gemm_matches_naive_checker_bitwise_fp32():
     """fp32 MFMA is an fmaf chain: tiled and naive kernels only differ in summation order."""
-    from plip_amd.engine import gemm_nt
+    from plip_amd.kernel_entries import gemm_nt
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(7)
     a = torch.randn(200, 256, generator=g).to(dev)
@@ -94,7 +94,7 @@ def test_every_tile_sums_k_in_the_same_order(epi, hdt):
     """A row's embedding must not depend on the batch it arrives in (PLIP.coalesce, the embedding caches): small problems run
     on the 128x128 tile (v_mfma 32x32x16), large ones on the 16x16x32 tiles (2, 3, 6, 7) -- so every tile has to produce the
     SAME bits from the same operands, i.e. the two MFMA shapes must sum K in the same order."""
-    from plip_amd.engine import gemm_nt
+    from plip_amd.kernel_entries import gemm_nt
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(77 + epi)
     for (M, N, K) in [(1300, 768, 768), (2100, 512, 2048), (1300, 1536, 512)]:
@@ -110,7 +110,7 @@ def test_every_tile_sums_k_in_the_same_order(epi, hdt):
 
 def test_gemm_rejects_bad_shapes():
     from plip_amd._lib import PlipmiError
-    from plip_amd.engine import gemm_nt
+    from plip_amd.kernel_entries import gemm_nt
     dev = torch.device("cuda:0")
     a = torch.zeros(8, 48, device=dev)
     w = torch.zeros(128, 48, device=dev)
@@ -121,7 +121,7 @@ def test_gemm_rejects_bad_shapes():
 def test_operands_of_four_gib_take_the_64bit_address_kernels():
     """The buffer-DMA kernels carry 32-bit byte offsets; gemm_launch must route a 4 GiB A operand to their
     global-address twins -- rows beyond the 4 GiB mark have to come out right."""
-    from plip_amd.engine import gemm_nt
+    from plip_amd.kernel_entries import gemm_nt
     dev = torch.device("cuda:0")
     M, N, K = (1 << 20) + 37, 256, 2048                       # A = 4 GiB + 148 KiB of bf16
     a = torch.empty(M, K, device=dev, dtype=torch.bfloat16)
@@ -160,7 +160,7 @@ def test_layernorm_folded_consumer_epilogue(variant, mode, hdt):
     -- the centring of W' is what subtracts the row mean -- and rstd recombined from the 64-column partials (Chan),
     against an fp64 product of the same rounded operands and against the textbook LayerNorm -> Linear.
     Rows carry a common offset and one outlier channel, so a naive E[x^2] - mean^2 would lose digits."""
-    from plip_amd.engine import gemm_nt_ln
+    from plip_amd.kernel_entries import gemm_nt_ln
     dev = torch.device("cuda:0")
     g0 = torch.Generator().manual_seed(100 + variant + 10 * mode)
     for (M, N, D) in [(1, 256, 128), (77, 512, 512), (300, 768, 768), (1200, 256, 1024)]:
@@ -203,7 +203,7 @@ def test_layernorm_folded_consumer_epilogue(variant, mode, hdt):
 def test_layernorm_folded_producer_epilogue(variant, hdt):
     """x += A @ W^T + bias in place (fp32), plus the bf16 copy and the per-slice {sum, centred M2} of the updated rows,
     the latter against fp64 statistics of the kernel's OWN fp32 output (so the check is exact to fp32 round-off)."""
-    from plip_amd.engine import gemm_nt_ln
+    from plip_amd.kernel_entries import gemm_nt_ln
     dev = torch.device("cuda:0")
     g0 = torch.Generator().manual_seed(200 + variant)
     for (M, N, K) in [(1, 256, 64), (50, 512, 512), (515, 768, 3072), (1300, 1024, 256)]:
@@ -232,7 +232,7 @@ def test_split_plane_residual_epilogue(variant, hdt):
     GEMM's A operand), lo = the signed remainder of its bit pattern, hi + lo == the fp32 value EXACTLY.  The kernel must
     (a) read the planes back to the very fp32 value, (b) produce the same fp32 result as the plain-array epilogue (mode 2)
     bit for bit, and (c) emit the statistics of the updated rows."""
-    from plip_amd.engine import gemm_nt_ln, join_planes, split_planes
+    from plip_amd.kernel_entries import gemm_nt_ln, join_planes, split_planes
     dev = torch.device("cuda:0")
     g0 = torch.Generator().manual_seed(300 + variant)
     for (M, N, K) in [(1, 256, 64), (50, 512, 512), (515, 768, 3072), (1300, 1024, 256)]:
@@ -270,7 +270,7 @@ def test_split_plane_epilogue_hands_the_stream_to_the_other_operand_type(variant
     """Mode 4 = mode 3 writing the planes in the OTHER 16-bit type's split format: what the last f16 block of a mixed text tower
     (plipmi_config.text_f16_layers) does instead of a re-coding pass.  Must equal mode 3 followed by plipmi_recode_planes bit
     for bit, planes and statistics, and the joined stream must be the same fp32 values."""
-    from plip_amd.engine import gemm_nt_ln, join_planes, recode_planes, split_planes
+    from plip_amd.kernel_entries import gemm_nt_ln, join_planes, recode_planes, split_planes
     dev = torch.device("cuda:0")
     other = torch.float16 if hdt == torch.bfloat16 else torch.bfloat16
     g0 = torch.Generator().manual_seed(400 + variant)
@@ -296,7 +296,7 @@ def test_small_m_split_k_gemm(epi, hdt):
     """gemm_skinny.hip (variant -3): 32 x 64 tile per workgroup, K split over its four waves with a k permutation shared by
     both operands, operands straight from L2 -- against fp64 and, bit for bit across batch sizes, against itself (a row's
     result must not depend on how many other rows the call carries: the pooled last block relies on it)."""
-    from plip_amd.engine import gemm_nt
+    from plip_amd.kernel_entries import gemm_nt
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(31 + epi)
     for (M, N, K) in [(1, 64, 256), (8, 768, 768), (256, 768, 3072), (256, 2048, 512), (333, 512, 2048)]:

@@ -139,7 +139,7 @@ def test_leading_text_blocks_on_f16_bs256(n_lead, engines, golden):
 @pytest.mark.parametrize("to", [torch.bfloat16, torch.float16])
 def test_recode_planes_is_exact(to):
     """plipmi_recode_planes: the residual planes change their CODE (bf16 <-> f16 split), never the fp32 value they hold."""
-    from plip_amd.engine import join_planes, recode_planes, split_planes
+    from plip_amd.kernel_entries import join_planes, recode_planes, split_planes
     dev = torch.device("cuda:0")
     frm = torch.float16 if to == torch.bfloat16 else torch.bfloat16
     g = torch.Generator().manual_seed(3)

@@ -40,6 +40,26 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 2 and lib.plipmi_gemm_variant_name(-1) is None
 
 
+def test_product_modules_do_not_call_the_test_header():
+    """include/plipmi_test.h is for tests/ and tools/: the only module of the package that binds its kernel-level entries is
+    plip_amd/kernel_entries.py (imported by tests and tools, never by the product path); Engine.hidden -- the parity tests'
+    window on the hidden states -- is the one test hook a product class carries."""
+    from plip_amd import _lib
+    pkg = os.path.join(ROOT, "plip_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if not f.endswith(".py") or f in ("kernel_entries.py", "_lib.py"):
+                continue
+            src = open(os.path.join(dirpath, f)).read()
+            assert "kernel_entries" not in src, f
+            for name in _lib.TEST_SYMBOLS:
+                if name == "plipmi_debug_hidden" and f == "engine.py":
+                    continue
+                assert name not in src, (f, name)
+    for f in ("bench.py", "__graft_entry__.py"):
+        assert "kernel_entries" not in open(os.path.join(ROOT, f)).read(), f
+
+
 def test_library_reads_no_environment_variables():
     """Every switch of the library is an argument (plipmi_config.flags, per-handle setters, the test hooks): the shared
     object does not even import getenv."""
@@ -321,7 +341,7 @@ def test_split_plane_host_mirror_is_exact():
     """The bf16 engine stores its fp32 residual stream as a bf16 plane + an int16 remainder plane (csrc/common.h
     split_f32); the host mirror used by the GPU tests must invert exactly and its hi plane must be the nearest bf16."""
     import torch
-    from plip_amd.engine import join_planes, split_planes
+    from plip_amd.kernel_entries import join_planes, split_planes
     g = torch.Generator().manual_seed(5)
     x = torch.randn(200000, generator=g) * torch.exp(torch.randn(200000, generator=g) * 6)
     x[:6] = torch.tensor([0.0, -0.0, 1e-38, -3.0e38, 1.00390625, -1.00390625])      # the last two are exact bf16 ties

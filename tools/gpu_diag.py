@@ -18,7 +18,7 @@ from oracle import clip_oracle as O  # noqa: E402
 from oracle.make_golden import case_inputs  # noqa: E402
 from plip_amd import weights as W  # noqa: E402
 from plip_amd.config import get_config  # noqa: E402
-from plip_amd.engine import gemm_nt, gemm_variants  # noqa: E402
+from plip_amd.kernel_entries import gemm_nt, gemm_variants  # noqa: E402
 from plip_amd.model import PlipModel  # noqa: E402
 
 dev = torch.device("cuda:0")
@@ -106,7 +106,7 @@ def sec_vitb32():
 
 
 def sec_attn():
-    from plip_amd.engine import attention
+    from plip_amd.kernel_entries import attention
     g = torch.Generator().manual_seed(0)
     for (B, S, H, causal) in ((3, 50, 12, False), (3, 77, 8, True), (2, 33, 2, True), (1, 128, 2, False)):
         qkv = torch.randn(B * S, 3 * H * 64, generator=g)
@@ -183,7 +183,7 @@ def sec_gemmbench():
 def sec_lnbench():
     """LayerNorm-folded epilogues vs the plain ones on the bs=256 production shapes (product tiles), plus the LayerNorm
     kernel they replace: what the fold costs inside the GEMMs and what it saves outside."""
-    from plip_amd.engine import gemm_nt_ln
+    from plip_amd.kernel_entries import gemm_nt_ln
     shapes = [("v.qkv", 12800, 2304, 768, 0), ("v.fc1", 12800, 3072, 768, 1), ("v.out", 12800, 768, 768, 2),
               ("v.fc2", 12800, 768, 3072, 2), ("t.qkv", 19712, 1536, 512, 0), ("t.fc1", 19712, 2048, 512, 1),
               ("t.out", 19712, 512, 512, 2), ("t.fc2", 19712, 512, 2048, 2)]
@@ -378,7 +378,7 @@ def sec_towerswap():
 
 def sec_ldpad():
     """Does padding the leading dimension (rows no longer a multiple of 2 KB apart) change the fill rate?"""
-    from plip_amd.engine import gemm_nt_ld
+    from plip_amd.kernel_entries import gemm_nt_ld
     g = torch.Generator().manual_seed(0)
     shapes = [("v.qkv", 12800, 2304, 768, 0), ("v.fc1", 12800, 3072, 768, 1), ("v.fc2", 12800, 768, 3072, 2),
               ("t.fc1", 19712, 2048, 512, 1), ("t.fc2", 19712, 512, 2048, 2), ("v.out", 12800, 768, 768, 2)]
@@ -485,7 +485,7 @@ def sec_qkvattn():
     """The text tower's fused q/k/v + attention kernel on the bs=256 production shape: us per launch against the two kernels it
     replaces (warm, and with the A operand cycling through buffer sets larger than the Infinity Cache), and its in-kernel
     timeline.  usage: gpu_diag.py qkvattn [B S H]"""
-    from plip_amd.engine import attention, gemm_nt_ln, qkv_attention
+    from plip_amd.kernel_entries import attention, gemm_nt_ln, qkv_attention
     B, S, H = (int(x) for x in sys.argv[2:5]) if len(sys.argv) > 4 else (256, 77, 8)
     D = H * 64
     g = torch.Generator().manual_seed(0)
@@ -582,7 +582,7 @@ def sec_tiles():
     in one process.  The vendor library (plain bias epilogue) on the same shapes as the yardstick."""
     import torch.nn.functional as F
     from plip_amd import _lib
-    from plip_amd.engine import gemm_nt_ln, split_planes
+    from plip_amd.kernel_entries import gemm_nt_ln, split_planes
     lib = _lib.load()
     hdt = torch.float16 if (len(sys.argv) > 2 and sys.argv[2] == "f16") else torch.bfloat16
     shapes = [("v.qkv", 12800, 2304, 768, 0), ("v.fc1", 12800, 3072, 768, 1), ("v.out", 12800, 768, 768, 3),
@@ -777,7 +777,7 @@ def sec_cold():
     """The production GEMMs with operands that are NOT resident in the 256 MiB Infinity Cache: every launch takes its A
     operand and its residual planes / output from the next of a ring of buffers (> 600 MB in total), as the engine's
     kernels find them -- written by the previous kernel, read once.  Same launches with ONE buffer set (warm) beside it."""
-    from plip_amd.engine import gemm_nt_ln, split_planes
+    from plip_amd.kernel_entries import gemm_nt_ln, split_planes
     shapes = [("v.qkv", 12800, 2304, 768, 0), ("v.fc1", 12800, 3072, 768, 1), ("v.out", 12800, 768, 768, 3),
               ("v.fc2", 12800, 768, 3072, 3), ("t.fc2", 19712, 512, 2048, 3)]
     variants = [int(x) for x in sys.argv[2:]] or [2, 3, 4, 5, 6]
@@ -835,7 +835,7 @@ def sec_power():
 def sec_sustain():
     """Burst vs sustained: the same GEMM timed over 20 launches after an idle gap, and over ~3000 back-to-back launches
     (~0.2 s of continuous MFMA load) -- does the chip hold its burst clock?"""
-    from plip_amd.engine import gemm_nt_ln, split_planes
+    from plip_amd.kernel_entries import gemm_nt_ln, split_planes
     g = torch.Generator().manual_seed(0)
     for name, M, N, K, mode, variants in (("v.fc2", 12800, 768, 3072, 3, (4, 5)), ("v.fc1", 12800, 3072, 768, 1, (3, 5))):
         a = torch.randn(M, K, generator=g).to(dev).bfloat16()
