@@ -369,6 +369,24 @@ def main(argv=None, model_factory=None):
                          "frac_mfma": round(tf / peak, 4), "frac_hbm": round(gbs / HBM_PEAK_GBS, 4)})
         return sorted(rows, key=lambda x: -x["calls_per_step"] * x["avg_launch_us"])
 
+    # N > 1: the step's ONE collective on its own -- the stacked [1, 2, B, P] all-gather, 20 back-to-back, max over ranks -- so a scaling
+    # curve can be read against it (value(N) = N * B / (t1 + c(N)))
+    collective_us = None
+    if world > 1:
+        from plip_amd.dist import all_gather_rows
+        P = cfg.projection_dim
+        buf = torch.zeros((1, 2, B, P), dtype=torch.float32, device=dev)
+        for _ in range(3):
+            all_gather_rows(buf, None, True)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            all_gather_rows(buf, None, True)
+        dev_sync()
+        tc = torch.tensor([(time.perf_counter() - t0) / 20], dtype=torch.float64, device=dev)
+        dist.all_reduce(tc, op=dist.ReduceOp.MAX)
+        collective_us = round(float(tc.item()) * 1e6, 1)
+
     roofline = roofline_2s = roles = None
     kernels = []
     one_stream_ms = None
@@ -420,6 +438,7 @@ def main(argv=None, model_factory=None):
                                 f"(plipmi_config.text_f16_layers, the engine default)" if getattr(model.engine, "text_f16_layers", 0) else ""),
                    "arch": args.arch, "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
                    "collective": "none" if world == 1 else "RCCL all-gather of [B,512] fp32 image+text embeddings",
+                   "collective_us": collective_us,
                    "streams": 2 if args.overlap else 1, "device": model.engine.device_name},
         "windows": {"ms_per_step": [round(w, 3) for w in win], "median": round(float(np.median(win)), 3), "min": round(min(win), 3),
                     "note": "three back-to-back windows of --steps steps each; `value` / `ms_per_step` are the FIRST (the contract's "

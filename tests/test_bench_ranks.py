@@ -94,7 +94,8 @@ def test_bench_main_on_two_gloo_ranks_prints_one_line_from_rank_zero():
     assert res["metric"] == "image+text pairs embedded/sec at 224px bs=256" and res["unit"] == "pairs/s"
     cfg = res["config"]
     assert cfg["global_batch"] == 512 and cfg["per_gpu_batch"] == 256 and cfg["parallelism"] == "dp2"
-    assert cfg["collective"].startswith("RCCL all-gather")
+    assert cfg["collective"].startswith("RCCL all-gather") and cfg["collective_us"] > 0      # the collective timed on its own, max over ranks
+    assert res["rccl_ranks"] == 2 and len(res["rank_devices"]) == 2 and res["rank_devices"][1].startswith("rank 1:")
     # value = the units ALL ranks processed / the max-over-ranks time of the first window of exactly --steps steps
     assert res["value"] == pytest.approx(512 * 3 / (res["ms_per_step"] * 3e-3), rel=2e-3)
     assert len(res["windows"]["ms_per_step"]) == 3 and res["windows"]["ms_per_step"][0] == pytest.approx(res["ms_per_step"], abs=2e-3)
