@@ -73,6 +73,51 @@ def load_pmc_traffic(kernel_name):
         return None
 
 
+def live_pmc_traffic(kernel_name, timeout=180):
+    """HBM/fabric bytes per launch of `kernel_name` measured ON THIS BOX, now: two `rocprofv3 --kernel-trace --pmc` passes (FETCH_SIZE, then
+    WRITE_SIZE -- one counter per pass, kernel trace only, as MI355X_MICROARCH.md's HBM section prescribes; FETCH_SIZE doubled on gfx950,
+    both in KB) over a 3-step one-stream run of this very script.  None when rocprofv3 is missing or a pass fails: the caller then falls
+    back to the committed, source-stamped profiles/pmc_traffic.json."""
+    import csv
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        from pmc_summary import pretty
+    except ImportError:
+        return None
+    vals = {}
+    try:
+        with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+            for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+                out = os.path.join(tmp, counter)
+                cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "pmc", "--", sys.executable,
+                       os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--overlap", "0", "--no-cpu-baseline",
+                       "--no-profile", "--no-extras"]
+                subprocess.run(cmd, cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp"}, stdout=subprocess.DEVNULL,
+                               stderr=subprocess.DEVNULL, timeout=timeout, check=True)
+                path = next((os.path.join(dp, f) for dp, _, fs in os.walk(out) for f in fs if f.endswith("counter_collection.csv")), None)
+                if path is None:
+                    return None
+                with open(path) as f:
+                    v = [float(r["Counter_Value"]) for r in csv.DictReader(f)
+                         if r["Counter_Name"] == counter and pretty(r["Kernel_Name"]) == kernel_name]
+                if not v:
+                    return None
+                vals[counter] = (sum(v) / len(v), len(v))
+    except (OSError, subprocess.SubprocessError, KeyError, ValueError):
+        return None
+    fetch, write = 2.0 * 1024.0 * vals["FETCH_SIZE"][0], 1024.0 * vals["WRITE_SIZE"][0]
+    return {"bytes_per_launch": round(fetch + write), "fetch_bytes": round(fetch), "write_bytes": round(write),
+            "launches": vals["FETCH_SIZE"][1],
+            "note": "measured in THIS run on this box: rocprofv3 --kernel-trace --pmc FETCH_SIZE (x2 gfx950 correction) and WRITE_SIZE in "
+                    "separate passes over `bench.py --steps 3 --overlap 0`, mean over the kernel's launches"}
+
+
 def usable_cores() -> int:
     """Host cores this process may actually run on: affinity mask, capped by the cgroup CPU quota.
     (os.cpu_count() reports every core of the node; asking torch for 256 threads inside a container
@@ -606,6 +651,18 @@ def main(argv=None, model_factory=None):
             del m32
         except Exception as e:  # pragma: no cover
             res["config1_fp32_image_tower"] = {"error": repr(e)}
+    if extras and res.get("roofline"):
+        # `roofline.traffic` as an OBSERVATION of this box (the committed, source-stamped PMC summary is a claim about another
+        # one): two rocprofv3 --pmc passes over a short one-stream run of this script, now.  The committed figure stays beside it.
+        try:
+            live = live_pmc_traffic(res["roofline"]["kernel"])
+        except Exception:  # pragma: no cover
+            live = None
+        if live:
+            res["roofline"]["traffic_committed_summary"] = res["roofline"].get("traffic")
+            res["roofline"]["traffic"] = live["bytes_per_launch"]
+            res["roofline"]["traffic_note"] = live["note"]
+            res["roofline"]["traffic_fetch_write"] = [live["fetch_bytes"], live["write_bytes"]]
     if extras:
         # The step's ONE collective on this box's single GPU: a one-rank RCCL group (communicator on this device, the stacked
         # [1, 2, B, P] all_gather_into_tensor enqueued behind the two tower streams every step).  Not a scaling number -- the cost
