@@ -10,6 +10,7 @@ Workload at every N: BASELINE.json config "Full dual-encoder (image+text) bs=256
 per GPU (weak scaling: the global batch is 256*N pairs).
 
     python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 8 --steps 20 --warmup 3          # no rank environment: bench.py starts its own 8 ranks (self_launch)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
         --master-port 29500 bench.py --gpus 8 --steps 20 --warmup 3
 
@@ -53,7 +54,49 @@ def parse(argv=None):
     # printing, teardown) for tests/test_bench_ranks.py, which supplies a stub engine through main(model_factory=...).
     # It measures nothing: the line it prints says so, and without a factory the flag is refused.
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help=argparse.SUPPRESS)
+    # rehearsal only: "path/to/file.py:Name" of the stub engine factory, so that a SELF-LAUNCHED rehearsal (ranks in other processes)
+    # can find the stub main(model_factory=...) would have been handed in-process
+    ap.add_argument("--stub-engine", default=None, help=argparse.SUPPRESS)
+    # set by self_launch() on the ranks it starts; "torchrun" when the ranks come from somebody else's launcher (the driver's form)
+    ap.add_argument("--launcher", default=None, choices=["self"], help=argparse.SUPPRESS)
     return ap.parse_args(argv)
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no rank environment: start the N ranks ourselves, exactly the way the driver's
+    multi-GPU command does (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P
+    bench.py ...`), relay their stderr, and print rank 0's ONE JSON line as ours.  Returns the launcher's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    argv = list(sys.argv[1:] if argv is None else argv)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv + ["--launcher", "self"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")           # dmabuf IPC: what RCCL between processes needs on this driver
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [l for l in proc.stdout.splitlines() if l.startswith("{") and '"metric"' in l]
+    for l in proc.stdout.splitlines():
+        if l not in lines and l.strip():
+            print(l, file=sys.stderr)                            # anything else a rank wrote to fd 1 is not part of the contract
+    if proc.returncode == 0 and len(lines) != 1:
+        print(f"bench.py: expected one JSON line from rank 0, got {len(lines)}", file=sys.stderr)
+        return 1
+    if lines:
+        print(lines[-1], flush=True)
+    return proc.returncode
+
+
+def load_stub_factory(spec):
+    import importlib.util
+    path, _, name = spec.rpartition(":")
+    path = path if os.path.isabs(path) else os.path.join(ROOT, path)
+    sp = importlib.util.spec_from_file_location("_bench_stub_engine", path)
+    mod = importlib.util.module_from_spec(sp)
+    sp.loader.exec_module(mod)
+    return getattr(mod, name)
 
 
 def load_pmc_traffic(kernel_name):
@@ -266,20 +309,45 @@ def main(argv=None, model_factory=None):
     """``model_factory(cfg, sd, device=, dtype=, max_batch=)``: tests only (with --backend gloo); the product path builds
     ``plip_amd.model.PlipModel`` and fails without an MI355X."""
     args = parse(argv)
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world_size_env = os.environ.get("WORLD_SIZE")
+    if world_size_env is None and args.gpus > 1:
+        # the driver starts benches as plain `python3 bench.py --gpus N ...`: one process per GPU is then OUR job
+        if model_factory is not None:
+            raise SystemExit("an in-process model factory cannot follow self-launched ranks: pass --stub-engine file.py:Name")
+        rc = self_launch(args, argv)
+        if rc:
+            raise SystemExit(rc)
+        return
+    world = int(world_size_env or "1")
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
+    if args.stub_engine:
+        if args.backend != "gloo" or model_factory is not None:
+            raise SystemExit("--stub-engine belongs to the --backend gloo rehearsal (and replaces main(model_factory=...))")
+        model_factory = load_stub_factory(args.stub_engine)
     # The contract is ONE JSON line on stdout.  Native libraries write there too (RCCL prints a version banner to fd 1 when a
     # communicator comes up): everything this process emits goes to stderr at the file-descriptor level, except the line itself.
     sys.stdout.flush()
     real_stdout_fd = os.dup(1)
     os.dup2(2, 1)
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit(f"--gpus {args.gpus} needs one process per GPU: launch with\n  python -m torch.distributed.run "
-                             f"--nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 --master-port 29500 "
-                             f"bench.py --gpus {args.gpus} ...")
-        raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
+
+    def emit(line):
+        sys.stdout.flush()
+        os.dup2(real_stdout_fd, 1)
+        print(line, flush=True)
+        os.dup2(2, 1)                   # whatever teardown prints is not part of the line either
+
+    try:
+        _run(args, world, rank, world_size_env, model_factory, emit)
+    finally:                            # in-process callers (tests) get their fd 1 back, and the duplicate does not leak (ADVICE r5)
+        sys.stdout.flush()
+        os.dup2(real_stdout_fd, 1)
+        os.close(real_stdout_fd)
+
+
+def _run(args, world, rank, world_size_env, model_factory, emit):
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     rehearsal = args.backend == "gloo"
     if rehearsal and model_factory is None:
         raise SystemExit("--backend gloo is the tests' host-only rehearsal of the multi-rank control flow (it needs a stub "
@@ -475,6 +543,10 @@ def main(argv=None, model_factory=None):
         # structured beside `dtype`: how many LEADING text blocks of the bf16 engine run on f16 MFMA operands
         "text_f16_lead_blocks": int(getattr(model.engine, "text_f16_layers", 0)),
         "rccl_ranks": rccl_ranks, "rank_devices": rank_devices,
+        # how the ranks came to be: WORLD_SIZE as this process found it, and who started the ranks -- "self" (bench.py re-executed
+        # itself under torch.distributed.run because --gpus N > 1 arrived without a rank environment), "torchrun" (somebody else's
+        # launcher set the environment) or "none" (one plain process)
+        "world_size_env": world_size_env, "launcher": args.launcher or ("torchrun" if world_size_env is not None else "none"),
         "data": "synthetic" if not rehearsal else "synthetic; gloo REHEARSAL with a stub engine -- control flow only, not a measurement",
         "config": {"workload": f"full dual encoder (image tower + text tower + L2 normalise + logits_per_image), "
                                f"{args.arch}, bs={B} pairs per GPU, {cfg.image_size}px, {cfg.context_length} tokens, "
@@ -690,10 +762,7 @@ def main(argv=None, model_factory=None):
         except Exception as e:  # pragma: no cover
             res["rccl_one_rank"] = {"error": repr(e)}
     res["cpu_baseline"] = cpu_baseline(cfg, sd, args.cpu_seconds) if (world == 1 and not args.no_cpu_baseline) else None
-    sys.stdout.flush()
-    os.dup2(real_stdout_fd, 1)
-    print(json.dumps(res), flush=True)
-    os.dup2(2, 1)                       # whatever teardown prints is not part of the line either
+    emit(json.dumps(res))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -110,11 +110,47 @@ def test_bench_refuses_the_rehearsal_backend_without_a_stub_and_a_world_size_mis
         monkeypatch.delenv(k, raising=False)
     with pytest.raises(SystemExit, match="rehearsal"):
         bench.main(["--backend", "gloo"])
-    with pytest.raises(SystemExit, match="one process per GPU"):
+    with pytest.raises(SystemExit, match="cannot follow self-launched ranks"):
+        bench.main(["--gpus", "2", "--backend", "gloo"], model_factory=_StubModel)
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    with pytest.raises(SystemExit, match="!= WORLD_SIZE 4"):
         bench.main(["--gpus", "2"])
+    monkeypatch.delenv("WORLD_SIZE")
     if not torch.cuda.is_available():
         with pytest.raises(SystemExit, match="no CPU path"):      # the product path never falls back to the host
             bench.main([])
+
+
+def test_bench_launches_its_own_ranks_when_started_as_plain_python():
+    """the driver's command form is `python3 bench.py --gpus N ...` with NO rank environment.  bench.py then
+    re-executes itself under torch.distributed.run (one process per GPU), and the caller still reads exactly one JSON line."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--backend", "gloo",
+                        "--stub-engine", "tests/test_bench_ranks.py:_StubModel"], env=env, cwd="/tmp", stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, p.stdout
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["rccl_ranks"] == 2 and res["config"]["global_batch"] == 512
+    assert res["launcher"] == "self" and res["world_size_env"] == "2"
+    assert len(res["rank_devices"]) == 2 and "REHEARSAL" in res["data"]
+
+
+def test_bench_in_process_gives_the_caller_its_stdout_back(monkeypatch):
+    """main() parks fd 1 on stderr while it runs; it must restore it and close its duplicate on every way out."""
+    sys.path.insert(0, ROOT)
+    import bench
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    before = os.fstat(1)
+    n_fds = len(os.listdir("/proc/self/fd"))
+    with pytest.raises(SystemExit):
+        bench.main(["--backend", "gloo"])                     # refused inside the redirected region
+    after = os.fstat(1)
+    assert (before.st_dev, before.st_ino) == (after.st_dev, after.st_ino)
+    assert len(os.listdir("/proc/self/fd")) == n_fds
 
 
 def test_sharded_zero_shot_example_on_two_gloo_ranks():
