@@ -4,8 +4,7 @@
  * NOT part of the product interface (include/plipmi.h, the drop-in boundary INTEGRATION.md maps to the reference's call
  * sites): these exports exist so that tests/ can compare single kernels with fp64 references through the same C ABI, and so
  * that tools/ can A/B tile choices on one box.  The product path (plip_amd/, bench.py's timed region) never calls them.
- * plipmi_set_gemm_variant is PROCESS-WIDE state (every handle, every later launch, also launches baked into a captured
- * hipGraph): a test hook only.
+ * The plipmi_test_* setters are PROCESS-WIDE state (every handle, every later launch): test hooks only.
  */
 #ifndef PLIPMI_TEST_H
 #define PLIPMI_TEST_H
@@ -35,14 +34,21 @@ int plipmi_gemm_nt(int dtype, int epilogue, int variant, int M, int N, int K, co
 const char* plipmi_gemm_variant_name(int variant);
 /* 1 if this build of the library carries `variant` for `dtype`, else 0 */
 int plipmi_gemm_variant_built(int dtype, int variant);
-/* TEST / A-B HOOK, process-wide, not used by the product path: force every GEMM onto one tile variant (>= 0), or back
- * to the engine's own choice (-1); 1000 + 100 a + b re-maps the engine's choice a to tile b (A/B runs of the step);
- * 2000 + m sets GemmParams.duo = m (tile 7: issue priority of the workgroup in the CU's first / second LDS slot);
- * 3000 / 3001 / 3002: the engines run the text tower's q/k/v projection and attention as two kernels / as the fused kernel where
- * it applies and the batch fills the chip (default) / as the fused kernel wherever it applies;
- * 4000 / 4001: fp32 pixels go through the unfold pass + the plain patch GEMM / the patch GEMM gathers them itself where it can (default);
- * -1 clears all of it.  (The library reads no environment variables.) */
-void plipmi_set_gemm_variant(int variant);
+/* TEST / A-B HOOKS, process-wide, never called by the product path (the library reads no environment variables either).  Each
+ * returns PLIPMI_OK, or PLIPMI_ERR_INVALID for a value outside its range (nothing changes then).  A hook changes what LATER launches
+ * are; hipGraphs a handle captured earlier are dropped and re-captured at its next small-batch call.
+ *   plipmi_test_force_gemm_tile(v)     every GEMM on tile v (0 .. n-1, plipmi_gemm_variant_name), -2 the naive checker kernel,
+ *                                      -1 the engine's own cost model again
+ *   plipmi_test_remap_gemm_tile(a, b)  where the cost model chooses tile a, run tile b (A/B runs of the whole step); b = -1 clears
+ *   plipmi_test_fused_qkv_attention(m) the text tower's q/k/v projection + attention: 0 two kernels, 1 the product rule (fused where it
+ *                                      applies and the batch fills the chip; default), 2 fused wherever it applies
+ *   plipmi_test_patch_gather(on)       fp32 pixels: 0 unfold pass + plain patch GEMM, 1 im2col on load where it applies (default)
+ *   plipmi_test_reset_hooks()          all of the above back to the product behaviour */
+int plipmi_test_force_gemm_tile(int variant);
+int plipmi_test_remap_gemm_tile(int from, int to);
+int plipmi_test_fused_qkv_attention(int mode);
+int plipmi_test_patch_gather(int on);
+void plipmi_test_reset_hooks(void);
 /* Test hook: the residual-stream planes {hi, lo} (n values, n % 4 == 0) from `from_dtype`'s split format to `to_dtype`'s
  * (PLIPMI_BF16 / PLIPMI_F16), in place -- what a text tower with plipmi_config.text_f16_layers does between its f16 and
  * its bf16 blocks.  Exact: both formats hold the fp32 value bit for bit (|x| < 65504). */
@@ -76,7 +82,7 @@ int plipmi_gemm_nt_ln(int dtype, int mode, int variant, int M, int N, int K, con
 /* Kernel-level entry for the text tower's fused kernel (csrc/qkv_attention.hip): LayerNorm-folded q/k/v projection (mode 0 of
  * plipmi_gemm_nt_ln with N = 3 * 64 H) with the attention in its epilogue, out [B*S, 64 H] -- bit-identical to
  * plipmi_gemm_nt_ln(mode 0) followed by plipmi_attention(impl 1).  dtype PLIPMI_BF16 | PLIPMI_F16, 65 <= S <= 80, ns = H.
- * (plipmi_set_gemm_variant(3000) makes the ENGINE run the two kernels instead, 3001 / -1 the product rule, 3002 the fused one at every batch.) */
+ * (plipmi_test_fused_qkv_attention(0) makes the ENGINE run the two kernels instead, 1 the product rule, 2 the fused one at every batch.) */
 int plipmi_qkv_attention(int dtype, const void* A, const void* W, const float* c2, const float* stats, int ns, float eps, void* out,
                          int B, int S, int H, int causal, const int64_t* key_mask,
                          uint64_t* trace /* NULL, or 8 x uint64 per workgroup: {start, prologue done, K loop done, Q/K/V images

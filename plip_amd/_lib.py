@@ -52,7 +52,11 @@ TEST_SYMBOLS = {
     "plipmi_debug_hidden": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp]),
     "plipmi_gemm_nt": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _f, _vp, _vp]),
     "plipmi_gemm_variant_name": (C.c_char_p, [_i]),
-    "plipmi_set_gemm_variant": (None, [_i]),
+    "plipmi_test_force_gemm_tile": (_i, [_i]),
+    "plipmi_test_remap_gemm_tile": (_i, [_i, _i]),
+    "plipmi_test_fused_qkv_attention": (_i, [_i]),
+    "plipmi_test_patch_gather": (_i, [_i]),
+    "plipmi_test_reset_hooks": (None, []),
     "plipmi_gemm_variant_built": (_i, [_i, _i]),
     "plipmi_recode_planes": (_i, [_vp, _vp, C.c_size_t, _i, _i, _vp]),
     "plipmi_gemm_nt_ln": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp]),

@@ -38,13 +38,17 @@ static constexpr int kLatencyBatch = 0;
 using namespace plipmi;
 
 static thread_local char g_err[512] = "";
-// TEST / A-B hook (plipmi_set_gemm_variant 3000 + mode; plipmi_test.h): 0 = the text tower's q/k/v projection and its attention run
-// as two kernels even where the fused kernel (qkv_attention.hip) applies, 1 = the product rule (fused where it applies AND the batch
-// fills the chip), 2 = fused wherever it applies, small batches too.  The product path never writes it.
+// TEST / A-B hooks (plipmi_test.h, process-wide; the product path never writes them).
+// g_fuse_qkv_attention (plipmi_test_fused_qkv_attention): 0 = the text tower's q/k/v projection and its attention run as two kernels
+// even where the fused kernel (qkv_attention.hip) applies, 1 = the product rule (fused where it applies AND the batch fills the chip),
+// 2 = fused wherever it applies, small batches too.
 static int g_fuse_qkv_attention = 1;
-// TEST / A-B hook (plipmi_set_gemm_variant 4000 + on): 0 = fp32 pixels always go through the unfold pass + the plain patch GEMM,
-// 1 (default) = the patch GEMM gathers them itself where gemm_gather_supports() says so.
+// g_patch_gather (plipmi_test_patch_gather): 0 = pixels always go through the unfold pass + the plain patch GEMM, 1 (default) = the
+// patch GEMM gathers them itself where gemm_gather_supports() says so.
 static int g_patch_gather = 1;
+// Captured hipGraphs hold the launches of the hook settings they were captured under: every hook change bumps this epoch, and a handle
+// whose graphs are older drops them before its next small-batch call.
+static unsigned g_hook_epoch = 0;
 
 static int fail(int code, const char* fmt, ...) {
   va_list ap;
@@ -140,6 +144,7 @@ struct plipmi_engine {
   // by fp32 summation order only; inside a regime a row's embedding does not depend on the batch it arrives in.
   int latency_batch = 0;
   std::map<std::tuple<int, int, int, int, int>, GraphEntry> graphs;
+  unsigned graphs_epoch = 0;  // g_hook_epoch the captured graphs belong to
   void* g_vin = nullptr;      // staged image input (fp32 pixels or uint8 tiles) [graph_batch_cap, 3, H, W] x 4 B
   int64_t* g_tin = nullptr;   // staged ids   [graph_batch_cap, ctx]
   int64_t* g_tmask = nullptr; // staged attention mask
@@ -595,6 +600,11 @@ int graph_or_eager(plipmi_handle h, int kind, int B, int normalize, int eos, int
                           float* out, float* out_stage, Fwd&& forward /* (in, mask, out, stream) -> rc */) {
   const bool eligible = h->graph_batch > 0 && B <= h->graph_batch && !h->prof;
   if (!eligible) return forward(in, mask, out, s);
+  if (h->graphs_epoch != g_hook_epoch) {   // a test hook changed what the launches are since these graphs were captured
+    for (auto& kv : h->graphs) if (kv.second.exec) hipGraphExecDestroy(kv.second.exec);
+    h->graphs.clear();
+    h->graphs_epoch = g_hook_epoch;
+  }
   GraphEntry& ge = h->graphs[std::make_tuple(kind, B, normalize, eos, has_mask)];
   if (ge.seen++ == 0) return forward(in, mask, out, s);
   HIP_TRY(hipMemcpyAsync(in_stage, in, in_bytes, hipMemcpyDeviceToDevice, s));
@@ -1017,11 +1027,33 @@ int plipmi_gemm_nt_ld(int dtype, int epilogue, int variant, int M, int N, int K,
   return PLIPMI_OK;
 }
 
-void plipmi_set_gemm_variant(int variant) {
-  if (variant >= 4000 && variant < 5000) { g_patch_gather = variant - 4000; return; }
-  if (variant >= 3000 && variant < 4000) { g_fuse_qkv_attention = variant - 3000; return; }
-  if (variant == -1) { g_fuse_qkv_attention = 1; g_patch_gather = 1; }
-  gemm_set_default_override(variant);
+int plipmi_test_force_gemm_tile(int variant) {
+  if (!gemm_force_tile(variant)) return fail(PLIPMI_ERR_INVALID, "tile %d: -1 (cost model), -2 (naive checker) or 0 .. %d", variant, gemm_num_variants() - 1);
+  ++g_hook_epoch;
+  return PLIPMI_OK;
+}
+int plipmi_test_remap_gemm_tile(int from, int to) {
+  if (!gemm_remap_tile(from, to)) return fail(PLIPMI_ERR_INVALID, "remap %d -> %d: tiles are 0 .. %d (to = -1 clears)", from, to, gemm_num_variants() - 1);
+  ++g_hook_epoch;
+  return PLIPMI_OK;
+}
+int plipmi_test_fused_qkv_attention(int mode) {
+  if (mode < 0 || mode > 2) return fail(PLIPMI_ERR_INVALID, "fused q/k/v + attention mode %d: 0 (two kernels), 1 (product rule), 2 (fused wherever it applies)", mode);
+  g_fuse_qkv_attention = mode;
+  ++g_hook_epoch;
+  return PLIPMI_OK;
+}
+int plipmi_test_patch_gather(int on) {
+  if (on != 0 && on != 1) return fail(PLIPMI_ERR_INVALID, "patch gather %d: 0 (unfold pass) or 1 (im2col on load where it applies)", on);
+  g_patch_gather = on;
+  ++g_hook_epoch;
+  return PLIPMI_OK;
+}
+void plipmi_test_reset_hooks(void) {
+  g_fuse_qkv_attention = 1;
+  g_patch_gather = 1;
+  gemm_reset_overrides();
+  ++g_hook_epoch;
 }
 int plipmi_qkv_attention(int dtype, const void* A, const void* W, const float* c2, const float* stats, int ns, float eps, void* out,
                          int B, int S, int H, int causal, const int64_t* key_mask, uint64_t* trace, void* stream) {

@@ -105,10 +105,6 @@ struct GemmParams {
   // test hook (plipmi_gemm_nt_traced): per workgroup 8 x u64 {start, prologue done, main loop done, epilogue
   // done, logical tile id, HW_ID, k tiles, 0}, s_memtime ticks.  nullptr on the product path.
   unsigned long long* trace = nullptr;
-  // test hook (plipmi_set_gemm_variant 2000 + mode; SCHED 9 tiles, two workgroups per CU): 1 = the workgroup that owns the CU's
-  // FIRST LDS allocation raises its waves' issue priority, 2 = the second one does -- the slot with priority finishes its K
-  // loop first and stores while the other slot multiplies.  0 (product path): no priorities.
-  int duo = 0;
 };
 
 // LDS-DMA (global_load_lds_dwordx4): each lane's 16 bytes at `gsrc` land at
@@ -277,10 +273,10 @@ __device__ __forceinline__ void tie_regs5(u32x4& a, u32x4& b, u32x4& c, u32x4& d
 // engine, SCHED 0 .. 6): BM / 32 blocks are dealt to the WM wave rows MI = ceil(BM / 32 / WM) at a time, so the LAST wave row may
 // hold fewer (160 x 256 on 2 x 4 waves: 3 + 2 blocks; waves w and w + 4 of a workgroup share a SIMD -- MI355X_MICROARCH.md, LDS
 // section: dispatch order 0->2->1->3 -- so with WN = 4 every SIMD hosts one wave of each wave row and the MFMA work per SIMD stays
-// even).  16x16x32 forms (SCHED 7 / 9): wave rows of BM / WM rows in 16-row blocks, every wave row the same (kHalf below).
+// even).  16x16x32 ring form (SCHED 7): wave rows of BM / WM rows in 16-row blocks, every wave row the same (kHalf below).
 // SCHED 0: fragment reads / MFMAs in compiler order, the whole fill issued at the top of the iteration;
 //       1: reads of K-step ks+1 pinned in front of the MFMAs of step ks (register double buffering), fill at the top;
-//       5 / 6: as 1, and the next fill's LDS-DMA requests are packed into the first 2 / 3 K steps of the iteration, one batch
+//       6: as 1, and the next fill's LDS-DMA requests are packed into the first 3 K steps of the iteration, one batch
 //          in front of each step's MFMA group, instead of queueing all of them on the texture-address unit at once.
 // NSTAGE 2: the fill runs ONE K tile ahead, the end-of-iteration wait is vmcnt(0);
 //        3: three LDS stages, the fill runs TWO K tiles ahead and the wait is a counted vmcnt (in-order retirement: the
@@ -317,26 +313,28 @@ template <typename T, int BM, int BN, int WM, int WN, int EPI, int SCHED = 0, in
 __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void gemm_nt_kernel(const GemmParams p) {
   constexpr int NT = WM * WN * 64;
-  // SCHED 7 / 9 (16x16x32 forms: ring of three / streamed two-stage): wave rows are dealt in 16-ROW blocks -- BM / WM rows each, a
+  // SCHED 7 (16x16x32 form on the ring of three): wave rows are dealt in 16-ROW blocks -- BM / WM rows each, a
   // multiple of 16 but not necessarily of 32 (160 rows on two wave rows: 80 rows = five 16-row MFMA tiles per wave row, all wave
   // rows equal).  The epilogues still walk 32-row slabs; a wave row's last slab may then be a half slab (kHalf paths below).
   // Round 5: the ring tile used to deal 32-row blocks 3 + 2 (96 x 64 and 64 x 64 wave tiles; the short waves read a block nobody
   // multiplied and waited at every barrier); 80 x 64 everywhere: 1876 -> 1825 cycles per K tile on fc2, 9 fragment reads per 20
   // MFMAs instead of 10 per 20, cold-operand launches -6 ... -12 %, the step -0.4 % / -0.9 % (profiles/r05_ring_even_dealing.txt).
-  constexpr bool kHalf = SCHED == 9 || SCHED == 7;
+  constexpr bool kHalf = SCHED == 7;
   constexpr int RB = BM / 32;                  // 32-row blocks of the tile
   constexpr int MI = kHalf ? (BM / WM + 31) / 32 : (RB + WM - 1) / WM;   // ... per wave row (the last one may hold fewer)
   constexpr bool kUneven = !kHalf && RB % WM != 0;
   constexpr int TM = kHalf ? BM / WM : MI * 32, TN = BN / WN;
-  static_assert(!kHalf || (BM % WM == 0 && TM % 16 == 0), "SCHED 9: wave rows of whole 16-row MFMA tiles");
+  static_assert(!kHalf || (BM % WM == 0 && TM % 16 == 0), "SCHED 7: wave rows of whole 16-row MFMA tiles");
   constexpr int NI = TN / 32;
   constexpr int ELEMS16 = 16 / sizeof(T);  // elements per 16-byte chunk
   using OutT = std::conditional_t<sizeof(T) == 4, float, T>;
   static_assert(!(epi_is_ln(EPI) || epi_emits_stats(EPI)) || sizeof(T) == 2, "LayerNorm folding is a 16-bit-engine form");
-  static_assert(SCHED == 0 || SCHED == 1 || SCHED == 5 || SCHED == 6 || SCHED == 7 || SCHED == 8 || SCHED == 9,
-                "schedules: 0, 1, 5 (fill2), 6 (fill3), 7 / 8 / 9 (16x16x32 form: ring of three / two stages / two stages, 16-row dealing)");
+  // five forms, each reachable from gemm_default_variant (gemm_inst.h): 0 / 1 the 128x128 tiles and the fp32 engine, 6 the 16-bit
+  // 192x256 / 160x256 two-stage tiles, 7 the ring, 8 the 256x256 / 320x256 tiles of the 16-bit engines
+  static_assert(SCHED == 0 || SCHED == 1 || SCHED == 6 || SCHED == 7 || SCHED == 8,
+                "schedules: 0, 1, 6 (fill in three parts), 7 / 8 (16x16x32 form: ring of three / two stages)");
   static_assert(NSTAGE == 2 || NSTAGE == 3, "two LDS stages or a ring of three");
-  constexpr bool kSpread = SCHED >= 5;
+  constexpr bool kSpread = SCHED >= 6;
   constexpr bool kM16 = SCHED >= 7;
   static_assert(!kM16 || sizeof(T) == 2, "the 16x16x32 form: 16-bit operands");
   static_assert(!kM16 || NSTAGE == (SCHED == 7 ? 3 : 2), "schedule 7 runs on the ring, 8 on two stages");
@@ -436,7 +434,7 @@ void gemm_nt_kernel(const GemmParams p) {
   };
   // the same fill cut in parts, one per K step of the MFMA block (SCHED 5 / 6: packed into the first 2 / 3 K steps, so the
   // last request has most of the iteration -- not a quarter of it -- to land before the end-of-iteration wait)
-  constexpr int kFillParts = SCHED == 5 ? 2 : 3;
+  constexpr int kFillParts = 3;
   auto stage_issue_part = [&](int buf, int part) {
     const unsigned base = lds0 + buf * STAGE + wave * 1024;
     if constexpr (kM16) {
@@ -471,13 +469,10 @@ void gemm_nt_kernel(const GemmParams p) {
 #pragma unroll
         for (int i = 0; i < PA; ++i)
           if (a_piece(i)) glds16_buf(rs_a, a_off[i], koff, base + i * NT * 16);
-        if constexpr (kFillParts == 2)
-          glds16_buf_n<HW, WO(0), WO(HW > 1 ? 1 : 0), WO(HW > 2 ? 2 : 0), WO(HW > 3 ? 3 : 0)>(
-              base, koff, rs_w, w_off[0], rs_w, w_off[HW > 1 ? 1 : 0], rs_w, w_off[HW > 2 ? 2 : 0], rs_w, w_off[HW > 3 ? 3 : 0]);
-      } else if (part == kFillParts - 2 && kFillParts == 3) {
+      } else if (part == 1) {
         glds16_buf_n<HW, WO(0), WO(HW > 1 ? 1 : 0), WO(HW > 2 ? 2 : 0), WO(HW > 3 ? 3 : 0)>(
             base, koff, rs_w, w_off[0], rs_w, w_off[HW > 1 ? 1 : 0], rs_w, w_off[HW > 2 ? 2 : 0], rs_w, w_off[HW > 3 ? 3 : 0]);
-      } else if (part == kFillParts - 1) {
+      } else if (part == 2) {
         glds16_buf_n<HW, WO(HW), WO(HW + (HW > 1 ? 1 : 0)), WO(HW + (HW > 2 ? 2 : 0)), WO(HW + (HW > 3 ? 3 : 0))>(
             base, koff, rs_w, w_off[HW], rs_w, w_off[HW + (HW > 1 ? 1 : 0)], rs_w, w_off[HW + (HW > 2 ? 2 : 0)], rs_w,
             w_off[HW + (HW > 3 ? 3 : 0)]);
@@ -827,12 +822,6 @@ void gemm_nt_kernel(const GemmParams p) {
     trace[6] = (unsigned long long)KT |
                ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 6 /* LDS_ALLOC [31:0] */) << 32);
   }
-  if constexpr (kHalf) {
-    if (p.duo) {   // wave-uniform
-      const unsigned lds_base = __builtin_amdgcn_s_getreg((7 << 11) | (0 << 6) | 6 /* LDS_ALLOC.LDS_BASE [7:0] */);
-      if ((lds_base == 0) == (p.duo == 1)) __builtin_amdgcn_s_setprio(2);
-    }
-  }
   if constexpr (NSTAGE == 3) {
     // Ring of three.  Invariants at the top of iteration kt: tile kt is visible and its K-step-0 fragments are in registers;
     // tile kt+1 is landing or landed; the stage of tile kt-1 is free (every wave's reads of it had returned before the
@@ -877,10 +866,14 @@ void gemm_nt_kernel(const GemmParams p) {
       // (this branch replaces the prologue above: see the `if constexpr (!kGather)` around it)
       using C0 = std::integral_constant<int, 0>; using C1 = std::integral_constant<int, 1>;
       // iteration kt (tile kt in stage cur, set S = kt & 1 free: tile kt's values were written to LDS an iteration ago)
-      auto iter = [&](auto s_c, int kt) __attribute__((always_inline)) {
+      // (fetch_c = 0: the loop's odd last iteration, kt = KT - 2, has no tile kt + 2 -- said at compile time, so that no pixel load
+      //  whose registers nobody reads afterwards is emitted there: hipcc gave five such dead loads ONE destination and reused it
+      //  straight away, harmless only because the run-time test never took them; tests/test_isa_audit.py found it)
+      auto iter = [&](auto s_c, auto fetch_c, int kt) __attribute__((always_inline)) {
         constexpr int S = decltype(s_c)::value;
-        const int fb = kt + 2 < KT ? nxt2 : -1;
-        if (fb >= 0) gather_load(ga[S], kt + 2);
+        constexpr bool kMayFetch = decltype(fetch_c)::value != 0;
+        const int fb = (kMayFetch && kt + 2 < KT) ? nxt2 : -1;
+        if constexpr (kMayFetch) { if (fb >= 0) gather_load(ga[S], kt + 2); }
         const char* sc = smem + cur * STAGE;
         step16_full(0, sc, 1, fb, kParts);            // W pieces of tile kt+2 ride in this step
         // tile kt+1: its pixels (set S ^ 1) and this wave's W pieces have arrived -- only tile kt+2's requests may be outstanding;
@@ -896,8 +889,8 @@ void gemm_nt_kernel(const GemmParams p) {
       read16_all(smem, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
       int kt = 0;
-      for (; kt + 1 < KT - 1; kt += 2) { iter(C0{}, kt); iter(C1{}, kt + 1); }
-      if (kt < KT - 1) iter(C0{}, kt);
+      for (; kt + 1 < KT - 1; kt += 2) { iter(C0{}, C1{}, kt); iter(C1{}, C1{}, kt + 1); }
+      if (kt < KT - 1) iter(C0{}, C0{}, kt);
       if constexpr (kRowOperand) {
         load_block(0, add[0]);
         add_ready = true;
@@ -1330,7 +1323,10 @@ bool gemm_variant_is_built(int dtype, int variant);
 // small-M kernel of the 16-bit engines (gemm_skinny.hip): 32 x 64 output tile per workgroup, K split over its waves
 bool gemm_skinny_supports(int epi, int M, int N, int K);
 int gemm_launch_skinny(int dtype, int epi, const GemmParams& p, hipStream_t stream, const char** kernel_name);
-void gemm_set_default_override(int variant);  // tests / A-B runs (process-wide hook, not a product knob)
+// tests / A-B runs (process-wide hooks behind plipmi_test.h, not product knobs); false = value out of range, nothing changed
+bool gemm_force_tile(int variant);            // -1 the cost model chooses, -2 the naive checker, >= 0 that tile for every launch
+bool gemm_remap_tile(int from, int to);       // the cost model's choice `from` runs as tile `to` (-1: as itself again)
+void gemm_reset_overrides();
 // the patch GEMM with its A operand gathered from fp32 pixels while it is staged (ADDR 2: im2col on load, no unfold pass)
 bool gemm_gather_supports(int dtype, int B, int image, int patch, int N);
 int gemm_launch_gather(int dtype, const GemmParams& p, hipStream_t stream, const char** kernel_name);

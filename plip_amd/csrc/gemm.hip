@@ -12,7 +12,7 @@ int gemm_num_cus();
 static const GemmVariant kVariants[kNumVariants] = {
     {"128x128_w2x2_glds64", 128, 128, 256}, {"128x128_w2x2_bufdma", 128, 128, 256}, {"256x256_w4x2_bufdma", 256, 256, 512},
     {"320x256_w2x4_bufdma", 320, 256, 512}, {"192x256_w2x4_bufdma", 192, 256, 512}, {"160x256_w2x4_bufdma", 160, 256, 512},
-    {"160x256_w2x4_ring3", 160, 256, 512}, {"160x128_w2x2_duo", 160, 128, 256},
+    {"160x256_w2x4_ring3", 160, 256, 512},
 };
 
 int gemm_num_cus() {
@@ -30,22 +30,23 @@ int gemm_num_cus() {
 int gemm_num_variants() { return kNumVariants; }
 const GemmVariant& gemm_variant(int v) { return kVariants[v]; }
 
-// Process-wide override for TESTS and A/B measurements (plipmi_set_gemm_variant): the product path never writes it, and
-// nothing here is read from the environment.
-static int g_override = -1;    // -1 = the cost model below chooses
+// Process-wide overrides for TESTS and A/B measurements (plipmi_test.h: plipmi_test_force_gemm_tile / _remap_gemm_tile): the product
+// path never writes them, and nothing here is read from the environment.
+static int g_override = -1;         // -1 = the cost model below chooses, -2 = the naive checker kernel, >= 0 = that tile
 static int g_remap[kNumVariants];   // A/B runs: the cost model's choice a runs as g_remap[a] - 1 (0 = itself)
-static int g_duo = 0;               // A/B runs: GemmParams.duo of every launch (issue priority per LDS slot, variant 7)
-// variant >= 2000: duo mode = variant - 2000; 1000 .. 1999: remap the cost model's choice a = (variant - 1000) / 100 to tile
-// b = variant % 100; -1 clears everything
-void gemm_set_default_override(int variant) {
-  if (variant >= 2000) { g_duo = variant - 2000; return; }
-  if (variant >= 1000) {
-    const int a = (variant - 1000) / 100, b = variant % 100;
-    if (a < kNumVariants && b < kNumVariants) g_remap[a] = b + 1;
-    return;
-  }
+bool gemm_force_tile(int variant) {
+  if (variant < -2 || variant >= kNumVariants) return false;
   g_override = variant;
-  if (variant == -1) { for (int& r : g_remap) r = 0; g_duo = 0; }
+  return true;
+}
+bool gemm_remap_tile(int from, int to) {
+  if (from < 0 || from >= kNumVariants || to < -1 || to >= kNumVariants) return false;
+  g_remap[from] = to + 1;
+  return true;
+}
+void gemm_reset_overrides() {
+  g_override = -1;
+  for (int& r : g_remap) r = 0;
 }
 bool gemm_variant_is_built(int dtype, int variant) {
   return dtype == 1 ? gemm_built_bf16(variant) : dtype == 2 ? gemm_built_f16(variant) : gemm_built_f32(variant);
@@ -114,7 +115,6 @@ int gemm_launch(int dtype, int epi, int variant, const GemmParams& p, hipStream_
   GemmLaunchFn fn = dtype == 1 ? gemm_get_bf16(variant, epi) : dtype == 2 ? gemm_get_f16(variant, epi) : gemm_get_f32(variant, epi);
   if (!fn) return (int)hipErrorInvalidValue;
   GemmParams pr = p;
-  pr.duo = g_duo;
   if (variant >= 0) {
     // column-group raster: minimise A*xn + W*(8/xn) fabric bytes subject to an XCD's W share fitting its L2
     const double esz = dtype == 0 ? 4.0 : 2.0;
@@ -152,6 +152,10 @@ bool gemm_gather_supports(int dtype, int B, int image, int patch, int N) {
   if (image % patch || N % 256) return false;
   const int g = image / patch, M = B * g * g, K = 3 * patch * patch;
   if (K / 64 < 2 || (size_t)B * 3 * image * image * 4 >= (1ull << 32)) return false;
+  // the ring tile addresses C and W through 32-bit buffer offsets as well: the output rows (patch rows + one CLS row per image + 1,
+  // as gemm_launch counts them) and the weight span must stay below 4 GiB too -- for 16-pixel patches the fp32 output of an image
+  // (197 x 768 x 4 B) is LARGER than its pixels; beyond, the unfold pass + gemm_launch's 64-bit tile take over
+  if (((size_t)M + B + 1) * N * 4 >= (1ull << 32) || (size_t)N * K * 2 >= (1ull << 32)) return false;
   return gemm_default_variant(dtype, M, N, K) == 6;
 }
 int gemm_launch_gather(int dtype, const GemmParams& p, hipStream_t stream, const char** kernel_name) {

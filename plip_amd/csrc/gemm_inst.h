@@ -42,7 +42,7 @@ int launch_naive(const GemmParams& p, hipStream_t stream) {
 }
 
 // The tile variants, each built for every dtype; numbers are what plipmi_gemm_nt(variant=...) and
-// plipmi_set_gemm_variant take, names come from gemm.hip.
+// plipmi_test_force_gemm_tile take, names come from gemm.hip.
 //   0  128x128, 2x2 waves, two workgroups per CU, 64-bit lane addresses (operands of 4 GiB and more; small problems)
 //   1  128x128, 2x2 waves, buffer-form LDS-DMA
 //   2  256x256, 4x2 waves; 16-bit engines: 16x16x32 MFMAs, hand-placed K steps, barrier in front of the tile's last groups
@@ -51,9 +51,7 @@ int launch_naive(const GemmParams& p, hipStream_t stream) {
 //   5  160x256, 2x4 waves with 3 + 2 row blocks per wave row: 240 / 248 tiles on the bs=256 residual GEMMs (256 CUs)
 //   6  160x256 on a ring of three LDS stages (two K tiles of lookahead, barrier in front of the last K step's MFMAs);
 //      16-bit engines: 16x16x32 MFMAs, hand-placed K steps
-//   7  160x128, 2x2 waves, 72 KB of LDS: TWO workgroups per CU, each with its own barriers -- one workgroup's K loop runs under
-//      the other's epilogue.  16-bit engines: 16x16x32 streamed form with wave rows of five 16-row tiles (80 x 64 wave tile)
-constexpr int kNumVariants = 8;
+constexpr int kNumVariants = 7;
 
 template <typename T>
 constexpr bool gemm_variant_built(int v) { return v == -2 || (v >= 0 && v < kNumVariants); }
@@ -77,7 +75,6 @@ struct GemmTable {
         case 4: return launch_tiled<T, 192, 256, 2, 4, EPI, kH ? 6 : 1, 1>;
         case 5: return launch_tiled<T, 160, 256, 2, 4, EPI, kH ? 6 : 1, 1>;
         case 6: return launch_tiled<T, 160, 256, 2, 4, EPI, kH ? 7 : 1, 1, 3>;
-        case 7: return launch_tiled<T, 160, 128, 2, 2, EPI, kH ? 9 : 1, 1>;
         case -2: if constexpr (!kLn) return launch_naive<T, EPI>; else return nullptr;
         default: return nullptr;
       }

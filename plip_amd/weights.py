@@ -396,6 +396,10 @@ def load_checkpoint(path: str, arch: str | None = None, trust_pickle: bool = Fal
             # a damaged file is not a trust question: do not steer the user towards arbitrary-code unpickling for it
             raise RuntimeError(f"{path} is truncated or corrupt ({type(e).__name__}: {e}); re-download or re-save it") from e
         except (pickle.UnpicklingError, RuntimeError, AttributeError, ImportError, KeyError) as e:
+            # a truncated torch ZIP checkpoint surfaces as RuntimeError("PytorchStreamReader failed reading zip archive: failed finding
+            # central directory"): damaged, not untrusted
+            if isinstance(e, RuntimeError) and any(k in str(e) for k in ("PytorchStreamReader", "central directory", "failed reading zip")):
+                raise RuntimeError(f"{path} is truncated or corrupt ({str(e)[:160]}); re-download or re-save it") from e
             # what weights_only=True raises on a code-carrying pickle ("Unsupported global / class", UnpicklingError) -- and what
             # legacy pickles naming modules that are gone raise on their way there: these get the trust guidance below
             if isinstance(e, RuntimeError) and not any(k in str(e) for k in ("Unsupported", "weights_only", "pickle", "GLOBAL", "global")):

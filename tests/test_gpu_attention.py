@@ -101,16 +101,16 @@ def test_engine_runs_the_fused_text_kernel_and_the_two_kernels_to_the_same_bits(
         ids, mask = W.synthetic_ids(cfg, 100, seed=77)
         ids_t, mask_t = torch.from_numpy(ids), torch.from_numpy(mask)
         try:
-            lib.plipmi_set_gemm_variant(3000)
+            lib.plipmi_test_fused_qkv_attention(0)
             two = model.get_text_features(input_ids=ids_t, attention_mask=mask_t)
             h_two = model.engine.hidden("text", 3, ids_t)
-            lib.plipmi_set_gemm_variant(3001)
+            lib.plipmi_test_fused_qkv_attention(1)
             one = model.get_text_features(input_ids=ids_t, attention_mask=mask_t)
             h_one = model.engine.hidden("text", 3, ids_t)
-            lib.plipmi_set_gemm_variant(3002)                       # fused at a batch the product rule leaves to the two kernels
+            lib.plipmi_test_fused_qkv_attention(2)                       # fused at a batch the product rule leaves to the two kernels
             small = model.get_text_features(input_ids=ids_t[:6], attention_mask=mask_t[:6])
         finally:
-            lib.plipmi_set_gemm_variant(-1)
+            lib.plipmi_test_reset_hooks()
         assert torch.equal(one, two) and torch.equal(h_one, h_two) and torch.equal(small, two[:6])
 
         def kernels(n):

@@ -26,10 +26,10 @@ def _ref(a, w, bias, epi, alpha, c0):
 
 # Tile variants (csrc/gemm_inst.h): 0 / 1 = 128x128 (64-bit addresses / buffer LDS-DMA), 2 = 256x256, 3 = 320x256,
 # 4 = 192x256, 5 = 160x256 (uneven wave rows: 3 + 2 row blocks), 6 = 160x256 on a ring of three LDS stages,
-# 7 = 160x128 on 2x2 waves (two workgroups per CU; 16-bit: wave rows of five 16-row MFMA tiles, half slabs in the epilogues);
-# -2 = the naive checker kernel.
+# (16-bit: wave rows of five 16-row MFMA tiles, half slabs in the epilogues); -2 = the naive checker kernel.
+# (Round 5's tile 7 -- 160x128, two workgroups per CU -- was measured, lost, and is no longer built: profiles/r05_duo_tile.txt.)
 HALF = {"bf16": torch.bfloat16, "f16": torch.float16}
-NVAR = 8
+NVAR = 7
 
 
 def _built(dtype):
@@ -92,7 +92,7 @@ def test_gemm_matches_naive_checker_bitwise_fp32():
 @pytest.mark.parametrize("epi", [0, 1, 2, 3])
 def test_every_tile_sums_k_in_the_same_order(epi, hdt):
     """A row's embedding must not depend on the batch it arrives in (PLIP.coalesce, the embedding caches): small problems run
-    on the 128x128 tile (v_mfma 32x32x16), large ones on the 16x16x32 tiles (2, 3, 6, 7) -- so every tile has to produce the
+    on the 128x128 tile (v_mfma 32x32x16), large ones on the 16x16x32 tiles (2, 3, 6) -- so every tile has to produce the
     SAME bits from the same operands, i.e. the two MFMA shapes must sum K in the same order."""
     from plip_amd.kernel_entries import gemm_nt
     dev = torch.device("cuda:0")
@@ -104,7 +104,7 @@ def test_every_tile_sums_k_in_the_same_order(epi, hdt):
         c0 = torch.randn(M, N, generator=g).to(dev)
         run = lambda v: gemm_nt(a, w, bias, epilogue=epi, variant=v, alpha=0.37, out=c0.clone() if epi == 2 else None)
         y0 = run(0)
-        for v in (1, 2, 3, 4, 5, 6, 7):
+        for v in (1, 2, 3, 4, 5, 6):
             assert torch.equal(run(v), y0), f"tile {v} differs from the 128x128 tile: epi {epi} {M}x{N}x{K} {hdt}"
 
 
@@ -265,7 +265,7 @@ def test_split_plane_residual_epilogue(variant, hdt):
 
 
 @pytest.mark.parametrize("hdt", list(HALF.values()), ids=list(HALF))
-@pytest.mark.parametrize("variant", [2, 6, 7, -1])
+@pytest.mark.parametrize("variant", [2, 3, 6, -1])
 def test_split_plane_epilogue_hands_the_stream_to_the_other_operand_type(variant, hdt):
     """Mode 4 = mode 3 writing the planes in the OTHER 16-bit type's split format: what the last f16 block of a mixed text tower
     (plipmi_config.text_f16_layers) does instead of a re-coding pass.  Must equal mode 3 followed by plipmi_recode_planes bit

@@ -413,20 +413,20 @@ def test_patch_gemm_im2col_on_load_is_bit_identical(arch, B, dtype):
     px = torch.from_numpy(W.synthetic_pixels(cfg, B, seed=77))
     px[3] *= 40.0                                             # large pixels in one image: the rounding of big values is the unfold kernel's too
     try:
-        lib.plipmi_set_gemm_variant(4000)
+        lib.plipmi_test_patch_gather(0)
         h0 = model.engine.hidden("vision", 0, px)
         f0 = model.get_image_features(pixel_values=px)
         rows0 = []
         with model.engine.profile(rows0):
             model.get_image_features(pixel_values=px)
-        lib.plipmi_set_gemm_variant(4001)
+        lib.plipmi_test_patch_gather(1)
         h1 = model.engine.hidden("vision", 0, px)
         f1 = model.get_image_features(pixel_values=px)
         rows1 = []
         with model.engine.profile(rows1):
             model.get_image_features(pixel_values=px)
     finally:
-        lib.plipmi_set_gemm_variant(-1)
+        lib.plipmi_test_reset_hooks()
     assert torch.isfinite(h1).all() and torch.equal(h0, h1) and torch.equal(f0, f1)
     n0 = {r["name"].split("|")[0] for r in rows0}
     n1 = {r["name"].split("|")[0] for r in rows1}

@@ -20,8 +20,8 @@ for B in (1, 4, 8, 16, 32, 48, 64, 96, 128, 256):
     r = {}
     for rep in range(2):
         for mode in (3000, 3002, 3001):       # two kernels / fused wherever it applies / the product rule (fused when the batch fills the chip)
-            lib.plipmi_set_gemm_variant(mode)
+            lib.plipmi_test_fused_qkv_attention(mode - 3000)
             ms = t(lambda: model.engine.encode_text(ids, mask, normalize=True))
             r[mode] = min(r.get(mode, 1e9), ms)
-    lib.plipmi_set_gemm_variant(-1)
+    lib.plipmi_test_reset_hooks()
     print(f"text tower B={B:4d}: two kernels {r[3000]:7.3f} ms   fused {r[3002]:7.3f} ms ({(r[3002]/r[3000]-1)*100:+.1f} %)   product rule {r[3001]:7.3f} ms")

@@ -419,10 +419,6 @@ def sec_gemmtrace():
     """In-kernel timeline of one GEMM launch: where a workgroup's lifetime goes.
     usage: gpu_diag.py gemmtrace <variant> <M> <N> <K> <epi>"""
     v, M, N, K, epi = (int(x) for x in sys.argv[2:7]) if len(sys.argv) > 6 else (5, 12800, 3072, 768, 1)
-    duo = int(sys.argv[7]) if len(sys.argv) > 7 else 0        # variant 7: issue priority per LDS slot (GemmParams.duo)
-    if duo:
-        from plip_amd import _lib
-        _lib.load().plipmi_set_gemm_variant(2000 + duo)
     g = torch.Generator().manual_seed(0)
     dtype = torch.bfloat16
     a = torch.randn(M, K, generator=g).to(dev).to(dtype)
@@ -469,16 +465,13 @@ def sec_gemmtrace():
     # two workgroups per CU (variant 7): which LDS allocation a workgroup got (HW_REG LDS_ALLOC, LDS_BASE = bits 7:0), and when
     # the workgroups of each slot reached their epilogue / ended -- staggered slots mean one slot's stores run under the other's K loop
     bases = sorted(set((lds_alloc & 0xFF).tolist()))
-    print(f"  LDS_ALLOC register values: {sorted(set(hex(int(x)) for x in lds_alloc.tolist()))[:6]}  duo mode {duo}")
+    print(f"  LDS_ALLOC register values: {sorted(set(hex(int(x)) for x in lds_alloc.tolist()))[:6]}")
     if len(bases) > 1:
         loop_end_us = start_us + (t[:, 2] - t[:, 0]) / np.maximum(clk, 1e-9) / 1e3
         for b in bases:
             sel = (lds_alloc & 0xFF) == b
             print(f"    LDS_BASE {b:3d}: {int(sel.sum()):4d} workgroups  start p50 {np.median(start_us[sel]):6.2f}  K loop done p50 {np.median(loop_end_us[sel]):6.2f}"
                   f"  end p50 {np.median(end_us[sel]):6.2f} us   loop {np.median(loop[sel]) / kt:6.0f} cyc/tile  epilogue p50 {np.median(epi_t[sel]) / np.median(clk) / 1e3:5.2f} us")
-    if duo:
-        from plip_amd import _lib
-        _lib.load().plipmi_set_gemm_variant(2000)
 
 
 def sec_qkvattn():
@@ -564,12 +557,12 @@ def sec_policy():
             if dt not in models:
                 models[dt] = PlipModel(cfg, sd, dtype=dt, max_batch=B)
             model = models[dt]
-            lib.plipmi_set_gemm_variant(int(var))
+            lib.plipmi_test_force_gemm_tile(int(var))
             for ov in (False, True):
                 ms = _time(lambda: sharded_pair_logits(model, px, ids, mask, overlap=ov), iters=10, warm=2)
                 if rep:                      # rep 0 = warm-up of clocks / caches
                     res[(arm, ov)].append(ms)
-    lib.plipmi_set_gemm_variant(-1)
+    lib.plipmi_test_reset_hooks()
     for arm in arms:
         a, b = res[(arm, False)], res[(arm, True)]
         print(f"dtype:variant {arm:12s} one stream {np.median(a):6.3f} ms (min {min(a):6.3f})   "
@@ -618,8 +611,8 @@ def sec_tiles():
 
 
 def sec_stepab():
-    """In-process interleaved A/B of the bs=256 bf16 step under remapped tile choices (test hook plipmi_set_gemm_variant
-    1000 + 100 a + b: the cost model's choice a runs as tile b).  arguments: arms like  base  2>7  2>7,3>9,6>10"""
+    """In-process interleaved A/B of the bs=256 bf16 step under remapped tile choices (test hook plipmi_test_remap_gemm_tile(a, b):
+    the cost model's choice a runs as tile b).  arguments: arms like  base  2>3  6>5,3>2  f0  g0"""
     from plip_amd import _lib
     from plip_amd.dist import sharded_pair_logits
     lib = _lib.load()
@@ -632,20 +625,17 @@ def sec_stepab():
     res = {a: {False: [], True: []} for a in arms}
     for rep in range(3):
         for arm in arms:
-            lib.plipmi_set_gemm_variant(-1)
+            lib.plipmi_test_reset_hooks()
             if arm != "base":
                 for pair in arm.split(","):
-                    if pair.startswith("d"):                  # dN: GemmParams.duo = N (issue priority per LDS slot, variant 7)
-                        lib.plipmi_set_gemm_variant(2000 + int(pair[1:]))
-                        continue
                     if pair.startswith("g"):                  # g0 / g1: unfold pass + plain patch GEMM / im2col on load (default)
-                        lib.plipmi_set_gemm_variant(4000 + int(pair[1:]))
+                        lib.plipmi_test_patch_gather(int(pair[1:]))
                         continue
                     if pair.startswith("f"):                  # f0 / f1: text q/k/v + attention as two kernels / fused (default)
-                        lib.plipmi_set_gemm_variant(3000 + int(pair[1:]))
+                        lib.plipmi_test_fused_qkv_attention(int(pair[1:]))
                         continue
                     a, b = (int(x) for x in pair.split(">"))
-                    lib.plipmi_set_gemm_variant(1000 + 100 * a + b)
+                    lib.plipmi_test_remap_gemm_tile(a, b)
             for ov in (False, True):
                 ms = _time(lambda: sharded_pair_logits(model, px, ids, mask, overlap=ov), iters=20, warm=3)
                 res[arm][ov].append(ms)
@@ -654,7 +644,7 @@ def sec_stepab():
                 if ref is None:
                     ref = out
                 print(f"arm {arm:24s} logits max |diff| vs first arm {float((out - ref).abs().max()):.3e}")
-    lib.plipmi_set_gemm_variant(-1)
+    lib.plipmi_test_reset_hooks()
     for arm in arms:
         one, two = res[arm][False], res[arm][True]
         print(f"{arm:24s} one stream {min(one):6.3f} ms (median {sorted(one)[1]:6.3f})   two streams {min(two):6.3f} ms (median {sorted(two)[1]:6.3f})"
