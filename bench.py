@@ -293,6 +293,57 @@ def logits_error_vs_hf_golden(model, cfg, sd, px, ids, mask, B, arch, fixture="v
             "pairs": n, "logits_compared": n * n}
 
 
+def h2d_inclusive(model, cfg, px, ids, mask, steps, warmup, overlap):
+    """pairs/s of the step when every batch starts in pinned host memory (double-buffered copy stream, overlapped with the towers)"""
+    from plip_amd.dist import sharded_pair_logits
+    dev = px.device
+    B = px.shape[0]
+    copy = torch.cuda.Stream(device=dev)
+    main = torch.cuda.current_stream(dev)
+    out = {}
+    tiles = torch.from_numpy(np.random.RandomState(7).randint(0, 256, size=(B, cfg.image_size, cfg.image_size, 3), dtype=np.uint8))
+    for label, host_img in (("fp32_pixels", px.cpu()), ("u8_tiles", tiles)):
+        host = [(host_img.clone().pin_memory(), ids.cpu().pin_memory(), mask.cpu().pin_memory()) for _ in range(2)]
+        devb = [tuple(torch.empty_like(t, device=dev) for t in host[0]) for _ in range(2)]
+        landed = [torch.cuda.Event() for _ in range(2)]
+        consumed = [None, None]
+
+        def fetch(k):
+            slot = k & 1
+            with torch.cuda.stream(copy):
+                if consumed[slot] is not None:
+                    copy.wait_event(consumed[slot])           # the towers that read this slot's previous batch are done
+                for d, h in zip(devb[slot], host[slot]):
+                    d.copy_(h, non_blocking=True)
+                landed[slot].record(copy)
+
+        def run(n):
+            fetch(0)
+            for k in range(n):
+                if k + 1 < n:
+                    fetch(k + 1)                              # batch k+1 crosses PCIe while batch k is in the towers
+                slot = k & 1
+                main.wait_event(landed[slot])
+                sharded_pair_logits(model, *devb[slot], overlap=overlap, equal_shards=True)
+                consumed[slot] = torch.cuda.Event()
+                consumed[slot].record(main)
+
+        run(max(2, warmup))
+        torch.cuda.synchronize(dev)
+        consumed[0] = consumed[1] = None
+        t0 = time.perf_counter()
+        run(steps)
+        torch.cuda.synchronize(dev)
+        dt = (time.perf_counter() - t0) / steps
+        nbytes = sum(t.numel() * t.element_size() for t in host[0])
+        out[label] = {"pairs_per_s": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 3), "host_bytes_per_step": nbytes,
+                      "pcie_GBps": round(nbytes / dt / 1e9, 2)}
+        del host, devb
+    out["note"] = ("inputs start in pinned host memory every step; a copy stream fills the second of two device buffers while the towers "
+                   "run on the first (the pattern of plip_amd/pipeline.py); `value` above is the HBM-resident rate")
+    return out
+
+
 def timed_steps(step, n, dev, warmup=0):
     sync = (lambda: torch.cuda.synchronize(dev)) if dev.type == "cuda" else (lambda: None)
     for _ in range(warmup):
@@ -332,8 +383,18 @@ def main(argv=None, model_factory=None):
     real_stdout_fd = os.dup(1)
     os.dup2(2, 1)
 
-    def emit(line):
+    def flush_all():
+        # C stdio too: RCCL printf()s its version banner into libc's stdout buffer, which is written out whenever libc next
+        # flushes it -- at exit, after fd 1 is the caller's again, unless it is pushed out NOW while fd 1 still is stderr
         sys.stdout.flush()
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except (OSError, AttributeError):  # pragma: no cover
+            pass
+
+    def emit(line):
+        flush_all()
         os.dup2(real_stdout_fd, 1)
         print(line, flush=True)
         os.dup2(2, 1)                   # whatever teardown prints is not part of the line either
@@ -341,7 +402,7 @@ def main(argv=None, model_factory=None):
     try:
         _run(args, world, rank, world_size_env, model_factory, emit)
     finally:                            # in-process callers (tests) get their fd 1 back, and the duplicate does not leak
-        sys.stdout.flush()
+        flush_all()
         os.dup2(real_stdout_fd, 1)
         os.close(real_stdout_fd)
 
@@ -653,23 +714,37 @@ def _run(args, world, rank, world_size_env, model_factory, emit):
             res["packed_captions"] = {"error": repr(e)}
         finally:
             model.engine.set_text_packing(False)
-        # larger per-GPU batches of the same step (the engine's asymptote; inputs generated on the device)
+        # larger per-GPU batches of the same step (inputs generated on the device).  The engine runs a call of B >= 2 * pass_batch samples
+        # as equal back-to-back passes (plipmi_config.pass_batch, 256 for this model: one pass's activations stay in the Infinity Cache);
+        # `one_pass` is the A/B with the splitting off (pass_batch = -1: round 5's behaviour)
         try:
             scal = {}
             for Bb in (512, 1024):
-                mb = PlipModel(cfg, sd, device=dev, dtype=args.dtype, max_batch=Bb)
                 g = torch.Generator(device=dev).manual_seed(5)
                 pxb = torch.randn((Bb, 3, cfg.image_size, cfg.image_size), generator=g, device=dev)
                 ib, mbk = W.synthetic_ids(cfg, Bb, seed=2000)
                 ib, mbk = torch.from_numpy(ib).to(dev), torch.from_numpy(mbk).to(dev)
-                dtb, _ = timed_steps(lambda: sharded_pair_logits(mb, pxb, ib, mbk, overlap=bool(args.overlap), equal_shards=True),
-                                     max(4, args.steps // 2), dev, 2)
-                scal[f"bs{Bb}"] = {"pairs_per_s": round(Bb / dtb, 1), "ms_per_step": round(dtb * 1e3, 3)}
-                mb.engine.close()
-                del mb, pxb
+                row = {}
+                for label, kw in (("passes", {}), ("one_pass", {"pass_batch": -1})):
+                    mb = PlipModel(cfg, sd, device=dev, dtype=args.dtype, max_batch=Bb, **kw)
+                    dtb, _ = timed_steps(lambda: sharded_pair_logits(mb, pxb, ib, mbk, overlap=bool(args.overlap), equal_shards=True),
+                                         args.steps, dev, 3)
+                    row[label] = {"pairs_per_s": round(Bb / dtb, 1), "ms_per_step": round(dtb * 1e3, 3)}
+                    mb.engine.close()
+                    del mb
+                scal[f"bs{Bb}"] = {**row["passes"], "one_pass": row["one_pass"]}
+                del pxb
             res["batch_scaling"] = scal
         except Exception as e:  # pragma: no cover
             res["batch_scaling"] = {"error": repr(e)}
+        # "report with and without H2D of inputs".  The same step with the inputs starting in PINNED HOST memory: a
+        # copy stream moves batch k+1 (pixels + ids + mask) into the second of two device buffers while the towers run on batch k -- what
+        # plip_amd/pipeline.py does for PLIP.encode_images.  fp32 pixels (154 MB per step: what the reference hands over, plip.py:49) and
+        # native uint8 tiles (38.5 MB; normalisation fused on the GPU).  Never `value`.
+        try:
+            res["h2d_inclusive"] = h2d_inclusive(model, cfg, px, ids, mask, args.steps, args.warmup, bool(args.overlap))
+        except Exception as e:  # pragma: no cover
+            res["h2d_inclusive"] = {"error": repr(e)}
         # one GPU's share of BASELINE.json configs[4] (ViT-L/14@336, bs=512 over 8 GPUs = 64 pairs per GPU), same dtype
         try:
             cl = get_config("ViT-L/14@336px")

@@ -42,7 +42,8 @@
 extern "C" {
 #endif
 
-#define PLIPMI_VERSION 400 /* 0.4.0: plipmi_config starts with `struct_size` (the struct can grow at its tail without breaking
+#define PLIPMI_VERSION 410 /* 0.4.1: `pass_batch` appended to plipmi_config (a 0.4.0 caller's shorter struct means 0 = automatic);
+                            * 0.4.0: plipmi_config starts with `struct_size` (the struct can grow at its tail without breaking
                             * callers compiled against an older header); test / A-B hooks moved to plipmi_test.h
                             * (0.3.1: `text_f16_layers`, PLIPMI_ERR_TOKEN_ID; 0.3.0: `flags`, `graph_batch`, PLIPMI_F16) */
 
@@ -117,6 +118,12 @@ typedef struct plipmi_config {
                             * rest of the tower and the whole image tower on bf16.  The bf16 engine's embedding error is mostly
                             * operand rounding in the text tower's first blocks; 0 = a pure bf16 engine,
                             * t_layers = PLIPMI_FLAG_TEXT_TOWER_F16.  The residual stream stays exact fp32 across the switch. */
+  int32_t pass_batch;      /* An encode call of B samples runs as ceil(B / pass_batch) back-to-back passes of equal size on the
+                            * caller's stream once B >= 2 * pass_batch, so that one pass's per-block activations stay resident in the
+                            * 256 MiB Infinity Cache however large the caller's batch is (the reference's `batch_size` is the
+                            * caller's, plip.py:31,55).  Same bits either way: a row's embedding does not depend on the batch it
+                            * travels in.  0 = automatic (the largest multiple of 32 samples whose per-block working set fits,
+                            * 256 for ViT-B/32; no splitting for towers where even 128 samples do not fit), < 0 = never split. */
 } plipmi_config;
 
 /* One pre-LN transformer block, HF CLIPEncoderLayer naming; all DEVICE pointers

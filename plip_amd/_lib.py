@@ -20,7 +20,7 @@ class Config(C.Structure):
         "struct_size", "image_size", "patch_size", "v_width", "v_layers", "v_heads", "v_mlp", "vocab_size",
         "context_length", "t_width", "t_layers", "t_heads", "t_mlp", "projection_dim")] + [
         ("layer_norm_eps", C.c_float), ("compute_dtype", C.c_int32), ("max_batch", C.c_int32), ("flags", C.c_int32),
-        ("graph_batch", C.c_int32), ("text_f16_layers", C.c_int32)]
+        ("graph_batch", C.c_int32), ("text_f16_layers", C.c_int32), ("pass_batch", C.c_int32)]
 
 
 _LAYER_FIELDS = ("ln1_w", "ln1_b", "q_w", "q_b", "k_w", "k_b", "v_w", "v_b", "o_w", "o_b",

@@ -143,6 +143,11 @@ struct plipmi_engine {
   // reference drives zero_shot_classification / retrieval at batch 8 (plip.py:90-91,112).  Results of the two regimes differ
   // by fp32 summation order only; inside a regime a row's embedding does not depend on the batch it arrives in.
   int latency_batch = 0;
+  // plipmi_config.pass_batch resolved: an encode call of B >= 2 * pass_batch samples runs as equal back-to-back passes of at most
+  // pass_batch (0 = never split).  A pass's per-block activations (qkv, att, mlp, the residual planes) then stay in the 256 MiB Infinity
+  // Cache whatever the caller's batch: at bs = 512 / 1024 in ONE pass the ViT-B/32 step ran 8 % / 3 % under the bs = 256 rate
+  // (BENCH_r05 batch_scaling).  Same bits: a row's embedding does not depend on the batch it travels in.
+  int pass_batch = 0;
   std::map<std::tuple<int, int, int, int, int>, GraphEntry> graphs;
   unsigned graphs_epoch = 0;  // g_hook_epoch the captured graphs belong to
   void* g_vin = nullptr;      // staged image input (fp32 pixels or uint8 tiles) [graph_batch_cap, 3, H, W] x 4 B
@@ -626,6 +631,13 @@ int graph_or_eager(plipmi_handle h, int kind, int B, int normalize, int eos, int
   return PLIPMI_OK;
 }
 
+// plipmi_config.pass_batch: how many equal passes an encode call of B samples runs as (1 = the whole batch at once), and the
+// rows of pass i -- the first B % n passes take one sample more
+int passes_of(const plipmi_engine* h, int B) {
+  return (h->pass_batch > 0 && B >= 2 * h->pass_batch) ? (B + h->pass_batch - 1) / h->pass_batch : 1;
+}
+int pass_rows(int B, int n, int i) { return B / n + (i < B % n ? 1 : 0); }
+
 }  // namespace
 
 extern "C" {
@@ -690,6 +702,14 @@ int plipmi_create(const plipmi_config* cfg, const plipmi_weights* w, void* strea
   e->pooled_last = e->ln_fold && !(g.flags & PLIPMI_FLAG_DENSE_LAST_BLOCK);
   e->text_pack = e->pooled_last && (g.flags & PLIPMI_FLAG_PACK_CAPTIONS);
   e->latency_batch = e->half() ? kLatencyBatch : 0;
+  {
+    // per-sample bytes of one block's activations in the larger tower: q/k/v (3D) + attention output (D) + the two residual planes
+    // (2D) + the MLP hidden (F), 16-bit each (the fp32 engine: twice that and no planes -- the same rule errs on the safe side)
+    auto per_sample = [&](int S, int D, int F) { return (double)S * (3.0 * D + D + 2.0 * D + F) * (double)(g.compute_dtype == PLIPMI_F32 ? 4 : 2); };
+    const double ps = std::max(per_sample(tokens, g.v_width, g.v_mlp), per_sample(g.context_length, g.t_width, g.t_mlp));
+    const int fit = (int)(208e6 / ps) / 32 * 32;       // 208 MB: the cache minus a tower's block weights and the other tower's share
+    e->pass_batch = g.pass_batch > 0 ? g.pass_batch : (g.pass_batch == 0 && fit >= 128) ? fit : 0;
+  }
   e->graph_batch_cap = std::min(g.max_batch, 32);
   e->graph_batch = g.graph_batch < 0 ? 0 : g.graph_batch == 0 ? e->graph_batch_cap : std::min(g.graph_batch, e->graph_batch_cap);
   e->np = tokens - 1;
@@ -771,6 +791,15 @@ int plipmi_encode_image(plipmi_handle h, const float* pixels, int B, float* out,
   if (!pixels || !out) return fail(PLIPMI_ERR_INVALID, "null pixels/out");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const size_t n = (size_t)B * 3 * h->cfg.image_size * h->cfg.image_size;
+  if (const int np_ = passes_of(h, B); np_ > 1) {
+    const size_t per = (size_t)3 * h->cfg.image_size * h->cfg.image_size;
+    for (int b0 = 0, i = 0; i < np_; ++i) {
+      const int nb = pass_rows(B, np_, i);
+      RUN(image_forward(h, pixels + (size_t)b0 * per, nullptr, nb, out + (size_t)b0 * h->cfg.projection_dim, normalize, s));
+      b0 += nb;
+    }
+    return PLIPMI_OK;
+  }
   return graph_or_eager(h, 0, B, normalize != 0, 0, 0, s, pixels, n * 4, h->g_vin, nullptr, 0, out, h->g_vout,
                         [&](const void* in, const int64_t*, float* o, hipStream_t st) {
                           return image_forward(h, reinterpret_cast<const float*>(in), nullptr, B, o, normalize, st); });
@@ -782,6 +811,15 @@ int plipmi_encode_image_u8(plipmi_handle h, const uint8_t* tiles, int B, float* 
   if (!tiles || !out) return fail(PLIPMI_ERR_INVALID, "null tiles/out");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const size_t n = (size_t)B * 3 * h->cfg.image_size * h->cfg.image_size;
+  if (const int np_ = passes_of(h, B); np_ > 1) {
+    const size_t per = (size_t)3 * h->cfg.image_size * h->cfg.image_size;
+    for (int b0 = 0, i = 0; i < np_; ++i) {
+      const int nb = pass_rows(B, np_, i);
+      RUN(image_forward(h, nullptr, tiles + (size_t)b0 * per, nb, out + (size_t)b0 * h->cfg.projection_dim, normalize, s));
+      b0 += nb;
+    }
+    return PLIPMI_OK;
+  }
   return graph_or_eager(h, 1, B, normalize != 0, 0, 0, s, tiles, n, h->g_vin, nullptr, 0, out, h->g_vout,
                         [&](const void* in, const int64_t*, float* o, hipStream_t st) {
                           return image_forward(h, nullptr, reinterpret_cast<const uint8_t*>(in), B, o, normalize, st); });
@@ -795,6 +833,16 @@ int plipmi_encode_text(plipmi_handle h, const int64_t* ids, const int64_t* atten
   if (!ids || !out) return fail(PLIPMI_ERR_INVALID, "null ids/out");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const size_t n = (size_t)B * h->cfg.context_length * 8;
+  if (const int np_ = passes_of(h, B); np_ > 1) {
+    const size_t per = (size_t)h->cfg.context_length;
+    for (int b0 = 0, i = 0; i < np_; ++i) {
+      const int nb = pass_rows(B, np_, i);
+      RUN(text_forward(h, ids + (size_t)b0 * per, attention_mask ? attention_mask + (size_t)b0 * per : nullptr, nb, eos_token_id,
+                       out + (size_t)b0 * h->cfg.projection_dim, normalize, s));
+      b0 += nb;
+    }
+    return PLIPMI_OK;
+  }
   return graph_or_eager(h, 2, B, normalize != 0, eos_token_id, attention_mask != nullptr, s, ids, n, h->g_tin,
                         attention_mask, n, out, h->g_tout,
                         [&](const void* in, const int64_t* m, float* o, hipStream_t st) {

@@ -44,13 +44,15 @@ class Engine:
                  max_batch: int = 256, *, ln_fold: bool = True, pooled_last_block: bool = True,
                  pack_captions: bool = False, mfma_attention: bool = True, graph_batch: Optional[int] = None,
                  text_f16: bool = False, text_f16_layers: Optional[int] = None, latency_batch: int = 0,
-                 _config_struct_size: Optional[int] = None):
+                 pass_batch: Optional[int] = None, _config_struct_size: Optional[int] = None):
         """``ln_fold`` / ``pooled_last_block`` / ``mfma_attention`` = False select the A/B forms of the 16-bit engines
         (separate LayerNorm kernels, the last block on every token, the exact VALU attention kernel);
         ``text_f16`` (bf16 engine only): the text tower runs on IEEE-half operands, the image tower stays bf16;
         ``text_f16_layers`` (bf16 engine only): only that many LEADING text blocks do (None = the engine default,
         ``DEFAULT_TEXT_F16_LAYERS``; 0 = a pure bf16 engine) -- plipmi_config.text_f16_layers;
         ``graph_batch``: None = default small-batch hipGraph replay (<= 32 samples), 0 = never, n = up to n samples.
+        ``pass_batch``: calls of at least twice that many samples run as equal back-to-back passes of at most that many
+        (plipmi_config.pass_batch: None = automatic -- 256 for ViT-B/32 --, 0 / negative = never split); same bits either way.
         ``latency_batch``: batches of at most that many samples run on the split-K small-M GEMMs (plipmi_set_latency_batch;
         faster up to batch 8, embeddings then differ from the big-batch path's by up to 6e-4 -- off by default).
         All of it is per-handle configuration (include/plipmi.h plipmi_config.flags): no environment variables.
@@ -92,7 +94,7 @@ class Engine:
             c = _lib.Config(C.sizeof(_lib.Config), cfg.image_size, cfg.patch_size, cfg.v_width, cfg.v_layers, cfg.v_heads, cfg.v_mlp,
                             cfg.vocab_size, cfg.context_length, cfg.t_width, cfg.t_layers, cfg.t_heads, cfg.t_mlp,
                             cfg.projection_dim, cfg.layer_norm_eps, self.dtype_code, self.max_batch, self.flags, gb,
-                            self.text_f16_layers)
+                            self.text_f16_layers, 0 if pass_batch is None else (int(pass_batch) if int(pass_batch) > 0 else -1))
             if _config_struct_size is not None:
                 c.struct_size = int(_config_struct_size)
             w = _lib.Weights()
@@ -212,8 +214,12 @@ class Engine:
         the towers are independent (separate workspaces), so the tail of one tower's GEMM grid -- 150..600
         workgroups over 256 CUs -- is filled by the other tower's kernels instead of idling."""
         if not overlap:
-            return self.encode_image(pixels, normalize), self.encode_text(input_ids, attention_mask, normalize)
+            return self._encode_image_any(pixels, normalize), self.encode_text(input_ids, attention_mask, normalize)
         return self._encode_pair_two_streams(pixels, input_ids, attention_mask, normalize)
+
+    def _encode_image_any(self, pixels: torch.Tensor, normalize: bool):
+        """fp32 NCHW pixels or native uint8 [B,H,W,3] tiles (normalisation fused on the GPU) -- the two image inputs of the path"""
+        return self.encode_image_u8(pixels, normalize) if pixels.dtype == torch.uint8 else self.encode_image(pixels, normalize)
 
     def check_async(self, synchronize: bool = True) -> None:
         """Raise IndexError if an earlier ``encode_text`` was given a token id outside the vocabulary -- the reference's
@@ -252,11 +258,11 @@ class Engine:
                 self._vis = torch.cuda.Stream(device=self.device, priority=-1)
             self._vis.wait_stream(main)
             with torch.cuda.stream(self._vis):
-                img = self.encode_image(pixels, normalize)
+                img = self._encode_image_any(pixels, normalize)
             main.wait_stream(self._vis)
             img.record_stream(main)
         else:
-            img = self.encode_image(pixels, normalize)
+            img = self._encode_image_any(pixels, normalize)
         main.wait_stream(side)
         txt.record_stream(main)
         return img, txt

@@ -325,6 +325,43 @@ def test_error_behaviour(engines):
     assert model.get_image_features(pixel_values=torch.zeros(0, 3, cfg.image_size, cfg.image_size)).shape == (0, cfg.projection_dim)
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+def test_large_batches_run_as_equal_passes_with_the_same_bits(engines, dtype):
+    """plipmi_config.pass_batch (throughput must not fall with the caller's batch): a call of B >= 2 * pass_batch
+    samples runs as ceil(B / pass_batch) equal back-to-back passes, and the embeddings are the bits of the one-pass engine --
+    fp32 pixels, uint8 tiles, captions with a mask; a call under 2 * pass_batch stays one pass; 0 resolves to "no splitting" on the
+    tiny towers' 1 GB-per-several-thousand-samples working set and to 256 on ViT-B/32."""
+    from plip_amd.model import PlipModel
+    from plip_amd import weights as W
+    _, cfg, sd, *_ = engines("tiny_b6", dtype)
+    B = 41                                                     # three passes of 14 / 14 / 13 at pass_batch 16
+    px = torch.from_numpy(W.synthetic_pixels(cfg, B, seed=5))
+    ids_np, mask_np = W.synthetic_ids(cfg, B, seed=6)
+    ids, mask = torch.from_numpy(ids_np), torch.from_numpy(mask_np)
+    rs = np.random.RandomState(3)
+    tiles = torch.from_numpy(rs.randint(0, 256, size=(B, cfg.image_size, cfg.image_size, 3), dtype=np.uint8))
+    one = PlipModel(cfg, sd, dtype=dtype, max_batch=64, pass_batch=-1)
+    split = PlipModel(cfg, sd, dtype=dtype, max_batch=64, pass_batch=16)
+    try:
+        for m in (one, split):
+            m.got = (m.engine.encode_image(px, True), m.engine.encode_image_u8(tiles, False), m.engine.encode_text(ids, mask, True),
+                     m.engine.encode_image(px[:31], False), m.engine.encode_text(ids[:31], None, False))
+            torch.cuda.synchronize()
+        for a, b in zip(one.got, split.got):
+            assert a.shape == b.shape and torch.equal(a, b)
+        rows = []
+        with split.engine.profile(rows):                       # 41 samples: 3 passes -> 3 patch GEMMs; 31 < 2 * 16: one
+            split.engine.encode_image(px, True)
+        assert sum(r["calls"] for r in rows if "patch_embed" in r["name"]) == 3
+        rows = []
+        with split.engine.profile(rows):
+            split.engine.encode_image(px[:31], True)
+        assert sum(r["calls"] for r in rows if "patch_embed" in r["name"]) == 1
+    finally:
+        one.engine.close()
+        split.engine.close()
+
+
 def test_config_struct_size_lets_the_struct_grow(engines):
     """plipmi_config starts with its own size: a caller compiled against an OLDER, shorter header -- one that
     ends at max_batch -- gets every later member as 0 (the product defaults), not whatever lies behind its struct; sizes

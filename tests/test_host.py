@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     product = open(os.path.join(ROOT, "include", "plipmi.h")).read()
     for hook in ("plipmi_gemm_nt", "plipmi_attention", "plipmi_test_force_gemm_tile", "plipmi_test_reset_hooks", "plipmi_recode_planes", "plipmi_debug_hidden"):
         assert not re.search(r"\b%s\s*\(" % hook, product), hook
-    assert lib.plipmi_version() == 400
+    assert lib.plipmi_version() == 410
     names = []
     i = 0
     while lib.plipmi_gemm_variant_name(i):
@@ -78,7 +78,7 @@ def test_struct_layouts_match_header():
     import ctypes as C
 
     from plip_amd import _lib
-    assert C.sizeof(_lib.Config) == 20 * 4
+    assert C.sizeof(_lib.Config) == 21 * 4
     assert _lib.Config._fields_[0][0] == "struct_size"      # plipmi_create reads that many bytes of the caller's struct
     assert C.sizeof(_lib.LayerWeights) == 16 * 8
     assert C.sizeof(_lib.Weights) == 15 * 8
