@@ -293,14 +293,19 @@ def logits_error_vs_hf_golden(model, cfg, sd, px, ids, mask, B, arch, fixture="v
             "pairs": n, "logits_compared": n * n}
 
 
-def h2d_inclusive(model, cfg, px, ids, mask, steps, warmup, overlap):
+def h2d_inclusive(model, cfg, px, ids, mask, steps, warmup, overlap, copy=None):
     """pairs/s of the step when every batch starts in pinned host memory (double-buffered copy stream, overlapped with the towers)"""
     from plip_amd.dist import sharded_pair_logits
     dev = px.device
     B = px.shape[0]
-    copy = torch.cuda.Stream(device=dev)
     main = torch.cuda.current_stream(dev)
     out = {}
+    # HIP streams share a handful of hardware queues: a copy stream that lands on the queue of one of the tower streams runs its
+    # copies IN ORDER with that tower's kernels instead of beside them (profiles/r06_h2d_copy_stream.txt: 4.56 ... 7.5 ms per step
+    # depending on which stream the pool hands out).  A high-priority stream lives in a queue class of its own; two ordinary ones are
+    # tried beside it and the one that overlaps best on a 4-step trial is kept.
+    candidates = [copy] if copy is not None else [torch.cuda.Stream(device=dev, priority=-1), torch.cuda.Stream(device=dev),
+                                                   torch.cuda.Stream(device=dev)]
     tiles = torch.from_numpy(np.random.RandomState(7).randint(0, 256, size=(B, cfg.image_size, cfg.image_size, 3), dtype=np.uint8))
     for label, host_img in (("fp32_pixels", px.cpu()), ("u8_tiles", tiles)):
         host = [(host_img.clone().pin_memory(), ids.cpu().pin_memory(), mask.cpu().pin_memory()) for _ in range(2)]
@@ -310,6 +315,7 @@ def h2d_inclusive(model, cfg, px, ids, mask, steps, warmup, overlap):
 
         def fetch(k):
             slot = k & 1
+            copy = fetch.stream
             with torch.cuda.stream(copy):
                 if consumed[slot] is not None:
                     copy.wait_event(consumed[slot])           # the towers that read this slot's previous batch are done
@@ -328,16 +334,26 @@ def h2d_inclusive(model, cfg, px, ids, mask, steps, warmup, overlap):
                 consumed[slot] = torch.cuda.Event()
                 consumed[slot].record(main)
 
+        def timed(n):
+            torch.cuda.synchronize(dev)
+            consumed[0] = consumed[1] = None
+            t0 = time.perf_counter()
+            run(n)
+            torch.cuda.synchronize(dev)
+            return (time.perf_counter() - t0) / n
+
+        trial = []
+        for st in candidates:
+            fetch.stream = st
+            run(2)
+            trial.append(timed(4))
+        fetch.stream = candidates[int(np.argmin(trial))]
         run(max(2, warmup))
-        torch.cuda.synchronize(dev)
-        consumed[0] = consumed[1] = None
-        t0 = time.perf_counter()
-        run(steps)
-        torch.cuda.synchronize(dev)
-        dt = (time.perf_counter() - t0) / steps
+        dt = timed(steps)
         nbytes = sum(t.numel() * t.element_size() for t in host[0])
         out[label] = {"pairs_per_s": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 3), "host_bytes_per_step": nbytes,
-                      "pcie_GBps": round(nbytes / dt / 1e9, 2)}
+                      "pcie_GBps": round(nbytes / dt / 1e9, 2),
+                      "copy_stream_trial_ms": [round(t * 1e3, 3) for t in trial]}
         del host, devb
     out["note"] = ("inputs start in pinned host memory every step; a copy stream fills the second of two device buffers while the towers "
                    "run on the first (the pattern of plip_amd/pipeline.py); `value` above is the HBM-resident rate")
@@ -724,14 +740,20 @@ def _run(args, world, rank, world_size_env, model_factory, emit):
                 pxb = torch.randn((Bb, 3, cfg.image_size, cfg.image_size), generator=g, device=dev)
                 ib, mbk = W.synthetic_ids(cfg, Bb, seed=2000)
                 ib, mbk = torch.from_numpy(ib).to(dev), torch.from_numpy(mbk).to(dev)
-                row = {}
-                for label, kw in (("passes", {}), ("one_pass", {"pass_batch": -1})):
-                    mb = PlipModel(cfg, sd, device=dev, dtype=args.dtype, max_batch=Bb, **kw)
-                    dtb, _ = timed_steps(lambda: sharded_pair_logits(mb, pxb, ib, mbk, overlap=bool(args.overlap), equal_shards=True),
-                                         args.steps, dev, 3)
-                    row[label] = {"pairs_per_s": round(Bb / dtb, 1), "ms_per_step": round(dtb * 1e3, 3)}
+                # the two engines interleaved, three rounds each: the first window behind an engine's creation runs slower than its later ones
+                arms = {"passes": PlipModel(cfg, sd, device=dev, dtype=args.dtype, max_batch=Bb),
+                        "one_pass": PlipModel(cfg, sd, device=dev, dtype=args.dtype, max_batch=Bb, pass_batch=-1)}
+                times = {k: [] for k in arms}
+                for rnd in range(3):
+                    for label, mb in arms.items():
+                        dtb, _ = timed_steps(lambda: sharded_pair_logits(mb, pxb, ib, mbk, overlap=bool(args.overlap), equal_shards=True),
+                                             max(4, args.steps // 2), dev, 2)
+                        times[label].append(dtb)
+                row = {k: {"pairs_per_s": round(Bb / float(np.median(v)), 1), "ms_per_step": round(float(np.median(v)) * 1e3, 3),
+                           "rounds_ms": [round(t * 1e3, 3) for t in v]} for k, v in times.items()}
+                for mb in arms.values():
                     mb.engine.close()
-                    del mb
+                del arms
                 scal[f"bs{Bb}"] = {**row["passes"], "one_pass": row["one_pass"]}
                 del pxb
             res["batch_scaling"] = scal

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define PLIPMI_VERSION 410 /* 0.4.1: `pass_batch` appended to plipmi_config (a 0.4.0 caller's shorter struct means 0 = automatic);
+#define PLIPMI_VERSION 410 /* 0.4.1: `pass_batch` appended to the config struct -- a 0.4.0 caller's shorter struct means 0 = automatic;
                             * 0.4.0: plipmi_config starts with `struct_size` (the struct can grow at its tail without breaking
                             * callers compiled against an older header); test / A-B hooks moved to plipmi_test.h
                             * (0.3.1: `text_f16_layers`, PLIPMI_ERR_TOKEN_ID; 0.3.0: `flags`, `graph_batch`, PLIPMI_F16) */

@@ -49,10 +49,12 @@ int plipmi_test_remap_gemm_tile(int from, int to);
 int plipmi_test_fused_qkv_attention(int mode);
 int plipmi_test_patch_gather(int on);
 void plipmi_test_reset_hooks(void);
-/* Test hook: the residual-stream planes {hi, lo} (n values, n % 4 == 0) from `from_dtype`'s split format to `to_dtype`'s
- * (PLIPMI_BF16 / PLIPMI_F16), in place -- what a text tower with plipmi_config.text_f16_layers does between its f16 and
- * its bf16 blocks.  Exact: both formats hold the fp32 value bit for bit (|x| < 65504). */
-int plipmi_recode_planes(void* hi, void* lo, size_t n, int from_dtype, int to_dtype, void* stream);
+/* Test hook: the residual-stream planes {hi [rows, D] uint16, lo = the 8-bit remainder plane in its blocked layout,
+ * ((rows + 15) / 16) * 16 * D bytes (plip_amd/csrc/common.h lo_plane_off)} from `from_dtype`'s split format to `to_dtype`'s
+ * (PLIPMI_BF16 / PLIPMI_F16), in place -- what a text tower with plipmi_config.text_f16_layers does between its f16 and its
+ * bf16 blocks on the small-M path.  The value is joined and split again: the new hi is the value rounded to the new operand type,
+ * the remainder is rounded once more (2^-16 relative for bf16, 2^-19 for f16).  D % 8 == 0. */
+int plipmi_recode_planes(void* hi, void* lo, size_t rows, int D, int from_dtype, int to_dtype, void* stream);
 /* same call with explicit leading dimensions (in elements) for A [M,K] and W [N,K]: rows may be padded */
 int plipmi_gemm_nt_ld(int dtype, int epilogue, int variant, int M, int N, int K, const void* A, int lda, const void* W,
                       int ldw, const float* bias, float alpha, void* C, void* stream);
@@ -69,11 +71,11 @@ int plipmi_gemm_nt_traced(int dtype, int epilogue, int variant, int M, int N, in
  *                                                     given; W is expected to carry LayerNorm's gain with CENTRED rows
  *                                                     (sum_k W[n,k] = 0), which is what subtracts the row mean
  *   mode 2: C(f32) += A.W^T + bias;  xb_out(h16)[M,N] = C;  st_out [M, N/64, 2] = partials of the updated rows
- *   mode 3: the same update on a residual kept as two 16-bit planes, xb_out = hi (uint16: the value rounded to h16) and
- *           C = lo (int16 remainder; bf16: bits(x) == (hi << 16) + lo, f16: x == hi + lo * 2^(E(hi) - 24)), an EXACT
- *           fp32 value either way (plip_amd/csrc/common.h split_f32): both read and written in place;
- *           st_out as in mode 2.  This is the form the engine runs (an fp32 stream at 8 bytes per element of epilogue
- *           traffic, whose hi plane is the next GEMM's A operand)
+ *   mode 3: the same update on a residual kept as two planes, xb_out = hi (uint16 [M, N]: the value rounded to h16) and
+ *           C = lo (8-bit remainders in the blocked layout of plip_amd/csrc/common.h lo_plane_off, ((M + 15) / 16) * 16 * N bytes;
+ *           bf16: bits(x) ~ (hi << 16) + (lo << 8), f16: x ~ hi + lo * 2^(E(hi) - 18)): the stream at 16 / 19 significand bits,
+ *           both planes read and written in place; st_out as in mode 2.  This is the form the engine runs (6 bytes per element
+ *           of epilogue traffic; the hi plane is the next GEMM's A operand)
  *   mode 4: mode 3 that READS the planes in dtype's split format and WRITES them in the other 16-bit type's (the last f16
  *           block of a bf16 text tower with plipmi_config.text_f16_layers hands the stream over without a re-coding pass) */
 int plipmi_gemm_nt_ln(int dtype, int mode, int variant, int M, int N, int K, const void* A, const void* W, const float* bias,

@@ -58,7 +58,7 @@ TEST_SYMBOLS = {
     "plipmi_test_patch_gather": (_i, [_i]),
     "plipmi_test_reset_hooks": (None, []),
     "plipmi_gemm_variant_built": (_i, [_i, _i]),
-    "plipmi_recode_planes": (_i, [_vp, _vp, C.c_size_t, _i, _i, _vp]),
+    "plipmi_recode_planes": (_i, [_vp, _vp, C.c_size_t, _i, _i, _i, _vp]),
     "plipmi_gemm_nt_ln": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp]),
     "plipmi_gemm_nt_ld": (_i, [_i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _f, _vp, _vp]),
     "plipmi_gemm_nt_traced": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp]),

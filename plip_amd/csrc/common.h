@@ -109,55 +109,76 @@ __device__ __forceinline__ float row8_sum(float v) {
 // LayerNorm statistics travel as per-row PARTIALS over 64-column slices: {sum, M2 = sum (x - sum/64)^2}.  Folding
 // NS slices with Chan's update gives the row mean and the (biased) variance without ever forming E[x^2] - mean^2.
 //
-// The LayerNorm-folded engines keep their fp32 residual stream as TWO 16-bit planes: hi = the value rounded to the engine's
-// 16-bit operand type -- which IS the next GEMM's A operand -- and lo = a signed 16-bit remainder chosen so that the pair
-// reproduces the fp32 value EXACTLY.  No precision is given up against a plain fp32 array; a residual GEMM's epilogue moves
-// 4 + 4 bytes per element instead of 4 + 4 + 2 (fp32 in place plus a separate 16-bit copy).
-//   bf16: hi = nearest bf16 (ties away from zero) = the upper half of the bit pattern after rounding, lo = the signed
-//         remainder of the bit pattern:  bits(x) == (hi << 16) + lo.
-//   f16:  hi = nearest f16 (ties to even, saturating at +-65504), lo = (x - hi) in units of 2^(E - 24) with E the exponent
-//         of hi (at least -14): x - hi is a multiple of ulp32(x) >= that unit and at most half an f16 ulp = 2^13 units, so
-//         it is an integer of at most 14 bits.  Exact for 2^-15 <= |x| <= 65504; below, the absolute error is < 2^-38;
-//         beyond, the stream saturates (the reference's own f16 CUDA path would hold inf there).
-template <typename H> __device__ __forceinline__ void split_f32(float x, unsigned& hi16, unsigned& lo16);
-template <typename H> __device__ __forceinline__ float join_f32(unsigned hi16, unsigned lo16);   // both in the low 16 bits of their words
-template <> __device__ __forceinline__ void split_f32<bf16_t>(float x, unsigned& hi16, unsigned& lo16) {
+// The LayerNorm-folded engines keep their residual stream as TWO planes: hi = the value rounded to the engine's 16-bit operand
+// type -- which IS the next GEMM's A operand, no separate copy exists -- and lo = a signed 8-BIT remainder (round 6; rounds 2-5
+// carried 16 bits, the exact fp32 value).  A residual GEMM's epilogue then moves 3 + 3 bytes per element instead of 4 + 4: those
+// epilogues are bound by the bytes they move (profiles/r06_bytes_plan.txt (c)).
+//   bf16: hi = nearest bf16 (ties away from zero) = the upper half of the bit pattern after rounding; the remainder of the bit pattern
+//         r = bits(x) - (hi << 16) lies in [-32768, 32767]; lo = round(r / 256) clamped to [-128, 127]:
+//         bits(x') = (hi << 16) + (lo << 8), |x' - x| <= 2^-16 |x| (8 + 8 significand bits; the operand plane itself keeps 8) --
+//         2^-15 in the corner r >= 32640, where the remainder rounds to +128 and is stored as +127 (0.2 % of values).
+//   f16:  hi = nearest f16 (ties to even, saturating at +-65504); lo = round((x - hi) / 2^(E - 18)) clamped to [-128, 127] with E the
+//         exponent of hi (at least -14): x - hi is at most half an f16 ulp = 2^(E - 11) = 128 units.  |x' - x| <= 2^-19 |x|
+//         (11 + 8 bits) for 2^-14 <= |x| <= 65504; beyond, the stream saturates (the reference's own f16 CUDA path would hold inf).
+// The stream is NOT the exact fp32 value any more: every residual update rounds it to 16 (bf16) / 19 (f16) significand bits -- three
+// orders of magnitude below the 2^-9 / 2^-12 rounding of the operands it feeds.  hi is always the correctly rounded operand of the
+// value the epilogue computed in fp32 (the remainder is rounded, never the operand).
+//
+// Memory layout of the lo plane [rows, D] (bytes): blocks of 16 rows x 8 columns = 128 bytes, [row & 7][row >> 3 & 1][column & 7]
+// inside a block, blocks column-major inside a 16-row band: a GEMM epilogue lane that owns 8 consecutive columns of rows r and
+// r + 8 of a band reads / writes ONE 16-byte piece, and a wave's 64 pieces are 1 KB of contiguous memory (8-byte pieces would go to
+// the fabric one by one through the write-through stores: MI355X_MICROARCH.md, "stores of each flavour").  Planes are allocated
+// for a whole number of bands.
+__host__ __device__ __forceinline__ size_t lo_plane_bytes(size_t rows, size_t D) { return (rows + 15) / 16 * 16 * D; }
+// byte offset of element (m, n); the 8 columns n & ~7 .. of row m are contiguous from lo_plane_off(m, n & ~7, D)
+__device__ __forceinline__ size_t lo_plane_off(size_t m, unsigned n, unsigned D) {
+  return (m >> 4) * 16 * (size_t)D + (size_t)(n >> 3) * 128 + (m & 7) * 16 + ((m >> 3) & 1) * 8 + (n & 7);
+}
+template <typename H> __device__ __forceinline__ void split_f32(float x, unsigned& hi16, unsigned& lo8);   // lo8: the remainder's two's complement in the low 8 bits
+template <typename H> __device__ __forceinline__ float join_f32(unsigned hi16, int lo8);                  // lo8 sign-extended
+template <> __device__ __forceinline__ void split_f32<bf16_t>(float x, unsigned& hi16, unsigned& lo8) {
   const unsigned u = __builtin_bit_cast(unsigned, x), t = u + 0x8000u;
   hi16 = t >> 16;
-  lo16 = (u - (t & 0xffff0000u)) & 0xffffu;
+  const int r = (int)(u - (t & 0xffff0000u));                    // [-32768, 32767]
+  const int q = (r + 128) >> 8;                                  // round to nearest, [-128, 128]
+  lo8 = (unsigned)(q > 127 ? 127 : q) & 0xffu;
 }
-template <> __device__ __forceinline__ float join_f32<bf16_t>(unsigned hi16, unsigned lo16) {
-  return __builtin_bit_cast(float, (hi16 << 16) + (unsigned)(((int)(lo16 << 16)) >> 16));
+template <> __device__ __forceinline__ float join_f32<bf16_t>(unsigned hi16, int lo8) {
+  return __builtin_bit_cast(float, (hi16 << 16) + (unsigned)(lo8 << 8));
 }
 __device__ __forceinline__ unsigned f16_plane_exp(float hf) {   // biased fp32 exponent of the f16 value, floor 127 - 14
   const unsigned eb = (__builtin_bit_cast(unsigned, hf) >> 23) & 0xffu;
   return eb < 113u ? 113u : eb;
 }
-template <> __device__ __forceinline__ void split_f32<f16_t>(float x, unsigned& hi16, unsigned& lo16) {
+template <> __device__ __forceinline__ void split_f32<f16_t>(float x, unsigned& hi16, unsigned& lo8) {
   const f16_t h = (f16_t)sat_f16(x);
   const float hf = (float)h;
-  const float scale = __builtin_bit_cast(float, (278u - f16_plane_exp(hf)) << 23);   // 2^(24 - E)
-  const float r = __builtin_amdgcn_fmed3f((x - hf) * scale, -32768.0f, 32767.0f);
+  const float scale = __builtin_bit_cast(float, (272u - f16_plane_exp(hf)) << 23);   // 2^(18 - E)
+  const float r = __builtin_amdgcn_fmed3f(__builtin_rintf((x - hf) * scale), -128.0f, 127.0f);
   hi16 = (unsigned)__builtin_bit_cast(unsigned short, h);
-  lo16 = (unsigned)(int)r & 0xffffu;
+  lo8 = (unsigned)(int)r & 0xffu;
 }
-template <> __device__ __forceinline__ float join_f32<f16_t>(unsigned hi16, unsigned lo16) {
+template <> __device__ __forceinline__ float join_f32<f16_t>(unsigned hi16, int lo8) {
   const float hf = (float)__builtin_bit_cast(f16_t, (unsigned short)hi16);
-  const float unit = __builtin_bit_cast(float, (f16_plane_exp(hf) - 24u) << 23);     // 2^(E - 24)
-  return fmaf((float)(((int)(lo16 << 16)) >> 16), unit, hf);
+  const float unit = __builtin_bit_cast(float, (f16_plane_exp(hf) - 18u) << 23);     // 2^(E - 18)
+  return fmaf((float)lo8, unit, hf);
 }
+// byte k (0 .. 3) of a word, sign-extended
+__device__ __forceinline__ int sbyte(unsigned w, int k) { return (int)(w << (24 - 8 * k)) >> 24; }
+// 4 consecutive columns n .. n + 3 (n % 4 == 0) of row m: 8 bytes of hi, 4 bytes of lo
 template <typename H>
-__device__ __forceinline__ void store4_split(unsigned short* hi, unsigned short* lo, float a, float b, float c, float d) {
+__device__ __forceinline__ void store4_split(unsigned short* hi, unsigned char* lo, size_t m, unsigned n, unsigned D, float a, float b, float c, float d) {
   unsigned h0, h1, h2, h3, l0, l1, l2, l3;
   split_f32<H>(a, h0, l0); split_f32<H>(b, h1, l1); split_f32<H>(c, h2, l2); split_f32<H>(d, h3, l3);
-  *reinterpret_cast<uint2*>(hi) = make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));
-  *reinterpret_cast<uint2*>(lo) = make_uint2(l0 | (l1 << 16), l2 | (l3 << 16));
+  *reinterpret_cast<uint2*>(hi + m * D + n) = make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));
+  *reinterpret_cast<unsigned*>(lo + lo_plane_off(m, n, D)) = l0 | (l1 << 8) | (l2 << 16) | (l3 << 24);
 }
 template <typename H>
-__device__ __forceinline__ float4 load4_split(const unsigned short* hi, const unsigned short* lo) {
-  const uint2 h = *reinterpret_cast<const uint2*>(hi), l = *reinterpret_cast<const uint2*>(lo);
-  return make_float4(join_f32<H>(h.x & 0xffffu, l.x & 0xffffu), join_f32<H>(h.x >> 16, l.x >> 16),
-                     join_f32<H>(h.y & 0xffffu, l.y & 0xffffu), join_f32<H>(h.y >> 16, l.y >> 16));
+__device__ __forceinline__ float4 load4_split(const unsigned short* hi, const unsigned char* lo, size_t m, unsigned n, unsigned D) {
+  const uint2 h = *reinterpret_cast<const uint2*>(hi + m * D + n);
+  const unsigned l = *reinterpret_cast<const unsigned*>(lo + lo_plane_off(m, n, D));
+  return make_float4(join_f32<H>(h.x & 0xffffu, sbyte(l, 0)), join_f32<H>(h.x >> 16, sbyte(l, 1)),
+                     join_f32<H>(h.y & 0xffffu, sbyte(l, 2)), join_f32<H>(h.y >> 16, sbyte(l, 3)));
 }
 
 constexpr int kLnSlice = 64;

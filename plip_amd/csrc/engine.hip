@@ -88,8 +88,8 @@ struct Tower {
   // workspace
   float* x = nullptr;
   void *h = nullptr, *qkv = nullptr, *att = nullptr, *mlp = nullptr;
-  // LayerNorm-folded engine: the residual stream lives as two 16-bit planes (common.h split_f32): h = its operand-type plane
-  // (the A operand of the q/k/v and fc1 GEMMs), lo = the int16 remainder (the pair == the fp32 value exactly); x only holds the
+  // LayerNorm-folded engine: the residual stream lives as two planes (common.h split_f32): h = its operand-type plane
+  // (the A operand of the q/k/v and fc1 GEMMs), lo = the 8-bit remainder plane (blocked layout); x only holds the
   // embedding rows before the first LayerNorm and a joined copy where something needs plain fp32.  st = the rows'
   // statistics partials [M, D/64, 2]
   float* st = nullptr;
@@ -251,7 +251,7 @@ void carve(plipmi_engine* e, Carver& c) {
     const size_t M = B * t->S;
     t->x = c.take<float>(M * D, 4);
     t->h = c.take<void>(M * D, es);
-    if (e->ln_fold) { t->st = c.take<float>(M * (D / kLnSlice) * 2, 4); t->lo = c.take<void>(M * D, 2); }
+    if (e->ln_fold) { t->st = c.take<float>(M * (D / kLnSlice) * 2, 4); t->lo = c.take<void>(lo_plane_bytes(M, D), 1); }
     if (e->ln_fold && t == &e->txt) {
       t->cu = c.take<int>(B + 1, 4); t->rowmap = c.take<int>(M, 4); t->mdev = c.take<int>(1, 4);
     }
@@ -335,10 +335,10 @@ int run_gemm(plipmi_engine* e, const Tower& t, int epi, const void* A, const voi
   if (skinny) ++role;
   skinny = skinny || (t.small && !m_dev);   // latency path: the whole tower of a small batch (packed rows keep the big kernels)
   const char* name = "gemm_nt";
-  // algorithmic bytes: operands once, output once (bf16 outputs 2 B, fp32 residual read + written -- as one array or as two
+  // algorithmic bytes: operands once, output once (bf16 outputs 2 B, residual read + written -- as one fp32 array or as the 16 + 8-bit
   // 16-bit planes --, + bf16 copy when EPI_RESID_EMIT writes one)
   const double out_bytes = epi_is_colwise(epi) ? (double)M * N * e->esz
-                           : (double)M * N * (epi_is_resid(epi) ? 8.0 : 4.0) + (epi == EPI_RESID_EMIT ? (double)M * N * 2.0 : 0.0);
+                           : (double)M * N * (epi == EPI_RESID_SPLIT ? 6.0 : epi_is_resid(epi) ? 8.0 : 4.0) + (epi == EPI_RESID_EMIT ? (double)M * N * 2.0 : 0.0);
   Scope sc(e, s, name, 2.0 * M * N * (double)K, ((double)M * K + (double)N * K) * e->esz + out_bytes);
   const int rc = (skinny && e->half() && gemm_skinny_supports(epi, M, N, K))
                      ? gemm_launch_skinny(t.cur, epi, p, s, &name)
@@ -357,8 +357,8 @@ int run_gemm(plipmi_engine* e, const Tower& t, int epi, const void* A, const voi
 int enter_block(plipmi_engine* e, Tower& t, int l, int M, hipStream_t s) {
   t.cur = t.layer_dtype(l);
   if (e->ln_fold && t.planes != t.cur) {
-    Scope sc(e, s, "recode_planes", 0, (double)M * t.D * 8);
-    HIP_TRY(launch_recode_planes(t.h, t.lo, (size_t)M * t.D, t.planes, t.cur, s));
+    Scope sc(e, s, "recode_planes", 0, (double)M * t.D * 6);
+    HIP_TRY(launch_recode_planes(t.h, t.lo, (size_t)M, t.D, t.planes, t.cur, s));
     t.planes = t.cur;
   }
   return PLIPMI_OK;
@@ -400,7 +400,7 @@ int run_layers(plipmi_engine* e, Tower& t, int B, int n_layers, int causal, cons
     return PLIPMI_OK;
   };
   if (e->ln_fold) {
-    // LayerNorm never runs as a pass: the residual stream x = {t.h, t.lo} (bf16 plane + remainder plane, exact fp32) and
+    // LayerNorm never runs as a pass: the residual stream x = {t.h, t.lo} (operand-type plane + 8-bit remainder plane) and
     // t.st = the rows' statistics partials come from x's producer (embedding kernel, or the residual GEMM's epilogue); the
     // consuming GEMMs read the bf16 plane as their A operand, carry LayerNorm's gain, centring and bias in their weights and
     // apply rstd in their epilogues.  HF order (modeling_clip.py:370-381) is unchanged:
@@ -424,8 +424,8 @@ int run_layers(plipmi_engine* e, Tower& t, int B, int n_layers, int causal, cons
     }
     if (!more_follow) {
       if (t.packed) return fail(PLIPMI_ERR_INVALID, "packed rows have no every-token form");   // a consumer of plain fp32 rows follows (the every-token head, plipmi_debug_hidden)
-      Scope sc(e, s, "join_planes", 0, (double)M * D * 8);
-      HIP_TRY(launch_join_planes(t.h, t.lo, t.x, (size_t)M * D, t.planes, s));
+      Scope sc(e, s, "join_planes", 0, (double)M * D * 7);
+      HIP_TRY(launch_join_planes(t.h, t.lo, t.x, (size_t)M, D, t.planes, s));
     }
     return PLIPMI_OK;
   }
@@ -1116,9 +1116,9 @@ int plipmi_check_async(plipmi_handle h) {
   if (!h) return fail(PLIPMI_ERR_INVALID, "null handle");
   return check_async(h);
 }
-int plipmi_recode_planes(void* hi, void* lo, size_t n, int from_dtype, int to_dtype, void* stream) {
-  if (!hi || !lo) return fail(PLIPMI_ERR_INVALID, "null planes");
-  HIP_TRY(launch_recode_planes(hi, lo, n, from_dtype, to_dtype, reinterpret_cast<hipStream_t>(stream)));
+int plipmi_recode_planes(void* hi, void* lo, size_t rows, int D, int from_dtype, int to_dtype, void* stream) {
+  if (!hi || !lo || D <= 0 || D % 8) return fail(PLIPMI_ERR_INVALID, "null planes / width not a multiple of 8");
+  HIP_TRY(launch_recode_planes(hi, lo, rows, D, from_dtype, to_dtype, reinterpret_cast<hipStream_t>(stream)));
   return PLIPMI_OK;
 }
 

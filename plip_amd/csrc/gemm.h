@@ -52,10 +52,9 @@ enum Epilogue : int {
   // ... and the producer of the NEXT LayerNorm's input: the in-place residual update also emits the bf16 copy of the
   // new rows (the next GEMM's A operand) and their statistics as per-64-column partials {sum, centred M2}
   EPI_RESID_EMIT = 7,  // C(f32) += acc + bias[n];  xb(bf16) = C;  st[m, n/64] = {sum, M2}
-  // The same update on a residual stream kept as TWO 16-bit planes: hi = the fp32 value rounded to bf16 (ties away), lo =
-  // the signed 16-bit remainder of its bit pattern, so that bits(x) == (hi << 16) + lo EXACTLY -- the stream stays fp32,
-  // its hi plane IS the next GEMM's bf16 A operand, and the epilogue moves 8 bytes per element (4 in, 4 out) like the
-  // plain fp32 residual instead of the 10 of EPI_RESID_EMIT (which writes fp32 and a separate bf16 copy).
+  // The same update on a residual stream kept as TWO planes (common.h split_f32): hi = the fp32 value rounded to the operand type, lo =
+  // an 8-bit remainder -- the stream at 16 (bf16) / 19 (f16) significand bits, its hi plane IS the next GEMM's A operand, and the
+  // epilogue moves 6 bytes per element (3 in, 3 out) instead of the 10 of EPI_RESID_EMIT (which writes fp32 and a separate 16-bit copy).
   EPI_RESID_SPLIT = 8, // {hi,lo} += acc + bias[n] (xb_out = hi, lo_io = lo);  st[m, n/64] = {sum, M2}
   EPI_COUNT = 9
 };
@@ -80,13 +79,13 @@ struct GemmParams {
   int ln_ns = 0;
   float ln_inv_d = 0.f, ln_eps = 0.f;
   // EPI_RESID_EMIT producer: bf16 copy of the updated rows [M, ldc] and their partial statistics [M, N/64, 2].
-  // EPI_RESID_SPLIT: xb_out is the hi plane (bf16, read AND written), lo_io the lo plane (int16, read and written)
+  // EPI_RESID_SPLIT: xb_out is the hi plane (16-bit, read AND written), lo_io the lo plane (8-bit, blocked layout, read and written)
   void* xb_out = nullptr;
   float* st_out = nullptr;
   void* lo_io = nullptr;
   // EPI_RESID_SPLIT: write the updated planes in the OTHER 16-bit type's split format (read them in T's): the last f16 block
   // of a mixed text tower (plipmi_config.text_f16_layers) hands the stream to the bf16 blocks without a re-coding pass.
-  // Exact: both formats hold the fp32 value bit for bit (|x| < 65504), common.h split_f32.
+  // (The epilogue splits the value it computed in fp32: no double rounding through T's format.)
   int planes_other = 0;
   // ADDR 2 (the patch GEMM, im2col ON LOAD; modeling_clip.py:148-154,209-210): A is not read as [M, K] rows -- row m = patch (img, gi, gj)
   // and column k = (c, u, v) are GATHERED from the fp32 NCHW pixels while a K tile is staged: four consecutive pixels of one image row
@@ -626,19 +625,28 @@ void gemm_nt_kernel(const GemmParams p) {
   bool add_ready = false;
   auto load_block = [&](int i, float4 (&dst)[NI / 2][8]) {
     if constexpr (EPI == EPI_RESID_SPLIT) {
-      // the residual planes in 16-byte pieces: a lane owns 8 consecutive columns of a row (8 lanes = one 64-column slice),
-      // 8 rows per pass; dst[jp][2*it] = hi piece (8 x 16-bit operand type), dst[jp][2*it+1] = lo piece (8 int16), raw
+      // the residual planes in 16-byte pieces: a lane owns 8 consecutive columns of a row (8 lanes = one 64-column slice), 8 rows per
+      // pass.  dst[jp][it] = hi piece of pass it (8 x 16-bit operand type); dst[jp][4 + pr] = lo piece of the pass PAIR pr: the 8-bit
+      // remainders of the lane's columns in rows r and r + 8 of a 16-row band (common.h lo_plane_off) -- 6 loads per slab, not 8
 #pragma unroll
-      for (int jp = 0; jp < NI / 2; ++jp)
+      for (int jp = 0; jp < NI / 2; ++jp) {
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
           if (it * 8 >= slab_rows(i)) continue;   // half slab: rows 16.. belong to the next wave row
           int m = m0 + wm * TM + i * 32 + it * 8 + (lane >> 3);
           m = m < Mrt ? m : Mrt - 1;
           const size_t off = (size_t)m * p.ldc + n0 + wn * TN + jp * 64 + (lane & 7) * 8;
-          dst[jp][2 * it] = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned short*>(p.xb_out) + off);
-          dst[jp][2 * it + 1] = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned short*>(p.lo_io) + off);
+          dst[jp][it] = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned short*>(p.xb_out) + off);
         }
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+          if (pr * 16 >= slab_rows(i)) continue;
+          int band = (m0 + wm * TM + i * 32 + pr * 16) >> 4;
+          band = band < ((Mrt - 1) >> 4) ? band : ((Mrt - 1) >> 4);      // bands past the live rows: re-read the last one, stores are masked
+          const size_t off = (size_t)band * 16 * p.ldc + (size_t)(((n0 + wn * TN + jp * 64) >> 3) + (lane & 7)) * 128 + (lane >> 3) * 16;
+          dst[jp][4 + pr] = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(p.lo_io) + off);
+        }
+      }
     } else {
 #pragma unroll
       for (int jp = 0; jp < NI / 2; ++jp)
@@ -1187,57 +1195,65 @@ void gemm_nt_kernel(const GemmParams p) {
           vb[it] = *reinterpret_cast<const f32x4*>(slab + (it * 8 + r8) * SLAB_PITCH + c8 * 4 + 16);
         }
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-          if (it * 8 >= slab_rows(i)) continue;
-          const int m = m0 + wm * TM + i * 32 + it * 8 + r8;
-          const bool in_range = m < Mrt;
-          const u32x4 h = __builtin_bit_cast(u32x4, add[kAddBufs == 2 ? (i & 1) : 0][jp][2 * it]);
-          const u32x4 l = __builtin_bit_cast(u32x4, add[kAddBufs == 2 ? (i & 1) : 0][jp][2 * it + 1]);
-          float o[8];
+        for (int pr = 0; pr < 2; ++pr) {           // pass pairs: rows r8 and r8 + 8 of a 16-row band share one lo piece
+          if (pr * 16 >= slab_rows(i)) continue;
+          const u32x4 l = __builtin_bit_cast(u32x4, add[kAddBufs == 2 ? (i & 1) : 0][jp][4 + pr]);
+          u32x4 lo4;
+          const int m_first = m0 + wm * TM + i * 32 + pr * 16 + r8;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            o[2 * e] = join_f32<T>(h[e] & 0xffffu, l[e] & 0xffffu);
-            o[2 * e + 1] = join_f32<T>(h[e] >> 16, l[e] >> 16);
-          }
-          // (residual + bias) + product: the order of the plain-array epilogues, so the stream is bit-identical to theirs
-          o[0] = (o[0] + b0.x) + va[it][0]; o[1] = (o[1] + b0.y) + va[it][1]; o[2] = (o[2] + b0.z) + va[it][2];
-          o[3] = (o[3] + b0.w) + va[it][3]; o[4] = (o[4] + b1.x) + vb[it][0]; o[5] = (o[5] + b1.y) + vb[it][1];
-          o[6] = (o[6] + b1.z) + vb[it][2]; o[7] = (o[7] + b1.w) + vb[it][3];
-          const float ssum = row8_sum(((o[0] + o[1]) + (o[2] + o[3])) + ((o[4] + o[5]) + (o[6] + o[7])));
-          const float mj = ssum * (1.0f / kLnSlice);
-          float q2 = 0.f;
+          for (int hh = 0; hh < 2; ++hh) {
+            const int it = 2 * pr + hh;
+            const int m = m_first + 8 * hh;
+            const bool in_range = m < Mrt;
+            const u32x4 h = __builtin_bit_cast(u32x4, add[kAddBufs == 2 ? (i & 1) : 0][jp][it]);
+            float o[8];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) { const float d = o[e] - mj; q2 = fmaf(d, d, q2); }
-          const float m2 = row8_sum(q2);
-          if (in_range) {
-            u32x4 ho, lo4;
+            for (int e = 0; e < 4; ++e) {             // columns 2e, 2e + 1: bytes 2e, 2e + 1 of this row's 8-byte half of the lo piece
+              o[2 * e] = join_f32<T>(h[e] & 0xffffu, sbyte(l[2 * hh + (e >> 1)], (2 * e) & 3));
+              o[2 * e + 1] = join_f32<T>(h[e] >> 16, sbyte(l[2 * hh + (e >> 1)], (2 * e + 1) & 3));
+            }
+            // (residual + bias) + product: the order of the plain-array epilogues
+            o[0] = (o[0] + b0.x) + va[it][0]; o[1] = (o[1] + b0.y) + va[it][1]; o[2] = (o[2] + b0.z) + va[it][2];
+            o[3] = (o[3] + b0.w) + va[it][3]; o[4] = (o[4] + b1.x) + vb[it][0]; o[5] = (o[5] + b1.y) + vb[it][1];
+            o[6] = (o[6] + b1.z) + vb[it][2]; o[7] = (o[7] + b1.w) + vb[it][3];
+            const float ssum = row8_sum(((o[0] + o[1]) + (o[2] + o[3])) + ((o[4] + o[5]) + (o[6] + o[7])));
+            const float mj = ssum * (1.0f / kLnSlice);
+            float q2 = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = o[e] - mj; q2 = fmaf(d, d, q2); }
+            const float m2 = row8_sum(q2);
+            u32x4 ho;
+            unsigned lb[8];
             using TO = std::conditional_t<std::is_same_v<T, bf16_t>, f16_t, bf16_t>;   // the other 16-bit type
             if (p.planes_other) {   // wave-uniform
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
-                unsigned ha, la, hb, lb;
-                split_f32<TO>(o[2 * e], ha, la);
-                split_f32<TO>(o[2 * e + 1], hb, lb);
+                unsigned ha, hb;
+                split_f32<TO>(o[2 * e], ha, lb[2 * e]);
+                split_f32<TO>(o[2 * e + 1], hb, lb[2 * e + 1]);
                 ho[e] = ha | (hb << 16);
-                lo4[e] = la | (lb << 16);
               }
             } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              unsigned ha, la, hb, lb;
-              split_f32<T>(o[2 * e], ha, la);
-              split_f32<T>(o[2 * e + 1], hb, lb);
-              ho[e] = ha | (hb << 16);
-              lo4[e] = la | (lb << 16);
+              for (int e = 0; e < 4; ++e) {
+                unsigned ha, hb;
+                split_f32<T>(o[2 * e], ha, lb[2 * e]);
+                split_f32<T>(o[2 * e + 1], hb, lb[2 * e + 1]);
+                ho[e] = ha | (hb << 16);
+              }
             }
+            lo4[2 * hh] = lb[0] | (lb[1] << 8) | (lb[2] << 16) | (lb[3] << 24);
+            lo4[2 * hh + 1] = lb[4] | (lb[5] << 8) | (lb[6] << 16) | (lb[7] << 24);
+            if (in_range) {
+              store16(reinterpret_cast<unsigned short*>(p.xb_out) + (size_t)m * p.ldc + nn, ho);
+              if ((lane & 7) == 0)
+                *reinterpret_cast<float2*>(p.st_out + ((size_t)m * (p.N / kLnSlice) + (n0 + wn * TN + jp * 64) / kLnSlice) * 2) =
+                    make_float2(ssum, m2);
             }
-            const size_t off = (size_t)m * p.ldc + nn;
-            store16(reinterpret_cast<unsigned short*>(p.xb_out) + off, ho);
-            store16(reinterpret_cast<unsigned short*>(p.lo_io) + off, lo4);
-            if ((lane & 7) == 0)
-              *reinterpret_cast<float2*>(p.st_out + ((size_t)m * (p.N / kLnSlice) + (n0 + wn * TN + jp * 64) / kLnSlice) * 2) =
-                  make_float2(ssum, m2);
           }
+          // (a band's second row may lie past the live rows while its first does not: its byte half then goes to the plane's padding)
+          if (m_first < Mrt)
+            store16(reinterpret_cast<unsigned char*>(p.lo_io) + (size_t)(m_first >> 4) * 16 * p.ldc + (size_t)((nn >> 3)) * 128 + r8 * 16, lo4);
         }
         __builtin_amdgcn_wave_barrier();
         continue;

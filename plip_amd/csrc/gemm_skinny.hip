@@ -126,16 +126,18 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(const GemmParams p
       *reinterpret_cast<float4*>(crow + 4) = make_float4(v[4] + p1.x, v[5] + p1.y, v[6] + p1.z, v[7] + p1.w);
     }
   } else if constexpr (EPI == EPI_RESID_SPLIT) {
-    // the residual stream as two 16-bit planes (gemm.h EPI_RESID_SPLIT): join, (x + bias) + product, split, statistics of
+    // the residual stream as its two planes (gemm.h EPI_RESID_SPLIT; common.h split_f32): join, (x + bias) + product, split, statistics of
     // the tile's 64-column slice -- a lane owns 8 consecutive columns of a row, 8 lanes the slice, as in the big kernel
-    const size_t off = (size_t)(in_range ? m : p.M - 1) * p.ldc + n;
+    const size_t mr = (size_t)(in_range ? m : p.M - 1);
+    const size_t off = mr * p.ldc + n;
+    const size_t loff = lo_plane_off(mr, (unsigned)n, (unsigned)p.ldc);     // this row's 8 bytes of a band's 16-byte piece
     const u32x4 h = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned short*>(p.xb_out) + off);
-    const u32x4 l = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned short*>(p.lo_io) + off);
+    const uint2 l = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned char*>(p.lo_io) + loff);
     float o[8], s = 0.f;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      o[2 * e] = join_f32<T>(h[e] & 0xffffu, l[e] & 0xffffu);
-      o[2 * e + 1] = join_f32<T>(h[e] >> 16, l[e] >> 16);
+      o[2 * e] = join_f32<T>(h[e] & 0xffffu, sbyte(e < 2 ? l.x : l.y, (2 * e) & 3));
+      o[2 * e + 1] = join_f32<T>(h[e] >> 16, sbyte(e < 2 ? l.x : l.y, (2 * e + 1) & 3));
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = (o[e] + bias[e]) + v[e];
@@ -147,17 +149,18 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(const GemmParams p
     for (int e = 0; e < 8; ++e) { const float d = o[e] - mj; q = fmaf(d, d, q); }
     const float m2 = row8_sum(q);
     if (in_range) {
-      u32x4 ho, lo4;
+      u32x4 ho;
+      unsigned lb[8];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        unsigned ha, la, hb, lb;
-        split_f32<T>(o[2 * e], ha, la);
-        split_f32<T>(o[2 * e + 1], hb, lb);
+        unsigned ha, hb;
+        split_f32<T>(o[2 * e], ha, lb[2 * e]);
+        split_f32<T>(o[2 * e + 1], hb, lb[2 * e + 1]);
         ho[e] = ha | (hb << 16);
-        lo4[e] = la | (lb << 16);
       }
       *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(p.xb_out) + off) = ho;
-      *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(p.lo_io) + off) = lo4;
+      *reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(p.lo_io) + loff) =
+          make_uint2(lb[0] | (lb[1] << 8) | (lb[2] << 16) | (lb[3] << 24), lb[4] | (lb[5] << 8) | (lb[6] << 16) | (lb[7] << 24));
       if ((tid & 7) == 0) *reinterpret_cast<float2*>(p.st_out + ((size_t)m * (p.N / kLnSlice) + n0 / kLnSlice) * 2) = make_float2(ssum, m2);
     }
   } else {

@@ -13,14 +13,14 @@ hipError_t launch_layernorm(const float* x, size_t x_row_stride, const float* g,
 
 // LayerNorm folded into the GEMMs (16-bit engines, gemm.h EPI_*_LN): the one LayerNorm pass a tower keeps -- fp32 rows in,
 // the normalised rows out as the split residual stream (common.h split_f32<H>: hi = the 16-bit operand plane [rows, D],
-// lo = int16 remainder plane, the pair == the fp32 value exactly) plus their statistics partials st [rows, D/64, 2]
+// lo = the 8-bit remainder plane in its blocked layout, lo_plane_bytes(rows, D) bytes) plus their statistics partials st [rows, D/64, 2]
 // (D % 64 == 0).  dtype (1 = bf16, 2 = f16) selects H.
 hipError_t launch_layernorm_emit(const float* x, const float* g, const float* b, void* hi, void* lo, float* st, int rows, int D,
                                  float eps, int dtype, hipStream_t s);
-// the two planes back to plain fp32 (n % 4 == 0 elements)
-hipError_t launch_join_planes(const void* hi, const void* lo, float* x, size_t n, int dtype, hipStream_t s);
-// {hi, lo} planes of n values from one 16-bit operand type's split format to the other's (1 bf16, 2 f16), in place, exact
-hipError_t launch_recode_planes(void* hi, void* lo, size_t n, int from_dtype, int to_dtype, hipStream_t s);
+// the two planes [rows, D] back to plain fp32 (D % 8 == 0)
+hipError_t launch_join_planes(const void* hi, const void* lo, float* x, size_t rows, int D, int dtype, hipStream_t s);
+// {hi, lo} planes [rows, D] from one 16-bit operand type's split format to the other's (1 bf16, 2 f16), in place (one rounding of the remainder)
+hipError_t launch_recode_planes(void* hi, void* lo, size_t rows, int D, int from_dtype, int to_dtype, hipStream_t s);
 // weight folding at plipmi_create: Wf[n,:] = H(pre * (W[n,:] * g - mean_k(W[n,:] * g))), c2[n] = pre * (W[n,:].b + bias[n])
 hipError_t launch_fold_ln(const float* W, const float* bias, const float* g, const float* b, void* Wf, float* c2, int rows,
                           int K, float pre, int dtype, hipStream_t s);

@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void layernorm_fixed_kernel(const float* x, si
 // LayerNorm folded into the neighbouring GEMMs (bf16 engine; gemm.h EPI_*_LN / EPI_RESID_EMIT).
 //   * layernorm_emit_kernel: the ONE LayerNorm pass a tower keeps (vision pre_layrnorm, modeling_clip.py:642): reads the
 //     fp32 embedding rows, writes the normalised rows as the engine's split residual stream (common.h split_f32: the hi
-//     plane is the bf16 A operand of the q/k/v GEMM, hi + lo the exact fp32 value) and the rows' statistics as
+//     plane is the bf16 A operand of the q/k/v GEMM, hi + the 8-bit lo plane the stream at 16 / 19 significand bits) and the rows' statistics as
 //     per-64-column partials {sum, centred M2} for the first block's folded LayerNorm.
 //   * fold_ln_kernel (plipmi_create): W'[n,:] = bf16(pre * (W[n,:] * g - mean_k(W[n,:] * g))) -- gain folded in and the
 //     row centred, so that x . W'^T == (x - mean(x)) . (W * g)^T and LayerNorm's mean subtraction needs no epilogue term;
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void layernorm_fixed_kernel(const float* x, si
 template <typename H>
 __global__ __launch_bounds__(256) void layernorm_emit_kernel(const float* __restrict__ x, const float* __restrict__ g,
                                                              const float* __restrict__ b, unsigned short* __restrict__ hi,
-                                                             unsigned short* __restrict__ lo, float* __restrict__ st, int rows,
+                                                             unsigned char* __restrict__ lo, float* __restrict__ st, int rows,
                                                              int D, float eps) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void layernorm_emit_kernel(const float* __rest
     const float d0 = y.x - mj, d1 = y.y - mj, d2 = y.z - mj, d3 = y.w - mj;
     const float m2 = row16_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
     if (live) {
-      store4_split<H>(hi + (size_t)row * D + idx, lo + (size_t)row * D + idx, y.x, y.y, y.z, y.w);
+      store4_split<H>(hi, lo, (size_t)row, (unsigned)idx, (unsigned)D, y.x, y.y, y.z, y.w);
       if ((lane & 15) == 0) *reinterpret_cast<float2*>(st + ((size_t)row * ns + idx / kLnSlice) * 2) = make_float2(ssum, m2);
     }
   }
@@ -168,50 +168,56 @@ hipError_t launch_layernorm_emit(const float* x, const float* g, const float* b,
   if (D % kLnSlice || D > kLnMaxVec * 256 || (dtype != 1 && dtype != 2)) return hipErrorInvalidValue;
   if (dtype == 1)
     hipLaunchKernelGGL(layernorm_emit_kernel<bf16_t>, dim3((rows + 3) / 4), dim3(256), 0, s, x, g, b, (unsigned short*)hi,
-                       (unsigned short*)lo, st, rows, D, eps);
+                       (unsigned char*)lo, st, rows, D, eps);
   else
     hipLaunchKernelGGL(layernorm_emit_kernel<f16_t>, dim3((rows + 3) / 4), dim3(256), 0, s, x, g, b, (unsigned short*)hi,
-                       (unsigned short*)lo, st, rows, D, eps);
+                       (unsigned char*)lo, st, rows, D, eps);
   return hipGetLastError();
 }
 
 // hi/lo planes -> plain fp32 rows (plipmi_debug_hidden, and the head of an engine that runs its last block on every token)
 template <typename H>
-__global__ __launch_bounds__(256) void join_planes_kernel(const unsigned short* __restrict__ hi, const unsigned short* __restrict__ lo,
-                                                          float* __restrict__ x, size_t n4) {
+__global__ __launch_bounds__(256) void join_planes_kernel(const unsigned short* __restrict__ hi, const unsigned char* __restrict__ lo,
+                                                          float* __restrict__ x, size_t n4, unsigned D) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n4) return;
-  *reinterpret_cast<float4*>(x + i * 4) = load4_split<H>(hi + i * 4, lo + i * 4);
+  const size_t m = i * 4 / D;
+  *reinterpret_cast<float4*>(x + i * 4) = load4_split<H>(hi, lo, m, (unsigned)(i * 4 - m * D), D);
 }
-hipError_t launch_join_planes(const void* hi, const void* lo, float* x, size_t n, int dtype, hipStream_t s) {
+hipError_t launch_join_planes(const void* hi, const void* lo, float* x, size_t rows, int D, int dtype, hipStream_t s) {
+  const size_t n = rows * (size_t)D;
   if (n == 0) return hipSuccess;
-  if (n % 4 || (dtype != 1 && dtype != 2)) return hipErrorInvalidValue;
+  if (D % 8 || (dtype != 1 && dtype != 2)) return hipErrorInvalidValue;
   if (dtype == 1)
     hipLaunchKernelGGL(join_planes_kernel<bf16_t>, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, (const unsigned short*)hi,
-                       (const unsigned short*)lo, x, n / 4);
+                       (const unsigned char*)lo, x, n / 4, (unsigned)D);
   else
     hipLaunchKernelGGL(join_planes_kernel<f16_t>, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, (const unsigned short*)hi,
-                       (const unsigned short*)lo, x, n / 4);
+                       (const unsigned char*)lo, x, n / 4, (unsigned)D);
   return hipGetLastError();
 }
 
-// the residual planes from one operand type's split format to the other's, in place: both hold the fp32 value exactly
-// (common.h split_f32), so this is a change of code, not of value; hi becomes the next block's A operand
+// the residual planes from one operand type's split format to the other's, in place: the value is joined in the old code and split
+// again in the new one (the new hi = the value rounded to the new operand type -- the next block's A operand -- and a new 8-bit
+// remainder: one more rounding of the stream at 2^-16 / 2^-19 relative, common.h split_f32)
 template <typename HF, typename HT>
-__global__ __launch_bounds__(256) void recode_planes_kernel(unsigned short* __restrict__ hi, unsigned short* __restrict__ lo, size_t n4) {
+__global__ __launch_bounds__(256) void recode_planes_kernel(unsigned short* __restrict__ hi, unsigned char* __restrict__ lo, size_t n4, unsigned D) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n4) return;
-  const float4 v = load4_split<HF>(hi + i * 4, lo + i * 4);
-  store4_split<HT>(hi + i * 4, lo + i * 4, v.x, v.y, v.z, v.w);
+  const size_t m = i * 4 / D;
+  const unsigned n = (unsigned)(i * 4 - m * D);
+  const float4 v = load4_split<HF>(hi, lo, m, n, D);
+  store4_split<HT>(hi, lo, m, n, D, v.x, v.y, v.z, v.w);
 }
-hipError_t launch_recode_planes(void* hi, void* lo, size_t n, int from_dtype, int to_dtype, hipStream_t s) {
+hipError_t launch_recode_planes(void* hi, void* lo, size_t rows, int D, int from_dtype, int to_dtype, hipStream_t s) {
+  const size_t n = rows * (size_t)D;
   if (n == 0 || from_dtype == to_dtype) return hipSuccess;
-  if (n % 4 || (from_dtype != 1 && from_dtype != 2) || (to_dtype != 1 && to_dtype != 2)) return hipErrorInvalidValue;
+  if (D % 8 || (from_dtype != 1 && from_dtype != 2) || (to_dtype != 1 && to_dtype != 2)) return hipErrorInvalidValue;
   const dim3 grid((unsigned)((n / 4 + 255) / 256));
   if (from_dtype == 2)
-    hipLaunchKernelGGL((recode_planes_kernel<f16_t, bf16_t>), grid, dim3(256), 0, s, (unsigned short*)hi, (unsigned short*)lo, n / 4);
+    hipLaunchKernelGGL((recode_planes_kernel<f16_t, bf16_t>), grid, dim3(256), 0, s, (unsigned short*)hi, (unsigned char*)lo, n / 4, (unsigned)D);
   else
-    hipLaunchKernelGGL((recode_planes_kernel<bf16_t, f16_t>), grid, dim3(256), 0, s, (unsigned short*)hi, (unsigned short*)lo, n / 4);
+    hipLaunchKernelGGL((recode_planes_kernel<bf16_t, f16_t>), grid, dim3(256), 0, s, (unsigned short*)hi, (unsigned char*)lo, n / 4, (unsigned)D);
   return hipGetLastError();
 }
 
@@ -425,7 +431,7 @@ hipError_t launch_text_embed(const int64_t* ids, const float* tok, const float* 
 template <typename H>
 __global__ __launch_bounds__(256) void text_embed_emit_kernel(const int64_t* __restrict__ ids, const float* __restrict__ tok,
                                                               const float* __restrict__ pos, unsigned short* __restrict__ hi,
-                                                              unsigned short* __restrict__ lo, float* __restrict__ st, int rows,
+                                                              unsigned char* __restrict__ lo, float* __restrict__ st, int rows,
                                                               int S, int D, int vocab, int* __restrict__ bad_id) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -448,7 +454,7 @@ __global__ __launch_bounds__(256) void text_embed_emit_kernel(const int64_t* __r
     const float d0 = y.x - mj, d1 = y.y - mj, d2 = y.z - mj, d3 = y.w - mj;
     const float m2 = row16_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
     if (live) {
-      store4_split<H>(hi + (size_t)row * D + idx, lo + (size_t)row * D + idx, y.x, y.y, y.z, y.w);
+      store4_split<H>(hi, lo, (size_t)row, (unsigned)idx, (unsigned)D, y.x, y.y, y.z, y.w);
       if ((lane & 15) == 0) *reinterpret_cast<float2*>(st + ((size_t)row * ns + idx / kLnSlice) * 2) = make_float2(ssum, m2);
     }
   }
@@ -459,10 +465,10 @@ hipError_t launch_text_embed_emit(const int64_t* ids, const float* tok, const fl
   if (D % kLnSlice || (dtype != 1 && dtype != 2)) return hipErrorInvalidValue;
   if (dtype == 1)
     hipLaunchKernelGGL(text_embed_emit_kernel<bf16_t>, dim3((B * S + 3) / 4), dim3(256), 0, s, ids, tok, pos, (unsigned short*)hi,
-                       (unsigned short*)lo, st, B * S, S, D, vocab, bad_id);
+                       (unsigned char*)lo, st, B * S, S, D, vocab, bad_id);
   else
     hipLaunchKernelGGL(text_embed_emit_kernel<f16_t>, dim3((B * S + 3) / 4), dim3(256), 0, s, ids, tok, pos, (unsigned short*)hi,
-                       (unsigned short*)lo, st, B * S, S, D, vocab, bad_id);
+                       (unsigned char*)lo, st, B * S, S, D, vocab, bad_id);
   return hipGetLastError();
 }
 
@@ -590,7 +596,7 @@ __device__ __forceinline__ int eos_position(const int64_t* row, int S, int eos_i
 // compact [B, D] buffers, on which out_proj / fc1 / fc2 of the last block then run (engine.hip run_last_block_pooled).
 template <typename H>
 __global__ __launch_bounds__(256) void pool_gather_kernel(const H* __restrict__ att, const unsigned short* __restrict__ hi,
-                                                          const unsigned short* __restrict__ lo, int S, int D,
+                                                          const unsigned char* __restrict__ lo, int S, int D,
                                                           const int64_t* __restrict__ ids, int eos_id, H* __restrict__ attp,
                                                           float* __restrict__ xp, int B, const int* __restrict__ cu) {
   const int lane = threadIdx.x & 63;
@@ -602,8 +608,8 @@ __global__ __launch_bounds__(256) void pool_gather_kernel(const H* __restrict__ 
   const size_t src = row * D, dst = (size_t)smp * D;
   for (int i = lane * 8; i < D; i += 512) {     // D % 8 == 0 (widths are multiples of 128)
     *reinterpret_cast<u32x4_t*>(attp + dst + i) = *reinterpret_cast<const u32x4_t*>(att + src + i);
-    *reinterpret_cast<float4*>(xp + dst + i) = load4_split<H>(hi + src + i, lo + src + i);
-    *reinterpret_cast<float4*>(xp + dst + i + 4) = load4_split<H>(hi + src + i + 4, lo + src + i + 4);
+    *reinterpret_cast<float4*>(xp + dst + i) = load4_split<H>(hi, lo, row, (unsigned)i, (unsigned)D);
+    *reinterpret_cast<float4*>(xp + dst + i + 4) = load4_split<H>(hi, lo, row, (unsigned)i + 4, (unsigned)D);
   }
 }
 hipError_t launch_pool_gather(const void* att, const void* hi, const void* lo, int S, int D, const int64_t* ids, int eos_id,
@@ -612,10 +618,10 @@ hipError_t launch_pool_gather(const void* att, const void* hi, const void* lo, i
   if (D % 8 || (dtype != 1 && dtype != 2)) return hipErrorInvalidValue;
   if (dtype == 1)
     hipLaunchKernelGGL(pool_gather_kernel<bf16_t>, dim3((B + 3) / 4), dim3(256), 0, s, (const bf16_t*)att, (const unsigned short*)hi,
-                       (const unsigned short*)lo, S, D, ids, eos_id, (bf16_t*)attp, xp, B, cu);
+                       (const unsigned char*)lo, S, D, ids, eos_id, (bf16_t*)attp, xp, B, cu);
   else
     hipLaunchKernelGGL(pool_gather_kernel<f16_t>, dim3((B + 3) / 4), dim3(256), 0, s, (const f16_t*)att, (const unsigned short*)hi,
-                       (const unsigned short*)lo, S, D, ids, eos_id, (f16_t*)attp, xp, B, cu);
+                       (const unsigned char*)lo, S, D, ids, eos_id, (f16_t*)attp, xp, B, cu);
   return hipGetLastError();
 }
 
@@ -665,7 +671,7 @@ hipError_t launch_text_pack(const int64_t* ids, int B, int S, int eos_id, int* c
 template <typename H>
 __global__ __launch_bounds__(256) void text_embed_emit_packed_kernel(const int64_t* __restrict__ ids, const float* __restrict__ tok,
                                                                      const float* __restrict__ pos, unsigned short* __restrict__ hi,
-                                                                     unsigned short* __restrict__ lo, float* __restrict__ st,
+                                                                     unsigned char* __restrict__ lo, float* __restrict__ st,
                                                                      const int* __restrict__ rowmap, const int* __restrict__ m_dev,
                                                                      int S, int D, int vocab, int* __restrict__ bad_id) {
   const int lane = threadIdx.x & 63;
@@ -690,7 +696,7 @@ __global__ __launch_bounds__(256) void text_embed_emit_packed_kernel(const int64
     const float d0 = y.x - mj, d1 = y.y - mj, d2 = y.z - mj, d3 = y.w - mj;
     const float m2 = row16_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
     if (live) {
-      store4_split<H>(hi + (size_t)row * D + idx, lo + (size_t)row * D + idx, y.x, y.y, y.z, y.w);
+      store4_split<H>(hi, lo, (size_t)row, (unsigned)idx, (unsigned)D, y.x, y.y, y.z, y.w);
       if ((lane & 15) == 0) *reinterpret_cast<float2*>(st + ((size_t)row * ns + idx / kLnSlice) * 2) = make_float2(ssum, m2);
     }
   }
@@ -702,10 +708,10 @@ hipError_t launch_text_embed_emit_packed(const int64_t* ids, const float* tok, c
   if (D % kLnSlice || S > 256 || (dtype != 1 && dtype != 2)) return hipErrorInvalidValue;
   if (dtype == 1)
     hipLaunchKernelGGL(text_embed_emit_packed_kernel<bf16_t>, dim3((max_rows + 3) / 4), dim3(256), 0, s, ids, tok, pos,
-                       (unsigned short*)hi, (unsigned short*)lo, st, rowmap, m_dev, S, D, vocab, bad_id);
+                       (unsigned short*)hi, (unsigned char*)lo, st, rowmap, m_dev, S, D, vocab, bad_id);
   else
     hipLaunchKernelGGL(text_embed_emit_packed_kernel<f16_t>, dim3((max_rows + 3) / 4), dim3(256), 0, s, ids, tok, pos,
-                       (unsigned short*)hi, (unsigned short*)lo, st, rowmap, m_dev, S, D, vocab, bad_id);
+                       (unsigned short*)hi, (unsigned char*)lo, st, rowmap, m_dev, S, D, vocab, bad_id);
   return hipGetLastError();
 }
 

@@ -84,8 +84,8 @@ def gemm_nt_ln(mode: int, a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, 
                eps: float = 1e-5, variant: int = -1, out: Optional[torch.Tensor] = None):
     """Kernel-level entry (tests) for the LayerNorm-folded epilogues, see include/plipmi.h plipmi_gemm_nt_ln.
     mode 0/1 -> bf16 [M,N]; mode 2 -> (C fp32 updated in place, xb bf16 [M,N], st fp32 [M,N/64,2]); mode 3 -> the same
-    update on the split residual stream: ``out`` = (hi bf16 [M,N], lo int16 [M,N]), both updated in place; returns
-    (hi, lo, st)."""
+    update on the split residual stream: ``out`` = (hi 16-bit [M,N], lo uint8 [lo_plane_bytes(M, N)], the blocked 8-bit remainder
+    plane), both updated in place; returns (hi, lo, st)."""
     lib = _lib.load()
     assert a.dtype in (torch.bfloat16, torch.float16) and w.dtype == a.dtype and a.is_contiguous() and w.is_contiguous()
     code, hdt = _code(a.dtype), a.dtype
@@ -102,7 +102,7 @@ def gemm_nt_ln(mode: int, a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, 
         st = torch.empty((M, N // 64, 2), dtype=torch.float32, device=a.device)
         if mode in (3, 4):           # 4: planes read in a's format, written in the other 16-bit type's (hi is then to be VIEWED as that type)
             hi, lo = out
-            assert hi.dtype == hdt and lo.dtype == torch.int16 and hi.is_contiguous() and lo.is_contiguous()
+            assert hi.dtype == hdt and lo.dtype == torch.uint8 and lo.numel() == lo_plane_bytes(M, N) and hi.is_contiguous() and lo.is_contiguous()
             _lib.check(lib.plipmi_gemm_nt_ln(code, mode, variant, M, N, K, _ptr(a), _ptr(w), _ptr(bias), None, 0, float(eps),
                                              _ptr(lo), _ptr(hi), _ptr(st), stream), "plipmi_gemm_nt_ln")
             return hi, lo, st
@@ -117,34 +117,61 @@ def _pow2(k: torch.Tensor) -> torch.Tensor:
     return ((k.to(torch.int64) + 1023) << 52).view(torch.float64)
 
 
+def lo_plane_index(M: int, N: int, device=None) -> torch.Tensor:
+    """Byte offset of element (m, n) in the blocked lo plane (csrc/common.h lo_plane_off): blocks of 16 rows x 8 columns = 128 B,
+    [row & 7][row >> 3 & 1][column & 7] inside a block, blocks column-major inside a 16-row band.  int64 [M, N]."""
+    m = torch.arange(M, dtype=torch.int64, device=device)[:, None]
+    n = torch.arange(N, dtype=torch.int64, device=device)[None, :]
+    return (m >> 4) * 16 * N + (n >> 3) * 128 + (m & 7) * 16 + ((m >> 3) & 1) * 8 + (n & 7)
+
+
+def lo_plane_bytes(M: int, N: int) -> int:
+    return (M + 15) // 16 * 16 * N
+
+
+def lo_plane_values(lo: torch.Tensor, M: int, N: int) -> torch.Tensor:
+    """The remainders of rows 0 .. M-1 as int8 [M, N] (a band's rows past M are padding: kernels may leave anything there)."""
+    return lo[lo_plane_index(M, N, lo.device).reshape(-1)].reshape(M, N).view(torch.int8)
+
+
 def split_planes(x: torch.Tensor, dtype=torch.bfloat16):
-    """fp32 -> the engine's two-plane residual form (csrc/common.h split_f32<H>), on the host in torch integer / float64
-    arithmetic; ``join_planes`` is the exact inverse.
-    bf16: hi = nearest bf16 (ties away from zero), lo = int16 remainder of the bit pattern, bits(x) == (hi << 16) + lo.
-    f16:  hi = nearest f16 (ties to even, saturating), lo = (x - hi) / 2^(E(hi) - 24) with E >= -14: an integer, |lo| <= 8192."""
+    """fp32 [M, N] -> the engine's two-plane residual form (csrc/common.h split_f32<H>), on the host in torch integer / float64
+    arithmetic, bit for bit what the kernels write: ``hi`` [M, N] in the operand type, ``lo`` = uint8 [lo_plane_bytes(M, N)] in the
+    blocked layout (padding bytes zero).
+    bf16: hi = nearest bf16 (ties away from zero); r = bits(x) - (hi << 16) in [-32768, 32767]; lo = min((r + 128) >> 8, 127).
+    f16:  hi = nearest f16 (ties to even, saturating); lo = clamp(rint((x - hi) * 2^(18 - E(hi))), -128, 127), E >= -14."""
+    assert x.dim() == 2
+    M, N = x.shape
     if dtype == torch.bfloat16:
         u = x.contiguous().view(torch.int32).to(torch.int64) & 0xFFFFFFFF
         t = (u + 0x8000) & 0xFFFFFFFF
         hi = (t >> 16).to(torch.int32)
-        lo = (u - (t & 0xFFFF0000))                                   # in [-32768, 32767]
+        r = (u - (t & 0xFFFF0000))                                   # in [-32768, 32767]
+        lo = ((r + 128) >> 8).clamp(max=127)
         hi16 = torch.where(hi >= 32768, hi - 65536, hi).to(torch.int16).view(torch.bfloat16)
-        return hi16, lo.to(torch.int16)
-    assert dtype == torch.float16
-    xc = x.contiguous().float()
-    hi = xc.clamp(-65504.0, 65504.0).to(torch.float16)
-    hf = hi.float()
-    eb = ((hf.view(torch.int32) >> 23) & 0xFF).clamp(min=113)
-    lo = (xc.double() - hf.double()) * _pow2(151 - eb)              # exact scaling by a power of two
-    return hi, lo.clamp(-32768, 32767).trunc().to(torch.int16)
+    else:
+        assert dtype == torch.float16
+        xc = x.contiguous().float()
+        hi16 = xc.clamp(-65504.0, 65504.0).to(torch.float16)
+        hf = hi16.float()
+        eb = ((hf.view(torch.int32) >> 23) & 0xFF).clamp(min=113)
+        lo = torch.round((xc.double() - hf.double()) * _pow2(145 - eb)).clamp(-128, 127).to(torch.int64)   # exact power-of-two scaling, ties to even
+    plane = torch.zeros(lo_plane_bytes(M, N), dtype=torch.uint8, device=x.device)
+    plane[lo_plane_index(M, N, x.device).reshape(-1)] = (lo & 0xFF).to(torch.uint8).reshape(-1)
+    return hi16, plane
 
 
 def join_planes(hi: torch.Tensor, lo: torch.Tensor) -> torch.Tensor:
+    """The fp32 value the two planes stand for (csrc/common.h join_f32<H>), bit for bit what the kernels read."""
+    M, N = hi.shape
+    l8 = lo[lo_plane_index(M, N, hi.device).reshape(-1)].reshape(M, N).to(torch.int64)
+    l8 = torch.where(l8 >= 128, l8 - 256, l8)
     if hi.dtype == torch.float16:
         hf = hi.float()
         eb = ((hf.view(torch.int32) >> 23) & 0xFF).clamp(min=113)
-        return (hf.double() + lo.double() * _pow2(eb - 151)).float()
+        return (hf.double() + l8.double() * _pow2(eb - 145)).float()
     h = hi.view(torch.int16).to(torch.int64) & 0xFFFF
-    u = ((h << 16) + lo.to(torch.int64)) & 0xFFFFFFFF
+    u = ((h << 16) + (l8 << 8)) & 0xFFFFFFFF
     u = torch.where(u >= 2 ** 31, u - 2 ** 32, u)
     return u.to(torch.int32).view(torch.float32)
 
@@ -154,9 +181,10 @@ def recode_planes(hi: torch.Tensor, lo: torch.Tensor, to_dtype) -> tuple:
     lib = _lib.load()
     frm = _code(hi.dtype)
     to = _code(to_dtype)
-    assert hi.is_cuda and lo.is_cuda and hi.is_contiguous() and lo.is_contiguous() and lo.dtype == torch.int16
+    M, N = hi.shape
+    assert hi.is_cuda and lo.is_cuda and hi.is_contiguous() and lo.is_contiguous() and lo.dtype == torch.uint8 and lo.numel() == lo_plane_bytes(M, N)
     with torch.cuda.device(hi.device):
-        _lib.check(lib.plipmi_recode_planes(_ptr(hi), _ptr(lo), hi.numel(), frm, to,
+        _lib.check(lib.plipmi_recode_planes(_ptr(hi), _ptr(lo), M, N, frm, to,
                                             C.c_void_p(torch.cuda.current_stream(hi.device).cuda_stream)), "plipmi_recode_planes")
     return hi.view(_TORCH_DTYPE[to]), lo
 

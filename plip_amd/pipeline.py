@@ -54,7 +54,9 @@ def run_batches(items: Sequence, batch_size: int, prepare_item: Optional[Callabl
         fut = ahead.submit(prep, items[bounds[0][0]:bounds[0][1]])
         use_gpu = device is not None and torch.device(device).type == "cuda"
         if use_gpu:
-            copy_stream = torch.cuda.Stream(device=device)
+            # high priority: a queue class of its own -- an ordinary stream may share its hardware queue with the stream the towers run
+            # on, and its copies then run in order with the kernels instead of beside them (profiles/r06_h2d_copy_stream.txt)
+            copy_stream = torch.cuda.Stream(device=device, priority=-1)
             staging = [None, None]
             copied = [torch.cuda.Event(), torch.cuda.Event()]
             consumed = [None, None]

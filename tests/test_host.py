@@ -343,29 +343,41 @@ def test_load_checkpoint_refuses_code_carrying_pickles(tmp_path, monkeypatch):
         assert "trust_pickle" not in str(ei.value) and "truncated or corrupt" in str(ei.value), (name, str(ei.value))
 
 
-def test_split_plane_host_mirror_is_exact():
-    """The bf16 engine stores its fp32 residual stream as a bf16 plane + an int16 remainder plane (csrc/common.h
-    split_f32); the host mirror used by the GPU tests must invert exactly and its hi plane must be the nearest bf16."""
+def test_split_plane_host_mirror_follows_the_format():
+    """The 16-bit engines keep their residual stream as the operand-type plane hi + an 8-bit remainder plane lo (csrc/common.h
+    split_f32, round 6; rounds 2-5 carried a 16-bit remainder = the exact fp32 value): hi is the correctly rounded operand, the pair
+    reproduces x to 2^-16 (bf16) / 2^-19 (f16) relative (twice that in the clamp corner), lo sits in the blocked layout the GEMM epilogues address in 16-byte pieces."""
     import torch
-    from plip_amd.kernel_entries import join_planes, split_planes
+    from plip_amd.kernel_entries import join_planes, lo_plane_bytes, lo_plane_index, split_planes
     g = torch.Generator().manual_seed(5)
-    x = torch.randn(200000, generator=g) * torch.exp(torch.randn(200000, generator=g) * 6)
+    M, N = 250, 800
+    x = (torch.randn(M * N, generator=g) * torch.exp(torch.randn(M * N, generator=g) * 6)).clamp(-3.0e38, 3.0e38)
     x[:6] = torch.tensor([0.0, -0.0, 1e-38, -3.0e38, 1.00390625, -1.00390625])      # the last two are exact bf16 ties
+    x = x.reshape(M, N)
     hi, lo = split_planes(x)
-    assert hi.dtype == torch.bfloat16 and lo.dtype == torch.int16
-    assert torch.equal(join_planes(hi, lo).view(torch.int32), x.view(torch.int32))
-    assert ((hi.float() - x).abs() <= (x.bfloat16().float() - x).abs()).all()
-    assert hi[4].item() == 1.0078125 and hi[5].item() == -1.0078125                  # ties go away from zero
-    # f16 engine: hi = nearest f16 (ties to even, saturating), lo = the remainder in units of 2^(E(hi) - 24): an integer of at
-    # most 14 bits, exact for 2^-15 <= |x| <= 65504 (csrc/common.h split_f32<f16_t>)
+    assert hi.dtype == torch.bfloat16 and lo.dtype == torch.uint8 and lo.numel() == lo_plane_bytes(M, N) == 256 * 800
+    assert ((hi.float() - x).abs() <= (x.bfloat16().float() - x).abs()).all()        # hi = the nearest bf16
+    assert hi[0, 4].item() == 1.0078125 and hi[0, 5].item() == -1.0078125            # ties go away from zero
+    xr = join_planes(hi, lo)
+    big = x.abs() > 1e-37
+    rel = ((xr - x).abs() / x.abs())[big]                                              # 8 + 8 significand bits: 2^-16, and 2^-15 in the
+    assert (rel <= 2.0 ** -15).all() and (rel > 2.0 ** -16).float().mean() < 4e-3    # corner where +128 is clamped to +127 (r >= 32640)
+    hi2, lo2 = split_planes(xr)                                                       # a stored value splits into itself
+    assert torch.equal(hi2.view(torch.int16), hi.view(torch.int16)) and torch.equal(lo2, lo)
+    # layout: a permutation of [0, M * N) into the padded plane; rows r and r + 8 of a band, 8 consecutive columns = 16 contiguous bytes
+    idx = lo_plane_index(M, N)
+    assert idx.unique().numel() == M * N and int(idx.max()) < lo_plane_bytes(M, N)
+    assert idx[35, 16:24].tolist() == list(range(int(idx[35, 16]), int(idx[35, 16]) + 8))
+    assert int(idx[43, 16]) == int(idx[35, 16]) + 8 and int(idx[35, 16]) % 16 == 0 and int(idx[35, 24]) == int(idx[35, 16]) + 128
+    # f16 engine: hi = nearest f16 (ties to even, saturating), lo = the remainder in units of 2^(E(hi) - 18), 11 + 8 bits
     y = x.clamp(-65504.0, 65504.0)
-    y = torch.where(y.abs() < 2.0 ** -15, torch.zeros_like(y), y)
-    y[:4] = torch.tensor([2.0 ** -14, 65504.0, 1.00048828125, -2047.5])              # smallest normal, largest, a tie, a tie
+    y = torch.where(y.abs() < 2.0 ** -14, torch.zeros_like(y), y)
+    y[0, :4] = torch.tensor([2.0 ** -14, 65504.0, 1.00048828125, -2047.5])           # smallest normal, largest, a tie, a tie
     hi, lo = split_planes(y, torch.float16)
-    assert hi.dtype == torch.float16 and lo.dtype == torch.int16 and int(lo.abs().max()) <= 8192
-    assert torch.equal(join_planes(hi, lo), y)
-    assert torch.equal(hi, y.half())
-    z = torch.tensor([1e5, -3e38, 1e-9])                                              # beyond the range: saturates / tiny: 2^-38 steps
+    assert hi.dtype == torch.float16 and torch.equal(hi, y.half())
+    yr = join_planes(hi, lo)
+    assert ((yr - y).abs() <= y.abs() * 2.0 ** -18).all() and ((yr - y).abs() > y.abs() * 2.0 ** -19).float().mean() < 4e-3
+    z = torch.tensor([[1e5, -3e38, 1e-9, 0.0, 0.0, 0.0, 0.0, 0.0]])                   # beyond the range: saturates / tiny: 2^-32 steps
     hi, lo = split_planes(z, torch.float16)
-    assert hi[0].item() == 65504.0 and hi[1].item() == -65504.0
-    assert abs(join_planes(hi, lo)[2].item() - 1e-9) < 2.0 ** -38
+    assert hi[0, 0].item() == 65504.0 and hi[0, 1].item() == -65504.0
+    assert abs(join_planes(hi, lo)[0, 2].item() - 1e-9) < 2.0 ** -32
