@@ -477,7 +477,9 @@ int vision_embed(plipmi_engine* e, const float* pixels, const uint8_t* tiles_u8,
   // fp32 pixels, 16-bit engine, 16- / 32-pixel patches: the patch GEMM reads the pixels itself (im2col on load -- four pixels per lane
   // into registers, rounded to the operand type, written to its A stage), no unfold pass and no `patches` round trip.  Same operand
   // bits as the unfold kernel's, hence the same embedding rows.
-  const bool gather = g_patch_gather && !tiles_u8 && e->half() && !t.small && e->kpad == 3 * g.patch_size * g.patch_size &&
+  // uint8 tiles (round 6): the same gather on the HWC bytes, CLIP normalisation as one fma per pixel -- the rows the unfold_u8 pass +
+  // plain patch GEMM produce, bit for bit.
+  const bool gather = g_patch_gather && e->half() && !t.small && e->kpad == 3 * g.patch_size * g.patch_size &&
                       gemm_gather_supports(t.dtype, B, g.image_size, g.patch_size, t.D);
   if (gather) {
     { Scope sc(e, s, "cls_rows", 0, (double)B * t.D * 4);
@@ -485,9 +487,9 @@ int vision_embed(plipmi_engine* e, const float* pixels, const uint8_t* tiles_u8,
     GemmParams p;
     p.A = nullptr; p.W = e->patch_w; p.C = t.x; p.bias = e->vpos;
     p.M = B * e->np; p.N = t.D; p.K = e->kpad; p.lda = e->kpad; p.ldw = e->kpad; p.ldc = t.D; p.alpha = 1.f; p.np = e->np;
-    p.pix = pixels; p.img_hw = g.image_size; p.patch_log2 = g.patch_size == 32 ? 5 : 4;
+    p.pix = pixels; p.tiles = tiles_u8; p.img_hw = g.image_size; p.patch_log2 = g.patch_size == 32 ? 5 : 4;
     const char* name = "gemm_nt";
-    Scope sc(e, s, name, 2.0 * p.M * p.N * (double)p.K, (double)B * 3 * g.image_size * g.image_size * 4 + (double)p.N * p.K * e->esz + (double)p.M * p.N * 4);
+    Scope sc(e, s, name, 2.0 * p.M * p.N * (double)p.K, (double)B * 3 * g.image_size * g.image_size * (tiles_u8 ? 1 : 4) + (double)p.N * p.K * e->esz + (double)p.M * p.N * 4);
     const int rc = gemm_launch_gather(t.dtype, p, s, &name);
     if (e->prof) sc.rename(name_with_role(name, "patch_embed"));
     if (rc != 0) return fail(PLIPMI_ERR_HIP, "patch GEMM (im2col on load) failed: %s", hipGetErrorString((hipError_t)rc));

@@ -93,6 +93,11 @@ struct GemmParams {
   // register-staged converting A path).  pix = the pixels, img_hw = image side, patch_log2 = log2 of the patch side (4 or 5).
   const float* pix = nullptr;
   int img_hw = 0, patch_log2 = 0;
+  // ADDR 3: the same gather from native uint8 HWC tiles [B, H, W, 3] (plipmi_encode_image_u8; reproducibility/embedders/transform.py:45-52
+  // on 224 x 224 tiles reduces to (u8 / 255 - mean) / std): a lane loads the 12 bytes of four RGB pixels, takes the K tile's channel and
+  // normalises with ONE fma per pixel -- fl(b * A_c + B_c) rounds to the same bf16 / f16 as the unfold kernel's (b / 255 - mean_c) * (1 / std_c)
+  // for every byte value and channel (exhaustive: tests/test_host.py::test_u8_normalisation_by_one_fma_is_exact_after_rounding)
+  const unsigned char* tiles = nullptr;
   // Row count known only on the device (packed captions, kernels.h launch_text_pack): when set, the kernel processes
   // min(*m_dev, M) rows -- M then only sizes the grid; workgroups whose tile starts past the live rows exit at once
   const int* m_dev = nullptr;
@@ -267,6 +272,20 @@ __device__ __forceinline__ void pix_load16(u32x4& dst, unsigned voff, const i32x
 __device__ __forceinline__ void tie_regs5(u32x4& a, u32x4& b, u32x4& c, u32x4& d, u32x4& e) {
   asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e) : : "memory");
 }
+// ADDR 3: twelve bytes = four RGB pixels of a uint8 tile
+typedef __attribute__((ext_vector_type(3))) unsigned u32x3;
+__device__ __forceinline__ void pix_load12(u32x3& dst, unsigned voff, const i32x4 rsrc, unsigned soff) {
+  asm volatile("s_nop 4\n\tbuffer_load_dwordx3 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+__device__ __forceinline__ void tie_regs5(u32x3& a, u32x3& b, u32x3& c, u32x3& d, u32x3& e) {
+  asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e) : : "memory");
+}
+// CLIP normalisation of a byte of channel c as one fma: A_c = fl((1 / std_c) / 255), B_c = fl(-mean_c / std_c)  (bit patterns, so that no
+// compiler's constant folding can move them)
+__device__ __forceinline__ float u8_norm(float b, int c) {
+  const unsigned A[3] = {0x3c6f2e3cu, 0x3c75e324u, 0x3c68fb47u}, Bc[3] = {0xbfe568dbu, 0xbfe044b8u, 0xbfbd77d7u};
+  return fmaf(b, __builtin_bit_cast(float, A[c]), __builtin_bit_cast(float, Bc[c]));
+}
 
 // BM x BN block tile, WM x WN waves.  A wave owns (BN / WN) columns and a run of the tile's rows.  32x32 MFMA forms (fp32
 // engine, SCHED 0 .. 6): BM / 32 blocks are dealt to the WM wave rows MI = ceil(BM / 32 / WM) at a time, so the LAST wave row may
@@ -285,7 +304,8 @@ __device__ __forceinline__ void tie_regs5(u32x4& a, u32x4& b, u32x4& c, u32x4& d
 //           with runs under matrix work instead of in front of it (1893 -> 1768 cycles per K tile).
 //           (With two stages AND the 32x32 burst schedule the same move buys 0-2 % per kernel and nothing on the step; the
 //           streamed 16x16x32 two-stage form, SCHED 8, makes it pay: 2965 -> 2608 cycles per K tile, profiles/r04_gemm_m16.txt.)
-// ADDR 0: 64-bit per-lane global addresses (any operand size); 1: buffer resource + 32-bit lane offset (< 4 GiB).
+// ADDR 0: 64-bit per-lane global addresses (any operand size); 1: buffer resource + 32-bit lane offset (< 4 GiB);
+//      2 / 3: as 1 for W, the A tile gathered from fp32 pixels / uint8 tiles through registers (im2col on load, the patch GEMM).
 // waves per SIMD the kernel is built for: 2 (LDS caps residency there, so let the allocator use 256 VGPRs)
 // index sets of the staged fill: [p0, p1) without [g0, g1)
 constexpr int count_outside(int p0, int p1, int g0, int g1) {
@@ -338,7 +358,8 @@ void gemm_nt_kernel(const GemmParams p) {
   static_assert(!kM16 || sizeof(T) == 2, "the 16x16x32 form: 16-bit operands");
   static_assert(!kM16 || NSTAGE == (SCHED == 7 ? 3 : 2), "schedule 7 runs on the ring, 8 on two stages");
   static_assert(!kSpread || ADDR >= 1, "the spread fill batches buffer-form requests");
-  constexpr bool kGather = ADDR == 2;      // A gathered from fp32 pixels through registers (W: buffer-form LDS-DMA as ADDR 1)
+  constexpr bool kGather = ADDR >= 2;      // A gathered from fp32 pixels (2) / uint8 tiles (3) through registers (W: buffer-form LDS-DMA as ADDR 1)
+  constexpr bool kGatherU8 = ADDR == 3;
   static_assert(!kGather || (SCHED == 7 && EPI == EPI_PATCH), "im2col on load: the ring tile's patch epilogue only");
   constexpr int BK = 8 * ELEMS16;          // 128-byte rows
   constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, STAGE = A_BYTES + W_BYTES;
@@ -347,7 +368,7 @@ void gemm_nt_kernel(const GemmParams p) {
   // thread count the last A piece exists for the first waves only (wave-uniform test a_piece(i))
   constexpr int PA = kGather ? 0 : (BM * 8 + NT - 1) / NT, PW = BN * 8 / NT;   // (gathered A: no A pieces in the LDS-DMA fill)
   constexpr int PA_MIN = kGather ? 0 : BM * 8 / NT;      // pieces every wave issues (counted vmcnt of the three-stage ring)
-  constexpr int NAL = BM * 16 / NT;        // kGather: 16-byte pixel loads (4 fp32) per thread and K tile
+  constexpr int NAL = BM * 16 / NT;        // kGather: four-pixel loads (16 B of fp32 / 12 B of RGB bytes) per thread and K tile
   static_assert(!kGather || (BM * 16) % NT == 0, "gathered A: whole passes of four-pixel loads");
   static_assert(BM % 32 == 0 && TN % 32 == 0, "wave tile must be a multiple of the 32x32 MFMA tile");
   static_assert((BM * 8) % 64 == 0 && (BN * 8) % NT == 0, "staging passes must be whole wave pieces");
@@ -531,9 +552,10 @@ void gemm_nt_kernel(const GemmParams p) {
   i32x4 rs_p;
   unsigned pix_off[kGather ? NAL : 1];
   int ga_dst[kGather ? NAL : 1];
-  u32x4 ga[2][kGather ? NAL : 1];
+  using GA = std::conditional_t<kGatherU8, u32x3, u32x4>;
+  GA ga[2][kGather ? NAL : 1];
   if constexpr (kGather) {
-    rs_p = make_buffer_rsrc(p.pix);
+    rs_p = kGatherU8 ? make_buffer_rsrc(p.tiles) : make_buffer_rsrc(p.pix);
     const int P = 1 << p.patch_log2, g = p.img_hw >> p.patch_log2, f4_per_row = P >> 2;   // patch side, patches per image side
 #pragma unroll
     for (int i = 0; i < NAL; ++i) {
@@ -542,7 +564,10 @@ void gemm_nt_kernel(const GemmParams p) {
       r = r < Mrt ? r : Mrt - 1;
       const int img = r / p.np, pp = r - img * p.np, gi = pp / g, gj = pp - gi * g;
       const int j = f4 / f4_per_row, gq = f4 - j * f4_per_row;        // patch row inside the K tile, four-pixel group inside it
-      pix_off[i] = (unsigned)((((size_t)img * 3 * p.img_hw + gi * P + j) * p.img_hw + gj * P + gq * 4) * 4);
+      if constexpr (kGatherU8)   // HWC bytes: pixel (img, y, x) at ((img * H + y) * W + x) * 3; the channel is picked after the load
+        pix_off[i] = (unsigned)((((size_t)img * p.img_hw + gi * P + j) * p.img_hw + gj * P + gq * 4) * 3);
+      else
+        pix_off[i] = (unsigned)((((size_t)img * 3 * p.img_hw + gi * P + j) * p.img_hw + gj * P + gq * 4) * 4);
       const int kl = j * P + gq * 4;                                   // column inside the K tile: 16-byte chunk kl >> 3, half (kl >> 2) & 1
       ga_dst[i] = row * 128 + ((((kl >> 3) ^ ((row >> 1) & 7))) << 4) + ((kl >> 2) & 1) * 8;
     }
@@ -551,18 +576,22 @@ void gemm_nt_kernel(const GemmParams p) {
   auto gather_soff = [&](int t) __attribute__((always_inline)) -> unsigned {
     const int tpc_log2 = 2 * p.patch_log2 - 6;
     const int c = t >> tpc_log2, u0 = (t & ((1 << tpc_log2) - 1)) << (6 - p.patch_log2);
+    if constexpr (kGatherU8) return (unsigned)(u0 * p.img_hw * 3);
     return (unsigned)((c * p.img_hw + u0) * p.img_hw * 4);
   };
   constexpr int NALX = kGather ? NAL : 1;
-  auto gather_load = [&](u32x4 (&set)[NALX], int t) __attribute__((always_inline)) {
+  auto gather_load = [&](GA (&set)[NALX], int t) __attribute__((always_inline)) {
     if constexpr (kGather) {
       const unsigned soff = gather_soff(t);
 #pragma unroll
-      for (int i = 0; i < NAL; ++i) pix_load16(set[i], pix_off[i], rs_p, soff);
+      for (int i = 0; i < NAL; ++i) {
+        if constexpr (kGatherU8) pix_load12(set[i], pix_off[i], rs_p, soff);
+        else pix_load16(set[i], pix_off[i], rs_p, soff);
+      }
     }
   };
   // (leave: how many of this wave's vector-memory requests may still be outstanding -- one tile's, or none)
-  auto gather_wait = [&](u32x4 (&set)[NALX], bool one_tile) __attribute__((always_inline)) {
+  auto gather_wait = [&](GA (&set)[NALX], bool one_tile) __attribute__((always_inline)) {
     if constexpr (kGather) {
       static_assert(NAL == 5, "the wait statement names five register sets");
       if (one_tile) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NAL + PW) : "memory");
@@ -570,15 +599,38 @@ void gemm_nt_kernel(const GemmParams p) {
       tie_regs5(set[0], set[1], set[2], set[3], set[4]);
     }
   };
-  auto gather_store = [&](u32x4 (&set)[NALX], int stage) __attribute__((always_inline)) {   // fp32 -> operand type (the unfold kernel's rounding), into the A stage
+  // t: the K tile the set holds (uint8 tiles: its channel picks the bytes and the normalisation constants; wave-uniform)
+  auto gather_store = [&](GA (&set)[NALX], int stage, int t) __attribute__((always_inline)) {   // -> operand type (the unfold kernels' rounding), into the A stage
     if constexpr (kGather && sizeof(T) == 2) {
       using Th = std::conditional_t<sizeof(T) == 2, T, bf16_t>;
       using X4h = typename half_traits<Th>::x4;
+      if constexpr (kGatherU8) {
+        const int c = t >> (2 * p.patch_log2 - 6);
+        auto put = [&](auto c_c) __attribute__((always_inline)) {
+          constexpr int C = decltype(c_c)::value;        // the lane's four pixels are bytes C, C + 3, C + 6, C + 9 of its twelve
 #pragma unroll
-      for (int i = 0; i < NAL; ++i) {
-        const f32x4 v = __builtin_bit_cast(f32x4, set[i]);
-        const X4h pk = {from_f32<Th>(v[0]), from_f32<Th>(v[1]), from_f32<Th>(v[2]), from_f32<Th>(v[3])};
-        *reinterpret_cast<X4h*>(smem + stage * STAGE + ga_dst[i]) = pk;
+          for (int i = 0; i < NAL; ++i) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              constexpr int dummy = 0; (void)dummy;
+              const int byte = C + 3 * e;
+              v[e] = u8_norm((float)((set[i][byte >> 2] >> (8 * (byte & 3))) & 0xffu), C);
+            }
+            const X4h pk = {from_f32<Th>(v[0]), from_f32<Th>(v[1]), from_f32<Th>(v[2]), from_f32<Th>(v[3])};
+            *reinterpret_cast<X4h*>(smem + stage * STAGE + ga_dst[i]) = pk;
+          }
+        };
+        if (c == 0) put(std::integral_constant<int, 0>{});
+        else if (c == 1) put(std::integral_constant<int, 1>{});
+        else put(std::integral_constant<int, 2>{});
+      } else {
+#pragma unroll
+        for (int i = 0; i < NAL; ++i) {
+          const f32x4 v = __builtin_bit_cast(f32x4, set[i]);
+          const X4h pk = {from_f32<Th>(v[0]), from_f32<Th>(v[1]), from_f32<Th>(v[2]), from_f32<Th>(v[3])};
+          *reinterpret_cast<X4h*>(smem + stage * STAGE + ga_dst[i]) = pk;
+        }
       }
     }
   };
@@ -858,7 +910,7 @@ void gemm_nt_kernel(const GemmParams p) {
       stage_issue(0);
       if (KT > 1) { gather_load(ga[1], 1); stage_issue(1); }
       gather_wait(ga[0], KT > 1);
-      gather_store(ga[0], 0);
+      gather_store(ga[0], 0, 0);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     } else {
     stage_issue(0);
@@ -887,7 +939,7 @@ void gemm_nt_kernel(const GemmParams p) {
         // tile kt+1: its pixels (set S ^ 1) and this wave's W pieces have arrived -- only tile kt+2's requests may be outstanding;
         // round and write its A rows, publish, then the last step's MFMAs with the next tile's first fragment reads
         gather_wait(ga[S ^ 1], fb >= 0);
-        gather_store(ga[S ^ 1], nxt);
+        gather_store(ga[S ^ 1], nxt, kt + 1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __syncthreads();
         __builtin_amdgcn_sched_barrier(0);

@@ -160,11 +160,15 @@ bool gemm_gather_supports(int dtype, int B, int image, int patch, int N) {
 }
 int gemm_launch_gather(int dtype, const GemmParams& p, hipStream_t stream, const char** kernel_name) {
   if (p.M <= 0) return 0;
-  if (!p.pix || (dtype != 1 && dtype != 2) || p.N % 256 || p.K % 64 || p.K / 64 < 2) return (int)hipErrorInvalidValue;
+  if ((!p.pix && !p.tiles) || (dtype != 1 && dtype != 2) || p.N % 256 || p.K % 64 || p.K / 64 < 2) return (int)hipErrorInvalidValue;
   GemmParams pr = p;
   pr.gw = 0;    // N-major sweep: the three or four column tiles of a row panel read the same pixels back to back
-  if (kernel_name) *kernel_name = dtype == 1 ? "gemm_nt<bf16,160x256_w2x4_ring3,patch_gather>" : "gemm_nt<f16,160x256_w2x4_ring3,patch_gather>";
-  GemmLaunchFn fn = dtype == 1 ? gemm_get_gather_bf16() : gemm_get_gather_f16();
+  const bool u8 = p.tiles != nullptr;
+  if (kernel_name)
+    *kernel_name = u8 ? (dtype == 1 ? "gemm_nt<bf16,160x256_w2x4_ring3,patch_gather_u8>" : "gemm_nt<f16,160x256_w2x4_ring3,patch_gather_u8>")
+                      : (dtype == 1 ? "gemm_nt<bf16,160x256_w2x4_ring3,patch_gather>" : "gemm_nt<f16,160x256_w2x4_ring3,patch_gather>");
+  GemmLaunchFn fn = u8 ? (dtype == 1 ? gemm_get_gather_u8_bf16() : gemm_get_gather_u8_f16())
+                       : (dtype == 1 ? gemm_get_gather_bf16() : gemm_get_gather_f16());
   return fn(pr, stream);
 }
 

@@ -33,6 +33,8 @@ int gemm_num_cus();  // gemm.hip
 // pixels (GemmParams.pix); 16-bit types only.
 GemmLaunchFn gemm_get_gather_bf16();
 GemmLaunchFn gemm_get_gather_f16();
+GemmLaunchFn gemm_get_gather_u8_bf16();   // ... from native uint8 HWC tiles (GemmParams.tiles), CLIP normalisation fused
+GemmLaunchFn gemm_get_gather_u8_f16();
 
 template <typename T, int EPI>
 int launch_naive(const GemmParams& p, hipStream_t stream) {

@@ -441,3 +441,39 @@ def test_patch_gemm_im2col_on_load_is_bit_identical(arch, B, dtype):
     small = model.get_image_features(pixel_values=px[:8])
     assert torch.equal(small, f1[:8])
     model.engine.close()
+
+
+@pytest.mark.parametrize("arch,B", [("ViT-B/32", 256), ("ViT-B/16", 64), ("ViT-B/32", 230)])
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_patch_gemm_im2col_on_load_from_uint8_tiles_is_bit_identical(arch, B, dtype):
+    """Round 6: the same gather for NATIVE uint8 tiles (plipmi_encode_image_u8, configs[3]'s whole corpus path) --
+    gemm.h ADDR 3: a lane loads the 12 bytes of four RGB pixels, picks the K tile's channel and normalises with one fma per pixel.
+    Bit-identical to the unfold_u8 pass + plain patch GEMM (the fma rounds to the same operand for every byte value,
+    tests/test_host.py::test_u8_normalisation_by_one_fma_is_exact_after_rounding), and the unfold pass is gone from the launches."""
+    from plip_amd import _lib, weights as W
+    from plip_amd.config import get_config
+    from plip_amd.model import PlipModel
+    lib = _lib.load()
+    cfg = get_config(arch)
+    model = PlipModel(cfg, W.synthetic_state_dict(cfg, 5), dtype=dtype, max_batch=B)
+    rs = np.random.RandomState(31)
+    tiles = torch.from_numpy(rs.randint(0, 256, size=(B, cfg.image_size, cfg.image_size, 3), dtype=np.uint8))
+    tiles[0] = 0
+    tiles[1] = 255                                            # both ends of the byte range in every channel
+    got = {}
+    try:
+        for on in (0, 1):
+            lib.plipmi_test_patch_gather(on)
+            rows = []
+            with model.engine.profile(rows):
+                f = model.engine.encode_image_u8(tiles, False)
+            got[on] = (f, {r["name"].split("|")[0] for r in rows})
+    finally:
+        lib.plipmi_test_reset_hooks()
+    assert torch.isfinite(got[1][0]).all() and torch.equal(got[0][0], got[1][0])
+    assert "unfold_patches_u8" in got[0][1] and not any("patch_gather" in n for n in got[0][1]), got[0][1]
+    assert "unfold_patches_u8" not in got[1][1] and any("patch_gather_u8" in n for n in got[1][1]), got[1][1]
+    small = model.engine.encode_image_u8(tiles[:8], False)    # small batches keep the unfold pass: same bits
+    assert torch.equal(small, got[1][0][:8])
+    model.engine.close()
+

@@ -381,3 +381,29 @@ def test_split_plane_host_mirror_follows_the_format():
     hi, lo = split_planes(z, torch.float16)
     assert hi[0, 0].item() == 65504.0 and hi[0, 1].item() == -65504.0
     assert abs(join_planes(hi, lo)[0, 2].item() - 1e-9) < 2.0 ** -32
+
+
+def test_u8_normalisation_by_one_fma_is_exact_after_rounding():
+    """csrc/gemm.h ADDR 3 (im2col on load from uint8 tiles) normalises a byte of channel c as fl(b * A_c + B_c); the unfold kernel --
+    and the reference's transform, reproducibility/embedders/transform.py:45-52 -- compute (b / 255 - mean_c) * (1 / std_c) in three fp32
+    roundings.  The two agree after rounding to the operand type for EVERY byte value and channel, bf16 and f16: checked here on all
+    2 x 3 x 256 cases with the kernel's constants (bit patterns) -- so the fused patch GEMM's A operand is the unfold pass's, bit for bit."""
+    import numpy as np
+    src = open(os.path.join(ROOT, "plip_amd", "csrc", "gemm.h")).read()
+    m = re.search(r"const unsigned A\[3\] = \{(0x[0-9a-f]+)u, (0x[0-9a-f]+)u, (0x[0-9a-f]+)u\}, Bc\[3\] = \{(0x[0-9a-f]+)u, (0x[0-9a-f]+)u, (0x[0-9a-f]+)u\}", src)
+    assert m, "u8_norm's constants not found in gemm.h"
+    bits = np.array([int(x, 16) for x in m.groups()], dtype=np.uint32)
+    A, Bc = bits[:3].view(np.float32), bits[3:].view(np.float32)
+    mean = np.array([0.48145466, 0.4578275, 0.40821073], dtype=np.float32)
+    istd = (np.float32(1.0) / np.array([0.26862954, 0.26130258, 0.27577711], dtype=np.float32)).astype(np.float32)
+    assert np.array_equal(A, (istd.astype(np.float64) / 255.0).astype(np.float32)) and np.array_equal(Bc, (-mean.astype(np.float64) * istd.astype(np.float64)).astype(np.float32))
+    b = np.arange(256, dtype=np.float32)
+
+    def bf16(x):
+        u = x.astype(np.float32).view(np.uint32).astype(np.uint64)
+        return ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)
+
+    for c in range(3):
+        three = (((b / np.float32(255.0)).astype(np.float32) - mean[c]).astype(np.float32) * istd[c]).astype(np.float32)
+        one = (b.astype(np.float64) * np.float64(A[c]) + np.float64(Bc[c])).astype(np.float32)    # fma: exact product and sum in fp64, ONE rounding
+        assert np.array_equal(bf16(one), bf16(three)) and np.array_equal(one.astype(np.float16).view(np.uint16), three.astype(np.float16).view(np.uint16)), c
