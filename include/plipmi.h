@@ -202,6 +202,10 @@ int plipmi_check_async(plipmi_handle h);
  * staging buffers (two device-to-device copies per call), results are bit-identical to the eager path.  The reference's
  * zero_shot_classification runs both towers at batch 8 (plip.py:90-91), where the step is launch-bound. */
 int plipmi_set_graph_batch(plipmi_handle h, int max_batch);
+/* plipmi_config.pass_batch as the handle resolved it (0 = encode calls are never split): a host layer that drives BOTH towers of a
+ * batch on two streams (plip_amd.Engine.encode_pair) cuts the batch itself, so that the towers of one pass finish together before
+ * the next pass starts -- the rhythm of back-to-back calls of pass_batch samples, which is what the split is meant to reproduce. */
+int plipmi_get_pass_batch(plipmi_handle h);
 
 /* Latency path (16-bit engines; OFF by default).  The big GEMM tiles walk K serially whatever M is -- fc2 at batch 8 is 48
  * dependent K tiles for 24 workgroups -- so after plipmi_set_latency_batch(h, n) an encode call of at most n samples runs every

@@ -857,6 +857,8 @@ int plipmi_set_graph_batch(plipmi_handle h, int max_batch) {
   return PLIPMI_OK;
 }
 
+int plipmi_get_pass_batch(plipmi_handle h) { return h ? h->pass_batch : 0; }
+
 int plipmi_set_latency_batch(plipmi_handle h, int max_batch) {
   if (!h) return fail(PLIPMI_ERR_INVALID, "null handle");
   const int v = h->half() ? std::max(0, max_batch) : 0;

@@ -27,6 +27,7 @@ _DTYPES = {"fp32": _lib.F32, "f32": _lib.F32, "float32": _lib.F32, torch.float32
 DEFAULT_TEXT_F16_LAYERS = 8
 
 _TORCH_DTYPE = {_lib.F32: torch.float32, _lib.BF16: torch.bfloat16, _lib.F16: torch.float16}
+_SIDE_STREAMS = {}      # device -> the text tower's stream of Engine.encode_pair (see _encode_pair_two_streams)
 
 
 def _code(dt) -> int:
@@ -131,6 +132,7 @@ class Engine:
             stream.synchronize()  # packing done -> the fp32 upload copies can go
             del dev
         self.device_name = self.lib.plipmi_device_name(self._h).decode()
+        self.pass_batch = int(self.lib.plipmi_get_pass_batch(self._h))     # plipmi_config.pass_batch as resolved (0 = never split)
         if latency_batch:
             self.set_latency_batch(latency_batch)
 
@@ -213,6 +215,16 @@ class Engine:
         """Both towers of one step.  With ``overlap`` the text tower is enqueued on a second HIP stream:
         the towers are independent (separate workspaces), so the tail of one tower's GEMM grid -- 150..600
         workgroups over 256 CUs -- is filled by the other tower's kernels instead of idling."""
+        n = pixels.shape[0]
+        if overlap and self.pass_batch > 0 and n >= 2 * self.pass_batch and input_ids.shape[0] == n:
+            # plipmi_config.pass_batch at the level that owns BOTH streams: equal passes, the two towers of a pass joined before the next
+            # one starts -- exactly back-to-back pair steps of pass_batch samples (left to the per-tower calls, the faster tower runs a
+            # whole pass ahead and a bs = 512 step measured 5 % SLOWER than one pass; profiles/r06_batch_scaling.txt).  Same bits.
+            k = -(-n // self.pass_batch)
+            bounds = [(i * n // k, (i + 1) * n // k) for i in range(k)]
+            parts = [self._encode_pair_two_streams(pixels[a:b], input_ids[a:b], None if attention_mask is None else attention_mask[a:b],
+                                                   normalize) for a, b in bounds]
+            return torch.cat([p[0] for p in parts]), torch.cat([p[1] for p in parts])
         if not overlap:
             return self._encode_image_any(pixels, normalize), self.encode_text(input_ids, attention_mask, normalize)
         return self._encode_pair_two_streams(pixels, input_ids, attention_mask, normalize)
@@ -245,9 +257,13 @@ class Engine:
 
     def _encode_pair_two_streams(self, pixels, input_ids, attention_mask, normalize):
         main = torch.cuda.current_stream(self.device)
-        if getattr(self, "_side", None) is None:
-            self._side = torch.cuda.Stream(device=self.device)
-        side = self._side
+        # ONE side stream per device and process, shared by every engine: HIP streams share a handful of hardware queues, and which
+        # queue a new stream lands on depends on how many streams the process has created before.  An engine created late (the ninth
+        # of a bench run) used to get a side stream on the main stream's queue -- its two towers then ran in order, 4.47 instead of
+        # 4.28 ms per step, which is what BENCH_r05's "throughput falls with batch" (bs512 54.6 k) mostly was (profiles/r06_batch_scaling.txt).
+        side = _SIDE_STREAMS.get(self.device)
+        if side is None:
+            side = _SIDE_STREAMS[self.device] = torch.cuda.Stream(device=self.device)
         side.wait_stream(main)                      # inputs produced on the main stream are ready
         with torch.cuda.stream(side):
             txt = self.encode_text(input_ids, attention_mask, normalize)

@@ -349,6 +349,11 @@ def test_large_batches_run_as_equal_passes_with_the_same_bits(engines, dtype):
             torch.cuda.synchronize()
         for a, b in zip(one.got, split.got):
             assert a.shape == b.shape and torch.equal(a, b)
+        # both towers on two streams (Engine.encode_pair): the host layer cuts the batch itself, pass by pass with the towers joined
+        assert split.engine.pass_batch == 16 and one.engine.pass_batch == 0
+        pa, pb = one.engine.encode_pair(px, ids, mask, normalize=True, overlap=True), split.engine.encode_pair(px, ids, mask, normalize=True, overlap=True)
+        torch.cuda.synchronize()
+        assert torch.equal(pa[0], pb[0]) and torch.equal(pa[1], pb[1]) and torch.equal(pa[0], one.got[0]) and torch.equal(pa[1], one.got[2])
         rows = []
         with split.engine.profile(rows):                       # 41 samples: 3 passes -> 3 patch GEMMs; 31 < 2 * 16: one
             split.engine.encode_image(px, True)
