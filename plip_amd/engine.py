@@ -132,6 +132,8 @@ class Engine:
             stream.synchronize()  # packing done -> the fp32 upload copies can go
             del dev
         self.device_name = self.lib.plipmi_device_name(self._h).decode()
+        if self.device not in _SIDE_STREAMS:                                # as early as possible: the first ordinary stream of the process
+            _SIDE_STREAMS[self.device] = torch.cuda.Stream(device=self.device)
         self.pass_batch = int(self.lib.plipmi_get_pass_batch(self._h))     # plipmi_config.pass_batch as resolved (0 = never split)
         if latency_batch:
             self.set_latency_batch(latency_batch)
