@@ -269,6 +269,18 @@ def logits_error_vs_hf_golden(model, cfg, sd, px, ids, mask, B, arch, fixture="v
     path = os.path.join(ROOT, "tests", "golden", fixture + ".npz")
     got = model(input_ids=ids, pixel_values=px, attention_mask=mask)
     lpi = got.logits_per_image.cpu().numpy()
+    if arch == "ViT-L/14@336px" and os.path.exists(path) and fixture != "vitb32_b256":
+        # the first rows of the ViT-L/14@336 share ARE a committed HF fixture's inputs (oracle/make_golden.py vitl14_336_b8)
+        g = np.load(path)
+        n = g["ids"].shape[0]
+        if n <= B and np.array_equal(g["ids"], ids[:n].cpu().numpy()):
+            want = g["logits_per_image"]
+            return {"cosine": float(np.abs(lpi[:n, :n] / scale - want / scale).max()),
+                    "image_embeds": float(np.abs(got.image_embeds[:n].cpu().numpy() - g["image_embeds"]).max()),
+                    "text_embeds": float(np.abs(got.text_embeds[:n].cpu().numpy() - g["text_embeds"]).max()),
+                    "vs": f"HF transformers CLIPModel (CPU fp32) golden logits, tests/golden/{fixture}.npz (the batch's first {n} pairs; "
+                          f"a row's embedding does not depend on the batch it travels in)",
+                    "pairs": n, "logits_compared": n * n}
     if arch == "ViT-B/32" and B == 256 and os.path.exists(path):
         g = np.load(path)
         if np.array_equal(g["ids"], ids.cpu().numpy()):
@@ -772,9 +784,13 @@ def _run(args, world, rank, world_size_env, model_factory, emit):
             cl = get_config("ViT-L/14@336px")
             sdl = W.synthetic_state_dict(cl, seed=3)
             ml = PlipModel(cl, sdl, device=dev, dtype=args.dtype, max_batch=64)
+            # rows 0..7 = the inputs of tests/golden/vitl14_336_b8.npz (HF outputs for exactly these pixels / ids), the rest device noise
             g = torch.Generator(device=dev).manual_seed(6)
             pxl = torch.randn((64, 3, cl.image_size, cl.image_size), generator=g, device=dev)
+            pxl[:8] = torch.from_numpy(W.synthetic_pixels(cl, 8, seed=6000)).to(dev)
             il, mk = W.synthetic_ids(cl, 64, seed=42)
+            i8, m8 = W.synthetic_ids(cl, 8, seed=6001)
+            il[:8], mk[:8] = i8, m8
             il, mk = torch.from_numpy(il).to(dev), torch.from_numpy(mk).to(dev)
             dtl, _ = timed_steps(lambda: sharded_pair_logits(ml, pxl, il, mk, overlap=bool(args.overlap), equal_shards=True), 5, dev, 2)
             res["vitl14_336_b64"] = {
@@ -785,7 +801,8 @@ def _run(args, world, rank, world_size_env, model_factory, emit):
                 "dense_equivalent_frac_of_mfma_peak": round(64 * cl.pair_flops() / dtl / 1e12 / PEAK_TFLOPS[args.dtype], 4)}
             if not args.no_cpu_baseline:
                 # this very batch's first pairs against the CPU oracle (batch-invariant engine: the same bits as inside the 64)
-                res["vitl14_336_b64"]["logits_max_abs_err"] = logits_error_vs_hf_golden(ml, cl, sdl, pxl, il, mk, 64, "ViT-L/14@336px")
+                res["vitl14_336_b64"]["logits_max_abs_err"] = logits_error_vs_hf_golden(ml, cl, sdl, pxl, il, mk, 64, "ViT-L/14@336px",
+                                                                                        fixture="vitl14_336_b8")
             ml.engine.close()
             del ml, pxl
         except Exception as e:  # pragma: no cover

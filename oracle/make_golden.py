@@ -43,9 +43,12 @@ CASES = {
     # BASELINE.json configs[4]'s architecture end to end: 336 px / patch 14 = 577 vision tokens (chunked MFMA attention inside
     # a 24-layer tower), 588 -> 640 zero-padded patch rows, width 1024 / 16 heads, text width 768 / 12 heads, projection 768
     "vitl14_336_b2": ("ViT-L/14@336px", 2, 3, 41, 42, "eos", None),
+    # ... and the first eight pairs of the ViT-L/14@336 share bench.py times (`vitl14_336_b64`: weights seed 3, pixels seed 6000, ids
+    # seed 6001): the line's error field for that architecture is then against HF itself, not the numpy oracle
+    "vitl14_336_b8": ("ViT-L/14@336px", 8, 3, 6000, 6001, "eos", None),
 }
 # cases whose fixtures hold embeddings and logits only (no features of every row / hidden states)
-SLIM = {"vitb32_b256", "vitb32_b256_heavy"}
+SLIM = {"vitb32_b256", "vitb32_b256_heavy", "vitl14_336_b8"}
 # hidden-state rows are stored at these depths only (fractions of the tower depth) for the big architectures
 HIDDEN_DEPTHS = {"vitl14_336_b2": (0, 1, 12, 24)}
 

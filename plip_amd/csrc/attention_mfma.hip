@@ -145,6 +145,13 @@ __global__ __launch_bounds__(64 * KT) __attribute__((amdgpu_waves_per_eu(4, 4)))
       // after a shift by 4hi its bit sits at a compile-time position, so masking a score is a 1-bit field extract (0 / -1),
       // an AND that turns it into 0.0 / -inf, and an add -- no compares, no 64-bit shifts, no branches.  (The two-operation form,
       // a bit select against -inf, was miscompiled by this hipcc: its v_bitop3_b32 folding mixed the elements' masks.)
+      // (round 6) a tile every query of the wave may use entirely -- all 32 keys valid and, under the causal mask, wholly below the
+      // diagonal: nothing to mask (wave-uniform test; the 50-token vision tower's first key tile is always one)
+      if (live && vw[t] == 0xffffffffu && (!causal || 32 * t + 31 <= q0)) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rmax = fmaxf(rmax, sc[t][r]);
+        continue;
+      }
       unsigned bits = live ? vw[t] : 0u;
       if (causal) {
         const int d = qidx - 32 * t;

@@ -169,9 +169,12 @@ __global__ __launch_bounds__(kNT) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     trace_real0 = __builtin_amdgcn_s_memrealtime();
     trace[5] = lid;
   }
+  // (round 6) the compiler-visible loads of this block -- statistics partials, biases, mask words -- are waited for with counted vmcnt
+  // the compiler derives from ITS loads only; the LDS-DMA fills are inline asm it cannot see, so any such wait placed behind them drains
+  // both tiles' fills first and the rest of the statistics loads then start a second round trip (3.45 us of prologue against 1.3 us in
+  // the GEMM kernels).  The fills of tile 0 go out first (the barrier needs them anyway), the block's own loads next, tile 1 behind.
   fill_a(0);
   fill_w(0);
-  if (KT > 1) { fill_a(1); fill_w(1); }
   {
     float* ln_rows = reinterpret_cast<float*>(smem + kLnRows);
     const int ns = D / kLnSlice;
@@ -196,6 +199,7 @@ __global__ __launch_bounds__(kNT) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       mkw[(wave >> 1) * 4 + 2 * (wave & 1) + 1] = (unsigned)(bits >> 32);
     }
   }
+  if (KT > 1) { fill_a(1); fill_w(1); }
   if (KT > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PA + PW) : "memory");   // tile 0 has landed (in-order retirement), tile 1 may still fly
   else wait_vm0();
   __syncthreads();
@@ -259,7 +263,10 @@ __global__ __launch_bounds__(kNT) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   if (trace && tid == 0) trace[3] = __builtin_amdgcn_s_memtime();
 
   // ---- epilogue 2: attention, two waves per caption
-  const int cl = wave >> 1, whalf = wave & 1;             // caption of the tile, which of its two waves
+  // caption of the tile, and which of its two waves: 0 = query blocks 0 + 1 (the longer instruction stream), 1 = block 2.  Waves w and
+  // w + 4 of a workgroup share a SIMD (dispatch order): the roles are dealt so that every SIMD hosts one wave of each kind (round 6;
+  // wave & 1 put both long waves of captions 0 and 2 on SIMD 0 and both of captions 1 and 3 on SIMD 2)
+  const int cl = wave >> 1, whalf = (wave ^ (wave >> 2)) & 1;
   const int cap = cap0 + cl;
   if (cap >= p.B && !trace) return;                       // wave-uniform (no barrier follows on the product path)
   if (cap < p.B) {
@@ -310,7 +317,17 @@ __global__ __launch_bounds__(kNT) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
       for (int t = 0; t < KTL; ++t) {
         const bool live = !(p.causal && 32 * t > q0 + 31);
-        unsigned bits = live ? vw[t] : 0u;
+        // (round 6) a tile entirely above the diagonal: its scores would all become -inf and change no maximum; the exp loop below
+        // zeroes them and the P V products skip the tile -- no mask arithmetic for it (three of the six tile passes of the wave that
+        // owns query blocks 0 + 1)
+        if (!live) continue;                                 // wave-uniform
+        // a tile every query of the block may use entirely (below the diagonal, all 32 keys valid): nothing to mask (wave-uniform)
+        if (vw[t] == 0xffffffffu && (!p.causal || 32 * t + 31 <= q0)) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) rmax[b] = fmaxf(rmax[b], sc[b][t][r]);
+          continue;
+        }
+        unsigned bits = vw[t];
         if (p.causal) {
           const int d = qidx - 32 * t;
           bits &= d < 0 ? 0u : (d >= 31 ? 0xffffffffu : (2u << d) - 1u);

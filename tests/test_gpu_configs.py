@@ -26,6 +26,27 @@ def _engine_args(dtype):
     return dict(dtype="bf16", text_f16=True) if dtype == "bf16+text_f16" else dict(dtype=dtype)
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_vitl14_336_first_pairs_of_the_bench_share_against_hf(dtype, golden):
+    """tests/golden/vitl14_336_b8.npz: HF's embeddings and logits for the first eight pairs of the ViT-L/14@336 batch bench.py times
+    (`vitl14_336_b64`) -- the bench line's error field for that architecture is against HF itself, not the numpy oracle."""
+    from plip_amd.model import PlipModel
+    g = golden("vitl14_336_b8")
+    cfg, sd, px, ids, mask = case_inputs("vitl14_336_b8")
+    assert np.array_equal(g["ids"], ids)
+    model = PlipModel(cfg, sd, dtype=dtype, max_batch=8)
+    try:
+        out = model(input_ids=torch.from_numpy(ids), pixel_values=torch.from_numpy(px), attention_mask=torch.from_numpy(mask))
+        scale = np.exp(np.float64(sd["logit_scale"]))
+        cos_err = np.abs(out.logits_per_image.cpu().numpy() - g["logits_per_image"]).max() / scale
+        e_img = np.abs(out.image_embeds.cpu().numpy() - g["image_embeds"]).max()
+        e_txt = np.abs(out.text_embeds.cpu().numpy() - g["text_embeds"]).max()
+        print(f"ViT-L/14@336 b8 {dtype}: cosine err {cos_err:.2e}, image_embeds {e_img:.2e}, text_embeds {e_txt:.2e}")
+        assert cos_err < COS[dtype] and e_img < EMB[dtype] and e_txt < EMB[dtype]
+    finally:
+        model.engine.close()
+
+
 @pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
 def test_vitl14_336_against_hf_golden(dtype, golden):
     from plip_amd.model import PlipModel
