@@ -182,38 +182,55 @@ __device__ __forceinline__ float4 load4_split(const unsigned short* hi, const un
 }
 
 constexpr int kLnSlice = 64;
-__device__ __forceinline__ void ln_combine(const float* __restrict__ st, int ns, float inv_d, float eps, float& mean,
-                                           float& rstd) {
-  // ns is even (widths are multiples of 128): two slices per 16-byte load.  The loads of a 16-slice batch are
-  // UNCONDITIONAL (index clamped) and issued back to back -- a per-load predicate makes hipcc branch around each load
-  // and wait for it separately, i.e. one L2/HBM round trip per load; only the (wave-uniform) folding steps are guarded.
-  float n = 0.f, mu = 0.f, m2 = 0.f;
-  for (int j0 = 0; j0 < ns; j0 += 16) {
-    float4 v[8];
+// The fold is cut in two so that a kernel prologue can put its LDS-DMA fills BETWEEN the loads and their use (round 6): the loads of a
+// batch of (up to) 16 slices -- 8 float4, indices clamped, unconditional, issued back to back (a per-load predicate makes hipcc branch
+// around each load and wait for it separately: one L2 / HBM round trip per load) -- and the update sequence over them.  ln_combine is
+// the two run one after the other; all three are ONE source of arithmetic, so a row's rstd is the same bits wherever it is folded.
+__device__ __forceinline__ void ln_load16(const float* __restrict__ st, int ns, int j0, float4 (&v)[8]) {
+  // ns is even (widths are multiples of 128): two slices per 16-byte load
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int j = j0 + 2 * k < ns ? j0 + 2 * k : ns - 2;
-      v[k] = *reinterpret_cast<const float4*>(st + 2 * j);
-    }
+  for (int k = 0; k < 8; ++k) {
+    const int j = j0 + 2 * k < ns ? j0 + 2 * k : ns - 2;
+    v[k] = *reinterpret_cast<const float4*>(st + 2 * j);
+  }
+}
+// The arithmetic is spelled out operation by operation with contraction OFF: the fold is inlined into several kernels (gemm.h, the
+// small-M kernel, the fused text kernel) whose results must agree bit for bit (packed captions = padded captions, fused = two kernels),
+// and hipcc's default contraction fuses `a * b + c` differently from one inlining context to the next (round 6: a twin of this function
+// with compile-time bounds differed in the last bit of rstd).
+__device__ __forceinline__ void ln_fold16(const float4 (&v)[8], int ns, int j0, float& n, float& mu, float& m2) {
+#pragma clang fp contract(off)
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      if (j0 + 2 * k < ns) {
+  for (int k = 0; k < 8; ++k) {
+    if (j0 + 2 * k < ns) {   // wave-uniform
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const float sj = h ? v[k].z : v[k].x, qj = h ? v[k].w : v[k].y;
-          const float mj = sj * (1.0f / kLnSlice);
-          const float nn = n + (float)kLnSlice;
-          const float d = mj - mu;
-          const float w = (float)kLnSlice * __builtin_amdgcn_rcpf(nn);   // nn = 64 (j + 1): 1-ulp reciprocal of a small integer
-          mu += d * w;
-          m2 += qj + d * d * n * w;
-          n = nn;
-        }
+      for (int h = 0; h < 2; ++h) {
+        const float sj = h ? v[k].z : v[k].x, qj = h ? v[k].w : v[k].y;
+        const float mj = sj * (1.0f / kLnSlice);                       // exact (power of two)
+        const float nn = n + (float)kLnSlice;                           // exact (small integers)
+        const float d = mj - mu;
+        const float w = (float)kLnSlice * __builtin_amdgcn_rcpf(nn);   // nn = 64 (j + 1): 1-ulp reciprocal of a small integer
+        mu = __builtin_fmaf(d, w, mu);
+        const float t = (d * d) * n;
+        m2 = m2 + __builtin_fmaf(t, w, qj);
+        n = nn;
       }
     }
   }
+}
+__device__ __forceinline__ float ln_rstd(float m2, float inv_d, float eps) {
+  return __builtin_amdgcn_rsqf(__builtin_fmaf(m2, inv_d, eps));   // v_rsq_f32, 1 ulp: far below the bf16 rounding of what it scales
+}
+__device__ __forceinline__ void ln_combine(const float* __restrict__ st, int ns, float inv_d, float eps, float& mean,
+                                           float& rstd) {
+  float n = 0.f, mu = 0.f, m2 = 0.f;
+  for (int j0 = 0; j0 < ns; j0 += 16) {
+    float4 v[8];
+    ln_load16(st, ns, j0, v);
+    ln_fold16(v, ns, j0, n, mu, m2);
+  }
   mean = mu;
-  rstd = __builtin_amdgcn_rsqf(m2 * inv_d + eps);   // v_rsq_f32, 1 ulp: far below the bf16 rounding of what it scales
+  rstd = ln_rstd(m2, inv_d, eps);
 }
 
 // QuickGELU: x * sigmoid(1.702 x)  (transformers/activations.py:117-123)

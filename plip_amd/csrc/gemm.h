@@ -857,6 +857,8 @@ void gemm_nt_kernel(const GemmParams p) {
 
   // rstd of this tile's BM LayerNorm-input rows goes to LDS once, while the first K tile is in flight: the epilogue
   // then reads one float per row instead of walking the partials (a chain of L2 round trips per row) before the stores.
+  // (Round 6: requesting the partials BEFORE the first fill and folding them behind it -- so that the compiler's vmcnt for these loads
+  //  does not drain the inline-asm fills first -- measured level on fc1 / q/k/v and on the step, and is not done.)
   auto stage_ln_rows = [&]() {
     if constexpr (epi_is_ln(EPI)) {
       float* ln_rows = reinterpret_cast<float*>(smem + NSTAGE * STAGE);

@@ -169,10 +169,11 @@ __global__ __launch_bounds__(kNT) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     trace_real0 = __builtin_amdgcn_s_memrealtime();
     trace[5] = lid;
   }
-  // (round 6) the compiler-visible loads of this block -- statistics partials, biases, mask words -- are waited for with counted vmcnt
-  // the compiler derives from ITS loads only; the LDS-DMA fills are inline asm it cannot see, so any such wait placed behind them drains
-  // both tiles' fills first and the rest of the statistics loads then start a second round trip (3.45 us of prologue against 1.3 us in
-  // the GEMM kernels).  The fills of tile 0 go out first (the barrier needs them anyway), the block's own loads next, tile 1 behind.
+  // (round 6) Prologue order.  The compiler waits for ITS loads -- statistics partials, biases, mask words -- with counted vmcnt and cannot
+  // see the inline-asm LDS-DMA fills: any such wait placed behind fills drains them first (3.45 us of prologue in round 5 with both
+  // tiles' fills in front of this block).  Tile 0's fills go out first (the barrier needs them anyway), the block's own loads next,
+  // tile 1's fills behind them: 3.0 us.  (Requesting the statistics BEFORE tile 0's fills, as the GEMM kernels now do, measured level
+  // to +1 us here -- 32 more live registers across the fill in a 229-register kernel -- and is not used.)
   fill_a(0);
   fill_w(0);
   {
