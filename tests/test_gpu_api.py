@@ -354,6 +354,13 @@ def test_large_batches_run_as_equal_passes_with_the_same_bits(engines, dtype):
         pa, pb = one.engine.encode_pair(px, ids, mask, normalize=True, overlap=True), split.engine.encode_pair(px, ids, mask, normalize=True, overlap=True)
         torch.cuda.synchronize()
         assert torch.equal(pa[0], pb[0]) and torch.equal(pa[1], pb[1]) and torch.equal(pa[0], one.got[0]) and torch.equal(pa[1], one.got[2])
+        if dtype == "bf16":                                    # packed captions: every pass packs its own captions; same bits again
+            for m in (one, split):
+                m.engine.set_text_packing(True)
+                m.packed = m.engine.encode_text(ids, mask, True)
+                m.engine.set_text_packing(False)
+            torch.cuda.synchronize()
+            assert torch.equal(one.packed, split.packed) and torch.equal(one.packed, one.got[2])
         rows = []
         with split.engine.profile(rows):                       # 41 samples: 3 passes -> 3 patch GEMMs; 31 < 2 * 16: one
             split.engine.encode_image(px, True)
