@@ -361,11 +361,12 @@ def h2d_inclusive(model, cfg, px, ids, mask, steps, warmup, overlap, copy=None):
             trial.append(timed(4))
         fetch.stream = candidates[int(np.argmin(trial))]
         run(max(2, warmup))
-        dt = timed(steps)
+        wins = [timed(steps) for _ in range(3)]             # three windows of --steps steps; the median is reported
+        dt = float(np.median(wins))
         nbytes = sum(t.numel() * t.element_size() for t in host[0])
         out[label] = {"pairs_per_s": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 3), "host_bytes_per_step": nbytes,
                       "pcie_GBps": round(nbytes / dt / 1e9, 2),
-                      "copy_stream_trial_ms": [round(t * 1e3, 3) for t in trial]}
+                      "windows_ms": [round(t * 1e3, 3) for t in wins], "copy_stream_trial_ms": [round(t * 1e3, 3) for t in trial]}
         del host, devb
     out["note"] = ("inputs start in pinned host memory every step; a copy stream fills the second of two device buffers while the towers "
                    "run on the first (the pattern of plip_amd/pipeline.py); `value` above is the HBM-resident rate")
