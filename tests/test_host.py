@@ -407,3 +407,27 @@ def test_u8_normalisation_by_one_fma_is_exact_after_rounding():
         three = (((b / np.float32(255.0)).astype(np.float32) - mean[c]).astype(np.float32) * istd[c]).astype(np.float32)
         one = (b.astype(np.float64) * np.float64(A[c]) + np.float64(Bc[c])).astype(np.float32)    # fma: exact product and sum in fp64, ONE rounding
         assert np.array_equal(bf16(one), bf16(three)) and np.array_equal(one.astype(np.float16).view(np.uint16), three.astype(np.float16).view(np.uint16)), c
+
+
+def test_named_test_hooks_reject_values_outside_their_range():
+    """include/plipmi_test.h (round 6): the A/B hooks are separate, named, range-checked setters -- a stray value changes
+    nothing and says so (the old multiplexed plipmi_set_gemm_variant let 5000 fall through into an unrelated switch).  No GPU needed."""
+    from plip_amd import _lib
+    lib = _lib.load()
+    n = 0
+    while lib.plipmi_gemm_variant_name(n):
+        n += 1
+    try:
+        for fn, good, bad in ((lib.plipmi_test_force_gemm_tile, (-2, -1, 0, n - 1), (-3, n, 1000, 2001)),
+                              (lib.plipmi_test_fused_qkv_attention, (0, 1, 2), (-1, 3, 3002)),
+                              (lib.plipmi_test_patch_gather, (0, 1), (-1, 2, 4001))):
+            for v in good:
+                assert fn(v) == 0, (fn.__name__, v)
+            for v in bad:
+                assert fn(v) == 1 and str(v) in _lib.last_error(), (fn.__name__, v, _lib.last_error())
+        assert lib.plipmi_test_remap_gemm_tile(2, 3) == 0 and lib.plipmi_test_remap_gemm_tile(2, -1) == 0
+        for a, b in ((-1, 0), (n, 0), (0, n), (0, -2)):
+            assert lib.plipmi_test_remap_gemm_tile(a, b) == 1
+    finally:
+        lib.plipmi_test_reset_hooks()
+    assert lib.plipmi_get_pass_batch(None) == 0
