@@ -117,7 +117,8 @@ typedef struct plipmi_config {
   int32_t text_f16_layers; /* bf16 engine: this many LEADING blocks of the text tower run on IEEE-half (f16) MFMA operands, the
                             * rest of the tower and the whole image tower on bf16.  The bf16 engine's embedding error is mostly
                             * operand rounding in the text tower's first blocks; 0 = a pure bf16 engine,
-                            * t_layers = PLIPMI_FLAG_TEXT_TOWER_F16.  The residual stream stays exact fp32 across the switch. */
+                            * t_layers = PLIPMI_FLAG_TEXT_TOWER_F16.  The residual stream crosses the switch as the fp32 value the last f16 block's epilogue
+                            * computed, re-split for the bf16 blocks (operand plane + 8-bit remainder). */
   int32_t pass_batch;      /* An encode call of B samples runs as ceil(B / pass_batch) back-to-back passes of equal size on the
                             * caller's stream once B >= 2 * pass_batch, so that one pass's per-block activations stay resident in the
                             * 256 MiB Infinity Cache however large the caller's batch is (the reference's `batch_size` is the
@@ -173,7 +174,8 @@ int plipmi_encode_image(plipmi_handle h, const float* pixels, int B, float* out,
 
 /* Same, from raw tiles: uint8 [B,H,W,3] (HWC RGB, already image_size x image_size).  The CLIP normalisation
  * (u8/255 - mean)/std of reproducibility/embedders/transform.py:45-52 / HF CLIPImageProcessor is fused into the
- * patch unfold, so a tile crosses PCIe and HBM as 150 KB instead of 602 KB of fp32. */
+ * patch GEMM's operand load (large batches: im2col on load from the HWC bytes, one fma per pixel; small ones: a fused unfold pass --
+ * the same bits), so a tile crosses PCIe and HBM as 150 KB instead of 602 KB of fp32. */
 int plipmi_encode_image_u8(plipmi_handle h, const uint8_t* tiles, int B, float* out, int normalize, void* stream);
 
 /* ids            : int64 [B, context_length] token ids

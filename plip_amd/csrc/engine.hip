@@ -352,8 +352,9 @@ int run_gemm(plipmi_engine* e, const Tower& t, int epi, const void* A, const voi
 #define RUN(expr) do { int rc_ = (expr); if (rc_ != PLIPMI_OK) return rc_; } while (0)
 
 // Block l is about to be enqueued: launch with its operand type and, on a LayerNorm-folded engine, make the residual planes
-// speak it (hi IS the block's A operand).  The planes are re-coded in place, exactly: both formats hold the fp32 value bit for
-// bit (|x| < 65504), so a mixed tower's stream is the very stream of the unmixed ones up to the blocks' own arithmetic.
+// speak it (hi IS the block's A operand).  On the big-tile path the predecessor's fc2 epilogue already wrote the planes in this block's
+// format (GemmParams.planes_other); otherwise (the small-M path) they are re-coded in place: joined in the old code, split in the new
+// one -- one more rounding of the 8-bit remainder (common.h split_f32), the new hi = the value correctly rounded to the new operand type.
 int enter_block(plipmi_engine* e, Tower& t, int l, int M, hipStream_t s) {
   t.cur = t.layer_dtype(l);
   if (e->ln_fold && t.planes != t.cur) {
