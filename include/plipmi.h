@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define PLIPMI_VERSION 410 /* 0.4.1: `pass_batch` appended to the config struct -- a 0.4.0 caller's shorter struct means 0 = automatic;
+#define PLIPMI_VERSION 411 /* 0.4.1: `pass_batch` appended to the config struct -- a 0.4.0 caller's shorter struct means 0 = automatic;
                             * 0.4.0: plipmi_config starts with `struct_size` (the struct can grow at its tail without breaking
                             * callers compiled against an older header); test / A-B hooks moved to plipmi_test.h
                             * (0.3.1: `text_f16_layers`, PLIPMI_ERR_TOKEN_ID; 0.3.0: `flags`, `graph_batch`, PLIPMI_F16) */
@@ -124,7 +124,8 @@ typedef struct plipmi_config {
                             * 256 MiB Infinity Cache however large the caller's batch is (the reference's `batch_size` is the
                             * caller's, plip.py:31,55).  Same bits either way: a row's embedding does not depend on the batch it
                             * travels in.  0 = automatic (the largest multiple of 32 samples whose per-block working set fits,
-                            * 256 for ViT-B/32; no splitting for towers where even 128 samples do not fit), < 0 = never split. */
+                            * 256 for the 16-bit ViT-B/32 engines; no splitting where fewer than 256 samples fit -- the fp32 engine, ViT-L/14 --:
+                            * smaller passes lose more in the GEMMs than the cache returns), < 0 = never split. */
 } plipmi_config;
 
 /* One pre-LN transformer block, HF CLIPEncoderLayer naming; all DEVICE pointers
@@ -208,6 +209,13 @@ int plipmi_set_graph_batch(plipmi_handle h, int max_batch);
  * batch on two streams (plip_amd.Engine.encode_pair) cuts the batch itself, so that the towers of one pass finish together before
  * the next pass starts -- the rhythm of back-to-back calls of pass_batch samples, which is what the split is meant to reproduce. */
 int plipmi_get_pass_batch(plipmi_handle h);
+/* Do two HIP streams run their kernels SIDE BY SIDE?  HIP maps streams onto a few hardware queues, and which queue a new stream
+ * lands on depends on how many streams the process created before; two streams on one queue execute in order however independent
+ * their work is -- a caller that puts the two towers of a pair on such streams gets the one-stream step.  Runs a
+ * workgroup that only waits (no memory traffic) for 250 us on each stream at once, three times, and writes
+ * *ratio = shortest elapsed time / 250 us: about 1.0-1.2 when the streams overlap, about 2 when they share a queue.  Synchronises
+ * both streams; not for use under stream capture.  plip_amd.Engine.encode_pair picks its second stream with it, once. */
+int plipmi_streams_overlap(plipmi_handle h, void* stream_a, void* stream_b, float* ratio);
 
 /* Latency path (16-bit engines; OFF by default).  The big GEMM tiles walk K serially whatever M is -- fc2 at batch 8 is 48
  * dependent K tiles for 24 workgroups -- so after plipmi_set_latency_batch(h, n) an encode call of at most n samples runs every

@@ -64,6 +64,7 @@ hipError_t launch_pool_gather(const void* att, const void* hi, const void* lo, i
                               void* attp, float* xp, int B, int dtype, hipStream_t s, const int* cu = nullptr);
 
 hipError_t launch_l2_normalize(float* x, int N, int D, hipStream_t s);
+hipError_t launch_occupy(unsigned long long wall_clock_ticks, hipStream_t s);   // one workgroup, no memory traffic (plipmi_streams_overlap)
 // C[M,N] = A[M,K] . W[N,K]^T, exact fp32 MFMA, split-K over the four waves of a 32x32-tile workgroup (N, K % 32 == 0)
 // (also the MFMA form of the logits: C = scale * A . W^T; exchanging A and W gives the bit-exact transpose)
 hipError_t launch_head_gemm(const float* A, const float* W, float* C, int M, int N, int K, hipStream_t s, float scale = 1.0f);

@@ -779,6 +779,18 @@ hipError_t launch_l2_normalize(float* x, int N, int D, hipStream_t s) {
   return hipGetLastError();
 }
 
+// Occupies ONE compute unit for `ticks` of the constant-rate wall clock (s_memrealtime) and touches no memory: two of these on two
+// streams finish in the time of one when the streams sit on different hardware queues, and one after the other when they share a
+// queue -- what plipmi_streams_overlap measures.  Bounded (about a second) whatever the clock does.
+__global__ __launch_bounds__(64) void occupy_kernel(unsigned long long ticks) {
+  const unsigned long long t0 = wall_clock64();
+  for (int i = 0; i < (1 << 22) && wall_clock64() - t0 < ticks; ++i) __builtin_amdgcn_s_sleep(8);
+}
+hipError_t launch_occupy(unsigned long long ticks, hipStream_t s) {
+  hipLaunchKernelGGL(occupy_kernel, dim3(1), dim3(64), 0, s, ticks);
+  return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------
 // Logits: logits_per_image = scale * img @ txt^T (modeling_clip.py:814-817), fp32 FMA.
 // 64x64 tile per 256-thread block, 4x4 outputs per thread, K staged through LDS in

@@ -27,7 +27,8 @@ _DTYPES = {"fp32": _lib.F32, "f32": _lib.F32, "float32": _lib.F32, torch.float32
 DEFAULT_TEXT_F16_LAYERS = 8
 
 _TORCH_DTYPE = {_lib.F32: torch.float32, _lib.BF16: torch.bfloat16, _lib.F16: torch.float16}
-_SIDE_STREAMS = {}      # device -> the text tower's stream of Engine.encode_pair (see _encode_pair_two_streams)
+_SIDE_STREAMS = {}      # device -> the process's first ordinary stream, the first candidate below (created with the first engine)
+_PAIR_STREAMS = {}      # (device, main stream) -> the text tower's stream of Engine.encode_pair, CHECKED to overlap with that main stream
 
 
 def _code(dt) -> int:
@@ -257,15 +258,41 @@ class Engine:
         lengths instead of the padded 77 (include/plipmi.h plipmi_set_text_packing).  Off by default."""
         _lib.check(self.lib.plipmi_set_text_packing(self._h, int(bool(on))), "plipmi_set_text_packing")
 
+    def streams_overlap(self, a: "torch.cuda.Stream", b: "torch.cuda.Stream") -> float:
+        """include/plipmi.h plipmi_streams_overlap: about 1 when kernels of ``a`` and ``b`` run side by side, about 2 when the two
+        streams share a hardware queue (one waits for the other).  Synchronises both."""
+        r = C.c_float(0.0)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.plipmi_streams_overlap(self._h, C.c_void_p(a.cuda_stream), C.c_void_p(b.cuda_stream), C.byref(r)),
+                       "plipmi_streams_overlap")
+        return float(r.value)
+
+    def pair_stream(self, main: "torch.cuda.Stream") -> "torch.cuda.Stream":
+        """The stream ``encode_pair`` runs the text tower on while the vision tower runs on ``main``: the process's first ordinary
+        stream if it overlaps with ``main`` (it does in a process that created no streams before the engine -- the bench), otherwise
+        the first of a few fresh ones that does; measured once per (device, main stream), about a millisecond each."""
+        key = (self.device, main.cuda_stream)
+        side = _PAIR_STREAMS.get(key)
+        if side is None:
+            tried = []
+            for k in range(8):
+                cand = _SIDE_STREAMS[self.device] if k == 0 and self.device in _SIDE_STREAMS else torch.cuda.Stream(device=self.device)
+                ratio = 2.0 if cand.cuda_stream == main.cuda_stream else self.streams_overlap(main, cand)
+                tried.append((ratio, k, cand))          # every candidate stays alive until the choice: fresh ones then differ
+                if ratio < 1.5:
+                    break
+            side = _PAIR_STREAMS[key] = min(tried, key=lambda t: t[:2])[2]
+            self.pair_stream_ratio = min(tried, key=lambda t: t[:2])[0]
+        return side
+
     def _encode_pair_two_streams(self, pixels, input_ids, attention_mask, normalize):
         main = torch.cuda.current_stream(self.device)
-        # ONE side stream per device and process, shared by every engine: HIP streams share a handful of hardware queues, and which
-        # queue a new stream lands on depends on how many streams the process has created before.  An engine created late (the ninth
-        # of a bench run) used to get a side stream on the main stream's queue -- its two towers then ran in order, 4.47 instead of
-        # 4.28 ms per step, which is what BENCH_r05's "throughput falls with batch" (bs512 54.6 k) mostly was (profiles/r06_batch_scaling.txt).
-        side = _SIDE_STREAMS.get(self.device)
-        if side is None:
-            side = _SIDE_STREAMS[self.device] = torch.cuda.Stream(device=self.device)
+        # ONE side stream per (device, caller's stream) and process, shared by every engine: HIP streams share a handful of hardware
+        # queues, and which queue a new stream lands on depends on how many streams the process has created before.  An engine created
+        # late (the ninth of a bench run) used to get a side stream on the main stream's queue -- its two towers then ran in order, 4.47
+        # instead of 4.28 ms per step, which is what BENCH_r05's "throughput falls with batch" (bs512 54.6 k) mostly was
+        # (profiles/r06_batch_scaling.txt).  The stream is picked once by MEASURING that it runs beside the caller's (pair_stream).
+        side = self.pair_stream(main)
         side.wait_stream(main)                      # inputs produced on the main stream are ready
         with torch.cuda.stream(side):
             txt = self.encode_text(input_ids, attention_mask, normalize)

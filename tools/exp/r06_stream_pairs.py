@@ -27,8 +27,7 @@ res = []
 for main in [None] + pool[:4] + hi[:1]:
     for side in pool + hi:
         if side is main: continue
-        E._SIDE_STREAMS[E.torch.device(dev)] = side
-        E._SIDE_STREAMS[model.engine.device] = side
+        E._PAIR_STREAMS[(model.engine.device, (main or cur).cuda_stream)] = side     # overrides Engine.pair_stream's measured choice
         if main is None:
             t = timed(step)
         else:
@@ -41,5 +40,5 @@ for main in [None] + pool[:4] + hi[:1]:
 res.sort()
 print("best five:", [(round(t, 3), a, b) for t, a, b in res[:5]])
 print("worst three:", [(round(t, 3), a, b) for t, a, b in res[-3:]])
-E._SIDE_STREAMS.clear()
+E._PAIR_STREAMS.clear()
 print("one stream:", round(timed(lambda: sharded_pair_logits(model, px, ids, mask, overlap=False, equal_shards=True)), 3))

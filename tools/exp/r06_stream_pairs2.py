@@ -26,7 +26,7 @@ arms = {"default + first": (None, first), "pool[2] + pool[5]": (pool[2], pool[5]
 res = {k: [] for k in arms}
 for rnd in range(5):
     for name, (main, side) in arms.items():
-        E._SIDE_STREAMS[model.engine.device] = side
+        E._PAIR_STREAMS[(model.engine.device, (main or cur).cuda_stream)] = side     # overrides Engine.pair_stream's measured choice
         if main is None:
             t = timed(step)
         else:

@@ -51,6 +51,7 @@ def main():
                     seen.add((d, r["Dispatch_Id"]))
                     dur[k].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
     order = sorted(acc, key=lambda k: -sum(dur[k]))
+    per_step = []
     for k in order:
         c = {n: sum(v) / len(v) for n, v in acc[k].items()}
         t_ns = sum(dur[k]) / len(dur[k])
@@ -62,6 +63,7 @@ def main():
             b = 2.0 * 1024 * c["FETCH_SIZE"] + 1024 * c["WRITE_SIZE"]
             print(f"   => HBM/fabric traffic {b / 1e6:.1f} MB per launch ({2.0 * 1024 * c['FETCH_SIZE'] / 1e6:.1f} read, x2 gfx950 correction; "
                   f"{1024 * c['WRITE_SIZE'] / 1e6:.1f} written) = {b / t_ns / 1e3:.2f} TB/s")
+            per_step.append((k, len(acc[k]["FETCH_SIZE"]), b))
         if "SQ_WAVE_CYCLES" in c and c["SQ_WAVE_CYCLES"] > 0:
             w = c["SQ_WAVE_CYCLES"]
             print(f"   => wave time: WAIT_ANY {100 * c.get('SQ_WAIT_ANY', 0) / w:.0f} %, WAIT_INST_ANY {100 * c.get('SQ_WAIT_INST_ANY', 0) / w:.0f} %, "
@@ -73,6 +75,14 @@ def main():
             clk = c["GRBM_GUI_ACTIVE"] / 8.0
             print(f"   => MFMA pipe busy {100 * c['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024 * clk):.1f} % of the matrix pipes' time (GRBM_GUI_ACTIVE / 8 as the time base)")
         print()
+    # bytes per step: the patch GEMM runs once per step, so its launch count is the number of steps the profiled command ran
+    steps = [n for k, n, _ in per_step if k.endswith(",patch>")]
+    if steps:
+        print(f"# ---- bytes per step (launches per step x (FETCH_SIZE x 2 + WRITE_SIZE) per launch; the profiled pass ran {steps[0]} steps) ----")
+        rows = sorted(((k, n / steps[0], b) for k, n, b in per_step), key=lambda r: -r[1] * r[2])
+        for k, n, b in rows:
+            print(f"#   {k:56s} {n:6.1f} x {b / 1e6:7.1f} MB = {n * b / 1e9:6.3f} GB")
+        print(f"#   TOTAL {sum(n * b for _, n, b in rows) / 1e9:.2f} GB per step")
 
 
 if __name__ == "__main__":
