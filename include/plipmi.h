@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define PLIPMI_VERSION 411 /* 0.4.1: `pass_batch` appended to the config struct -- a 0.4.0 caller's shorter struct means 0 = automatic;
+#define PLIPMI_VERSION 412 /* 0.4.1: `pass_batch` appended to the config struct -- a 0.4.0 caller's shorter struct means 0 = automatic;
                             * 0.4.0: plipmi_config starts with `struct_size` (the struct can grow at its tail without breaking
                             * callers compiled against an older header); test / A-B hooks moved to plipmi_test.h
                             * (0.3.1: `text_f16_layers`, PLIPMI_ERR_TOKEN_ID; 0.3.0: `flags`, `graph_batch`, PLIPMI_F16) */
@@ -159,6 +159,15 @@ typedef struct plipmi_weights {
 /* ---- lifetime ----------------------------------------------------------- */
 int  plipmi_create(const plipmi_config* cfg, const plipmi_weights* w, void* stream, plipmi_handle* out);
 void plipmi_destroy(plipmi_handle h);
+/* A second handle on the SAME packed weights with a workspace (activations, staging buffers, captured graphs) of its own: the
+ * configuration and the setters' state are copied as they are at the call, the weight memory is shared and lives until the last
+ * of the handles that use it is destroyed (any order).  A handle runs one batch per tower at a time -- its workspace is the batch's
+ * activations --, so a caller that walks a corpus through ONE tower (the loops of plip.py:41-52 and :64-71, the image side of
+ * reproducibility/evaluation/zero_shot/zero_shot.py) gives consecutive batches to two handles on two HIP streams: the launch
+ * boundaries, prologues / epilogues and the pooled tail of one batch then run under the GEMMs of the next, as the two towers of a
+ * pair do for each other -- configs[3]'s shard 99.1 -> 107.5 k img/s (tools/exp/r06_two_batches.py); same bits per row.  Costs the
+ * workspace again (ViT-B/32, max_batch 256: 1.4 GB), no second copy of the weights and no packing time. */
+int  plipmi_clone(plipmi_handle src, plipmi_handle* out);
 int  plipmi_version(void);
 const char* plipmi_last_error(void);
 /* name of the device the engine runs on ("gfx950:..."), for logs */

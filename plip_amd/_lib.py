@@ -79,6 +79,7 @@ SYMBOLS = {
     "plipmi_set_latency_batch": (_i, [_vp, _i]),
     "plipmi_set_graph_batch": (_i, [_vp, _i]),
     "plipmi_get_pass_batch": (_i, [_vp]),
+    "plipmi_clone": (_i, [_vp, C.POINTER(_vp)]),
     "plipmi_streams_overlap": (_i, [_vp, _vp, _vp, C.POINTER(_f)]),
     "plipmi_l2_normalize": (_i, [_vp, _vp, _i, _i, _vp]),
     "plipmi_logits": (_i, [_vp, _vp, _i, _vp, _i, _i, _f, _vp, _vp, _vp, _vp]),

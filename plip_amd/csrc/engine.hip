@@ -17,6 +17,7 @@
 
 #include <algorithm>
 #include <map>
+#include <memory>
 #include <string>
 #include <tuple>
 #include <vector>
@@ -123,6 +124,11 @@ struct ProfRec {
 
 }  // namespace
 
+struct DeviceSlab {            // one hipMalloc, freed with its last owner (a handle and the clones that share its weights)
+  char* p = nullptr;
+  ~DeviceSlab() { if (p) hipFree(p); }
+};
+
 struct plipmi_engine {
   plipmi_config cfg;
   int dtype = 0;
@@ -167,8 +173,9 @@ struct plipmi_engine {
   float *tok = nullptr, *tpos = nullptr, *fin_w = nullptr, *fin_b = nullptr, *tproj_t = nullptr;
   float *vproj = nullptr, *tproj = nullptr;        // [P, D] fp32, the HF layout (NT GEMM operand)
   float *vpooled = nullptr, *tpooled = nullptr;    // [max_batch, D] fp32 LayerNorm'd pooled rows
-  char* slab = nullptr;
+  char* slab = nullptr;       // this handle's own allocation: [weights | workspace] (plipmi_create) or [workspace] (plipmi_clone)
   size_t slab_bytes = 0;
+  std::shared_ptr<DeviceSlab> own, weights;   // `weights` keeps the allocation the weight pointers point into alive (a clone: its source's)
   int attn_impl = 0, attn_impl_vis = 0, attn_impl_txt = 0;
   // raised by the embedding kernels when a token id lies outside the vocabulary (host-visible memory; reported by the next
   // call on the handle and by plipmi_check_async -- the reference's lookup raises, plip.py:68)
@@ -222,10 +229,11 @@ struct Carver {  // two-pass slab carving: pass 1 sizes, pass 2 hands out pointe
   }
 };
 
-void carve(plipmi_engine* e, Carver& c) {
+// The slab of a handle made by plipmi_create is [packed weights | workspace]; a handle made by plipmi_clone shares its source's weights
+// (carve_weights is not run for it: it keeps the copied pointers) and carves a workspace of its own.
+void carve_weights(plipmi_engine* e, Carver& c) {
   const plipmi_config& g = e->cfg;
   const size_t es = e->esz;
-  const size_t B = (size_t)g.max_batch;
   e->patch_w = c.take<void>((size_t)g.v_width * e->kpad, es);
   e->cls = c.take<float>(g.v_width, 4);
   e->vpos = c.take<float>((size_t)(e->np + 1) * g.v_width, 4);
@@ -238,8 +246,6 @@ void carve(plipmi_engine* e, Carver& c) {
   e->tproj_t = c.take<float>((size_t)g.t_width * g.projection_dim, 4);
   e->vproj = c.take<float>((size_t)g.v_width * g.projection_dim, 4);
   e->tproj = c.take<float>((size_t)g.t_width * g.projection_dim, 4);
-  e->vpooled = c.take<float>(B * g.v_width, 4);
-  e->tpooled = c.take<float>(B * g.t_width, 4);
   for (Tower* t : {&e->vis, &e->txt}) {
     const size_t D = t->D, F = t->F;
     t->layers.resize(t->L);
@@ -249,6 +255,17 @@ void carve(plipmi_engine* e, Carver& c) {
       w.bqkv = c.take<float>(3 * D, 4); w.bo = c.take<float>(D, 4); w.b1 = c.take<float>(F, 4); w.b2 = c.take<float>(D, 4);
       w.ln1w = c.take<float>(D, 4); w.ln1b = c.take<float>(D, 4); w.ln2w = c.take<float>(D, 4); w.ln2b = c.take<float>(D, 4);
     }
+  }
+}
+
+void carve_workspace(plipmi_engine* e, Carver& c) {
+  const plipmi_config& g = e->cfg;
+  const size_t es = e->esz;
+  const size_t B = (size_t)g.max_batch;
+  e->vpooled = c.take<float>(B * g.v_width, 4);
+  e->tpooled = c.take<float>(B * g.t_width, 4);
+  for (Tower* t : {&e->vis, &e->txt}) {
+    const size_t D = t->D, F = t->F;
     const size_t M = B * t->S;
     t->x = c.take<float>(M * D, 4);
     t->h = c.take<void>(M * D, es);
@@ -731,7 +748,8 @@ int plipmi_create(const plipmi_config* cfg, const plipmi_weights* w, void* strea
   e->attn_impl_vis = e->attn_impl ? 1 : 0;
 
   Carver sizing;
-  carve(e, sizing);
+  carve_weights(e, sizing);
+  carve_workspace(e, sizing);
   e->slab_bytes = align_up(sizing.off, 256);
   hipError_t me = hipMalloc(reinterpret_cast<void**>(&e->slab), e->slab_bytes);
   if (me != hipSuccess) {
@@ -739,9 +757,13 @@ int plipmi_create(const plipmi_config* cfg, const plipmi_weights* w, void* strea
     delete e;
     return fail(PLIPMI_ERR_NOMEM, "hipMalloc(%zu bytes) failed: %s", need, hipGetErrorString(me));
   }
+  e->own = std::make_shared<DeviceSlab>();
+  e->own->p = e->slab;
+  e->weights = e->own;
   Carver placing;
   placing.base = e->slab;
-  carve(e, placing);
+  carve_weights(e, placing);
+  carve_workspace(e, placing);
   if (hipHostMalloc(reinterpret_cast<void**>(&e->bad_id), sizeof(int), hipHostMallocMapped) != hipSuccess) e->bad_id = nullptr;
   else *e->bad_id = 0;
 
@@ -770,11 +792,44 @@ int plipmi_create(const plipmi_config* cfg, const plipmi_weights* w, void* strea
   };
   rc = body();
   if (rc != PLIPMI_OK) {
-    hipFree(e->slab);
     if (e->bad_id) hipHostFree(e->bad_id);
-    delete e;
+    delete e;                  // frees the slab with its last owner
     return rc;
   }
+  *out = e;
+  return PLIPMI_OK;
+}
+
+int plipmi_clone(plipmi_handle src, plipmi_handle* out) {
+  if (!src || !out) return fail(PLIPMI_ERR_INVALID, "null argument");
+  *out = nullptr;
+  plipmi_engine* e = new plipmi_engine(*src);      // configuration, setters' state and every weight pointer
+  e->graphs.clear();                               // per-handle state starts empty
+  e->cap_stream = nullptr;
+  e->sim_ws = nullptr; e->sim_ws_bytes = 0;
+  e->prof = false; e->recs.clear(); e->pool.clear();
+  e->bad_id = nullptr;
+  e->own.reset();
+  e->slab = nullptr;
+  e->vis.small = e->txt.small = false; e->vis.packed = e->txt.packed = false;
+  e->vis.cur = e->vis.planes = e->vis.dtype;
+  e->txt.cur = e->txt.planes = e->txt.layer_dtype(0);
+  Carver sizing;
+  carve_workspace(e, sizing);
+  e->slab_bytes = align_up(sizing.off, 256);
+  hipError_t me = hipMalloc(reinterpret_cast<void**>(&e->slab), e->slab_bytes);
+  if (me != hipSuccess) {
+    const size_t need = e->slab_bytes;
+    delete e;
+    return fail(PLIPMI_ERR_NOMEM, "hipMalloc(%zu bytes) failed: %s", need, hipGetErrorString(me));
+  }
+  e->own = std::make_shared<DeviceSlab>();
+  e->own->p = e->slab;
+  Carver placing;
+  placing.base = e->slab;
+  carve_workspace(e, placing);
+  if (hipHostMalloc(reinterpret_cast<void**>(&e->bad_id), sizeof(int), hipHostMallocMapped) != hipSuccess) e->bad_id = nullptr;
+  else *e->bad_id = 0;
   *out = e;
   return PLIPMI_OK;
 }
@@ -785,7 +840,6 @@ void plipmi_destroy(plipmi_handle h) {
   for (hipEvent_t ev : h->pool) hipEventDestroy(ev);
   for (auto& kv : h->graphs) if (kv.second.exec) hipGraphExecDestroy(kv.second.exec);
   if (h->cap_stream) hipStreamDestroy(h->cap_stream);
-  if (h->slab) hipFree(h->slab);
   if (h->sim_ws) hipFree(h->sim_ws);
   if (h->bad_id) hipHostFree(h->bad_id);
   delete h;

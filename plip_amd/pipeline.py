@@ -27,12 +27,15 @@ def _prepare_batch(items: Sequence, prepare_item: Callable, pool: Optional[Threa
 
 def run_batches(items: Sequence, batch_size: int, prepare_item: Optional[Callable], consume: Callable,
                 device: Optional[torch.device] = None, num_workers: int = 1,
-                prepare_batch: Optional[Callable] = None) -> List[torch.Tensor]:
+                prepare_batch: Optional[Callable] = None, lanes: Optional[Sequence] = None) -> List[torch.Tensor]:
     """``consume(batch_on_device)`` for consecutive batches of ``prepare_item(item)`` arrays, order preserved.
 
     With ``prepare_batch(items, pool) -> (tag, ndarray)`` the caller prepares whole batches (and may route them:
     raw tiles / to-be-resized images / host-preprocessed pixels) and ``consume(tag, batch_on_device)`` gets the tag.
-    ``device=None`` (CPU-side tests) skips the pinned / copy-stream part and hands host tensors to ``consume``."""
+    ``device=None`` (CPU-side tests) skips the pinned / copy-stream part and hands host tensors to ``consume``.
+    ``lanes`` = ``Engine.lanes()``: batch k runs on lane k % n -- ``consume(..., engine)`` gets the lane's engine as its last
+    argument and is called inside the lane's stream --, so consecutive batches overlap on the GPU; every lane is joined into the
+    caller's stream before the outputs are returned."""
     n = len(items)
     if n == 0:
         return []
@@ -44,11 +47,11 @@ def run_batches(items: Sequence, batch_size: int, prepare_item: Optional[Callabl
     outs: List[torch.Tensor] = []
     if prepare_batch is not None:
         prep = lambda chunk: prepare_batch(chunk, pool)
-        eat = lambda tagged, t: consume(tagged[0], t)
+        eat = lambda tagged, t, *lane: consume(tagged[0], t, *lane)
         arr = lambda tagged: tagged[1]
     else:
         prep = lambda chunk: _prepare_batch(chunk, prepare_item, pool)
-        eat = lambda host, t: consume(t)
+        eat = lambda host, t, *lane: consume(t, *lane)
         arr = lambda host: host
     try:
         fut = ahead.submit(prep, items[bounds[0][0]:bounds[0][1]])
@@ -70,7 +73,7 @@ def run_batches(items: Sequence, batch_size: int, prepare_item: Optional[Callabl
                 nlo, nhi = bounds[k + 1]
                 fut = ahead.submit(prep, items[nlo:nhi])
             if not use_gpu:
-                outs.append(eat(prepared, host if torch.is_tensor(host) else torch.from_numpy(host)))
+                outs.append(eat(prepared, host if torch.is_tensor(host) else torch.from_numpy(host), *([lanes[k % len(lanes)][0]] if lanes else [])))
                 continue
             slot = k & 1
             if consumed[slot] is not None:
@@ -87,15 +90,28 @@ def run_batches(items: Sequence, batch_size: int, prepare_item: Optional[Callabl
                 staging[slot].copy_(ht)
                 src = staging[slot]
             pinned_src[slot] = src is host
-            main = torch.cuda.current_stream(device)
+            caller = torch.cuda.current_stream(device)
+            lane = lanes[k % len(lanes)] if lanes else None
+            main = lane[1] if lane else caller
             with torch.cuda.stream(copy_stream):
                 dev = src.to(device, non_blocking=True)
                 copied[slot].record(copy_stream)
             main.wait_event(copied[slot])
             dev.record_stream(main)
-            outs.append(eat(prepared, dev))
+            if lane:
+                with torch.cuda.stream(main):
+                    out = eat(prepared, dev, lane[0])
+                if torch.is_tensor(out):
+                    out.record_stream(caller)
+                outs.append(out)
+            else:
+                outs.append(eat(prepared, dev))
             consumed[slot] = torch.cuda.Event()
             consumed[slot].record(main)
+        if use_gpu and lanes:
+            caller = torch.cuda.current_stream(device)
+            for _, st in lanes[1:]:
+                caller.wait_stream(st)
     finally:
         ahead.shutdown(wait=True)
         if pool is not None:

@@ -19,6 +19,8 @@ prepare the caller's batches one by one (same routing, same preprocessing per ba
 """
 from __future__ import annotations
 
+import contextlib
+
 from typing import Callable, List, Optional, Sequence, Union
 
 import numpy as np
@@ -83,6 +85,17 @@ def _uniform_u8_images(chunk, n_px):
     return np.stack(arrs)
 
 
+@contextlib.contextmanager
+def _lane_loop(eng):
+    """``Engine.lane_loop`` where the engine has one (a PlipModel's); any other engine object: every call on it, in order."""
+    loop = getattr(eng, "lane_loop", None)
+    if loop is None:
+        yield lambda fn: fn(eng)
+    else:
+        with loop() as run:
+            yield run
+
+
 class PLIP:
     coalesce = True          # engine calls carry up to engine.max_batch rows whatever ``batch_size`` says (module docstring)
 
@@ -138,15 +151,18 @@ class PLIP:
         def flush():
             nonlocal pend, kind, rows
             if kind == "stage":            # native tiles: each copied ONCE, into the pinned staging rows; one H2D, one engine call
-                outs.append(eng.encode_image_u8(self._fill_stage(pend, n_px, cap)))
+                stage = self._fill_stage(pend, n_px, cap)       # (the H2D copy inside the call is synchronous: the rows may be refilled)
+                outs.append(run(lambda e: e.encode_image_u8(stage)))
             elif pend:
                 if len(pend) > 1 and any(t.is_cuda for t in pend):
                     pend = [t.to(eng.device) for t in pend]
                 t = pend[0] if len(pend) == 1 else torch.cat(pend)
-                outs.append(eng.encode_image_u8(t) if kind == "tiles" else self.model.get_image_features(pixel_values=t))
+                outs.append(run((lambda e: e.encode_image_u8(t)) if kind == "tiles" else (lambda e: e.encode_image(t, normalize=False))))
             pend, kind, rows = [], None, 0
 
-        with torch.no_grad():
+        # consecutive engine calls of the loop alternate between the engine and a clone on a second stream (Engine.lane_loop): one
+        # batch's launch boundaries and pooled tail run under the next batch's GEMMs; the rows' bits do not depend on the lane
+        with torch.no_grad(), _lane_loop(eng) as run:
             for s in range(0, len(images), batch_size):
                 chunk = images[s:s + batch_size]
                 if isinstance(chunk, (list, tuple)) and any(isinstance(c, str) for c in chunk):
@@ -221,17 +237,18 @@ class PLIP:
             arrs = list(pool.map(one, chunk)) if pool is not None else [one(c) for c in chunk]
             return "pixels", np.stack(arrs)
 
-        def consume(tag, t):
+        def consume(tag, t, e=eng):
             if tag == "tiles":
-                return eng.encode_image_u8(t)
+                return e.encode_image_u8(t)
             if tag == "resize":
-                return eng.encode_image_u8(eng.resize_crop_u8(t, crop=_CROP))
-            return self.model.get_image_features(pixel_values=t)
+                return e.encode_image_u8(e.resize_crop_u8(t, crop=_CROP))
+            return e.encode_image(t, normalize=False)
 
         bs = min(int(batch_size), eng.max_batch)
+        lanes = eng.lanes() if getattr(eng, "use_lanes", False) and hasattr(eng, "lanes") else None
         with torch.no_grad():
             outs = run_batches(images, bs, None, consume, device=eng.device, num_workers=num_workers,
-                               prepare_batch=prepare_batch)
+                               prepare_batch=prepare_batch, lanes=lanes)
         return torch.cat(outs).detach().cpu().numpy()
 
     # -- plip.py:55-71 ---------------------------------------------------------
@@ -248,10 +265,10 @@ class PLIP:
         step = int(batch_size)
         if self.coalesce:      # the captions are tokenised already: only the size of the engine calls changes
             step = max(step, int(getattr(self.model.engine, "max_batch", step)))
-        with torch.no_grad():
+        with torch.no_grad(), _lane_loop(self.model.engine) as run:
             for s in range(0, len(ids), step):
                 m = None if mask is None else mask[s:s + step]
-                outs.append(self.model.get_text_features(input_ids=ids[s:s + step], attention_mask=m))
+                outs.append(run(lambda e, s=s, m=m: e.encode_text(ids[s:s + step], m, normalize=False)))
         if not outs:
             return np.zeros((0, self.model.config.projection_dim), np.float32)
         return torch.cat(outs).detach().cpu().numpy()

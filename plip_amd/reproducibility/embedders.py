@@ -62,18 +62,20 @@ class CLIPEmbedder:
             from ..pipeline import run_batches          # decode on a thread pool, H2D on a copy stream
             step = max(1, min(int(batch_size), eng.max_batch))
             outs = run_batches(list(list_of_images), step, lambda i: np.asarray(self.preprocess(i), dtype=np.float32),
-                               lambda t: eng.encode_image(t, normalize=True), device=eng.device, num_workers=num_workers)
+                               lambda t, e=eng: e.encode_image(t, normalize=True), device=eng.device, num_workers=num_workers,
+                               lanes=eng.lanes() if eng.use_lanes else None)     # consecutive batches on two engines / streams
             return torch.cat(outs).cpu().numpy() if outs else np.zeros((0, self.model.config.projection_dim), np.float32)
         out = []
-        for a, b in self._chunks(len(list_of_images), batch_size):
-            items = list_of_images[a:b]
-            if torch.is_tensor(items):
-                px = items.to(dtype=torch.float32)
-            elif isinstance(items, np.ndarray) and items.dtype != object and items.ndim == 4 and items.shape[1] == 3:
-                px = torch.from_numpy(np.ascontiguousarray(items, dtype=np.float32))     # already preprocessed NCHW
-            else:
-                px = torch.from_numpy(np.stack([np.asarray(self.preprocess(i), dtype=np.float32) for i in items]))
-            out.append(eng.encode_image(px, normalize=True))       # :48 encode_image + :53 row normalisation
+        with eng.lane_loop() as run:       # consecutive batches alternate between the engine and a clone on a second stream
+            for a, b in self._chunks(len(list_of_images), batch_size):
+                items = list_of_images[a:b]
+                if torch.is_tensor(items):
+                    px = items.to(dtype=torch.float32)
+                elif isinstance(items, np.ndarray) and items.dtype != object and items.ndim == 4 and items.shape[1] == 3:
+                    px = torch.from_numpy(np.ascontiguousarray(items, dtype=np.float32))     # already preprocessed NCHW
+                else:
+                    px = torch.from_numpy(np.stack([np.asarray(self.preprocess(i), dtype=np.float32) for i in items]))
+                out.append(run(lambda e, px=px: e.encode_image(px, normalize=True)))       # :48 encode_image + :53 row normalisation
         if not out:
             return np.zeros((0, self.model.config.projection_dim), np.float32)
         return torch.cat(out).cpu().numpy()
@@ -96,10 +98,11 @@ class CLIPEmbedder:
     def embed_text(self, list_of_labels, device="cuda", num_workers=1, batch_size=32) -> np.ndarray:
         eng = self.model.engine
         out = []
-        for a, b in self._chunks(len(list_of_labels), batch_size):
-            ids = self._tokenize(list_of_labels[a:b])
-            # clip.tokenize pads with 0 and the OpenAI model pools at argmax(ids): eos_token_id < 0 selects that rule
-            out.append(eng.encode_text(ids, None, normalize=True, eos_token_id=-1))      # :66 + :73
+        with eng.lane_loop() as run:
+            for a, b in self._chunks(len(list_of_labels), batch_size):
+                ids = self._tokenize(list_of_labels[a:b])
+                # clip.tokenize pads with 0 and the OpenAI model pools at argmax(ids): eos_token_id < 0 selects that rule
+                out.append(run(lambda e, ids=ids: e.encode_text(ids, None, normalize=True, eos_token_id=-1)))      # :66 + :73
         if not out:
             return np.zeros((0, self.model.config.projection_dim), np.float32)
         return torch.cat(out).cpu().numpy()

@@ -408,6 +408,80 @@ def test_pair_stream_is_measured_to_run_beside_the_callers_stream(engines):
     print("overlap ratios of held[0] against ten later streams:", [round(r, 2) for r in ratios], "sharing a queue:", len(aliased))
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+def test_clone_shares_the_weights_and_lanes_keep_the_bits(dtype):
+    """plipmi_clone: a second handle on the same packed weights with a workspace of its own.  Its embeddings are the source's bits; the
+    weights outlive the source (destroyed first here); calls of more than max_batch rows run their chunks alternately on the engine
+    and its clone on two streams (Engine.lanes) with the bits of the one-lane call -- images, uint8 tiles, captions --; the setters
+    reach the clone; a token id out of range that a CLONE's embedding kernel met is reported by the engine; Engine.lane_loop and the
+    PLIP host loops give the plain loops' results."""
+    from plip_amd.model import PlipModel
+    from plip_amd.plip import PLIP
+    from plip_amd import weights as W
+    cfg, sd, *_ = case_inputs("tiny_b6")
+    B = 37                                                     # max_batch 8: five chunks, the last one ragged
+    px = torch.from_numpy(W.synthetic_pixels(cfg, B, seed=15))
+    ids_np, mask_np = W.synthetic_ids(cfg, B, seed=16)
+    ids, mask = torch.from_numpy(ids_np), torch.from_numpy(mask_np)
+    tiles = torch.from_numpy(np.random.RandomState(4).randint(0, 256, size=(B, cfg.image_size, cfg.image_size, 3), dtype=np.uint8))
+    model = PlipModel(cfg, sd, dtype=dtype, max_batch=8)
+    eng = model.engine
+    try:
+        eng.use_lanes = False
+        want = (eng.encode_image(px, True), eng.encode_image_u8(tiles, False), eng.encode_text(ids, mask, True), eng.encode_text(ids, None, False))
+        torch.cuda.synchronize()
+        assert getattr(eng, "_lanes", None) is None            # nothing was cloned for the one-lane calls
+        # a clone by itself, used after its source is gone
+        src = PlipModel(cfg, sd, dtype=dtype, max_batch=8).engine
+        twin = src.clone()
+        src.close()
+        twin.use_lanes = False
+        assert torch.equal(twin.encode_image(px, True), want[0]) and torch.equal(twin.encode_text(ids, mask, True), want[2])
+        twin.close()
+        # chunks on two lanes
+        eng.use_lanes = True
+        got = (eng.encode_image(px, True), eng.encode_image_u8(tiles, False), eng.encode_text(ids, mask, True), eng.encode_text(ids, None, False))
+        torch.cuda.synchronize()
+        assert eng._lanes is not None and len(eng._lanes) == 1
+        for a, b in zip(want, got):
+            assert torch.equal(a, b)
+        rows = []
+        with eng.profile(rows):                                # profiling keeps every chunk on the profiled handle
+            eng.encode_image(px, True)
+        assert sum(r["calls"] for r in rows if "patch_embed" in r["name"]) == 5
+        # a bad id in the FOURTH chunk (rows 24..31 -> the clone's lane, its last chunk of the call) is the engine's to report, once
+        bad = ids.to(eng.device).clone()
+        bad[25, 2] = cfg.vocab_size
+        eng.encode_text(bad, None)
+        with pytest.raises(IndexError):
+            eng.check_async()
+        eng.check_async()
+        eng.encode_text(bad, None)
+        torch.cuda.synchronize()
+        with pytest.raises(IndexError):
+            eng.encode_text(ids, None)
+        assert torch.equal(eng.encode_text(ids, None, False), want[3])
+        # setters reach the clone: packed captions (bit-identical by construction) and the latency path (tolerance) on every lane
+        if dtype == "bf16":
+            eng.set_text_packing(True)
+            assert torch.equal(eng.encode_text(ids, mask, True), want[2])
+            eng.set_text_packing(False)
+        # the host loop form
+        with eng.lane_loop() as run:
+            parts = [run(lambda e, a=a: e.encode_image_u8(tiles[a:a + 8], False)) for a in range(0, B, 8)]
+        assert torch.equal(torch.cat(parts), want[1])
+        plip = PLIP(model=model, tokenizer=None)
+        imgs = [t.numpy() for t in tiles]
+        two = (plip.encode_images(imgs, batch_size=8), plip.encode_text(ids_np, batch_size=8), plip.encode_images(imgs, batch_size=8, num_workers=2))
+        eng.use_lanes = False
+        one = (plip.encode_images(imgs, batch_size=8), plip.encode_text(ids_np, batch_size=8), plip.encode_images(imgs, batch_size=8, num_workers=2))
+        for a, b in zip(one, two):
+            assert np.array_equal(a, b)
+        assert np.array_equal(one[0], one[2]) and np.array_equal(one[0], want[1].cpu().numpy())
+    finally:
+        eng.close()
+
+
 def test_config_struct_size_lets_the_struct_grow(engines):
     """plipmi_config starts with its own size: a caller compiled against an OLDER, shorter header -- one that
     ends at max_batch -- gets every later member as 0 (the product defaults), not whatever lies behind its struct; sizes

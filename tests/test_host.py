@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     product = open(os.path.join(ROOT, "include", "plipmi.h")).read()
     for hook in ("plipmi_gemm_nt", "plipmi_attention", "plipmi_test_force_gemm_tile", "plipmi_test_reset_hooks", "plipmi_recode_planes", "plipmi_debug_hidden"):
         assert not re.search(r"\b%s\s*\(" % hook, product), hook
-    assert lib.plipmi_version() == 411
+    assert lib.plipmi_version() == 412
     names = []
     i = 0
     while lib.plipmi_gemm_variant_name(i):

@@ -56,9 +56,9 @@ def main():
     nb = (args.images + B - 1) // B
     sizes = [min(B, args.images - k * B) for k in range(nb)]
 
-    def classify(tiles):
-        img = eng.encode_image_u8(tiles, normalize=True)
-        return eng.logits(img, class_emb, scale=1.0, want_text=False, want_argmax=True)[2]
+    def classify(tiles, e=eng):
+        img = e.encode_image_u8(tiles, normalize=True)
+        return e.logits(img, class_emb, scale=1.0, want_text=False, want_argmax=True)[2]
 
     def scores(tiles):
         img = eng.encode_image_u8(tiles, normalize=True)
@@ -67,21 +67,38 @@ def main():
     for k in range(3):
         classify(dev_pool[k % args.pool])
     torch.cuda.synchronize()
-    # ---- resident ---------------------------------------------------------------------------------------------------
-    t0 = time.perf_counter()
-    preds = [classify(dev_pool[k % args.pool][:sizes[k]]) for k in range(nb)]
-    torch.cuda.synchronize()
-    dt_res = time.perf_counter() - t0
-    pred_res = torch.cat(preds).cpu().numpy()
+    # ---- resident: consecutive batches on two lanes (the engine + a clone on a second stream, Engine.lane_loop) = the product's loop;
+    #      `one_lane` = every batch on the one engine and stream (rounds 1-5) ---------------------------------------------------
+    def resident(two_lanes):
+        eng.use_lanes = two_lanes
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with eng.lane_loop() as run:
+            preds = [run(lambda e, k=k: classify(dev_pool[k % args.pool][:sizes[k]], e)) for k in range(nb)]
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, torch.cat(preds).cpu().numpy()
+
     # ---- H2D-inclusive: pinned host batches -> copy stream -> towers (double buffered) ----------------------------------
     items = list(range(nb))
-    t0 = time.perf_counter()
-    outs = run_batches(items, 1, None, lambda tag, t: classify(t), device=dev, num_workers=1,
-                       prepare_batch=lambda chunk, pool: ("tiles", host_pool[chunk[0] % args.pool][:sizes[chunk[0]]]))
-    torch.cuda.synchronize()
-    dt_h2d = time.perf_counter() - t0
-    pred_h2d = torch.cat(outs).cpu().numpy()
-    assert np.array_equal(pred_res, pred_h2d), "resident and H2D paths disagree"
+
+    def h2d(two_lanes):
+        eng.use_lanes = two_lanes
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        outs = run_batches(items, 1, None, lambda tag, t, e=eng: classify(t, e), device=dev, num_workers=1,
+                           prepare_batch=lambda chunk, pool: ("tiles", host_pool[chunk[0] % args.pool][:sizes[chunk[0]]]),
+                           lanes=eng.lanes() if two_lanes else None)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, torch.cat(outs).cpu().numpy()
+
+    resident(True)                                   # the clone's workspace and the second stream exist before anything is timed
+    dt_res1, pred_res1 = resident(False)
+    dt_res, pred_res = resident(True)
+    dt_h2d1, pred_h2d1 = h2d(False)
+    dt_h2d, pred_h2d = h2d(True)
+    eng.use_lanes = True
+    assert np.array_equal(pred_res, pred_h2d) and np.array_equal(pred_res, pred_res1) and np.array_equal(pred_res, pred_h2d1), \
+        "resident / H2D / one-lane / two-lane paths disagree"
     # ---- agreement with the reference's head on the fixture's sample (HF scores stored in the fixture) ---------------------------
     ns = min(n_sample, args.pool * B, args.images)
     sim = gold["scores"][:ns]
@@ -99,8 +116,11 @@ def main():
                   f"{args.images} images = {nb} batches of {B}, {args.classes} class prompts replicated, arg-max head",
         "device": eng.device_name,
         "resident": {"images_per_s": round(args.images / dt_res, 1), "seconds": round(dt_res, 3),
-                     "note": "tiles resident in HBM (pool of distinct batches, cycled)"},
+                     "one_lane_images_per_s": round(args.images / dt_res1, 1),
+                     "note": "tiles resident in HBM (pool of distinct batches, cycled); consecutive batches alternate between the engine and "
+                             "a clone on a second stream (Engine.lane_loop) -- one_lane: every batch on one engine and stream, same predictions"},
         "h2d_inclusive": {"images_per_s": round(args.images / dt_h2d, 1), "seconds": round(dt_h2d, 3),
+                          "one_lane_images_per_s": round(args.images / dt_h2d1, 1),
                           "bytes_per_image": 3 * n_px * n_px,
                           "pcie_GBps": round(args.images * 3 * n_px * n_px / dt_h2d / 1e9, 2),
                           "note": "tiles in pinned host memory -> copy stream -> towers, double buffered (plip_amd/pipeline.py)"},
