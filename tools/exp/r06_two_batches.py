@@ -3,8 +3,8 @@
 
 The pair step hides a tower's launch boundaries, prologues / epilogues and tail behind the OTHER tower's kernels (4.65 -> 4.30 ms).  A corpus
 pass (configs[3]: the image tower + the arg-max head over 489 batches) has no other tower -- but it has the NEXT batch.  Arms, interleaved:
-  one     every batch on the default stream, one handle (what tools/config3_shard.py measures as `resident`)
-  two     even batches on the default stream / handle A, odd batches on a second stream (Engine.pair_stream) / handle B, no cross-stream waits
+  n lanes   batch k on stream k % n / handle k % n (plipmi_clone of the first: same weights, a workspace each), no cross-stream waits;
+            1 lane = what tools/config3_shard.py measured as `resident` through round 5
 """
 import os
 import sys
@@ -23,13 +23,20 @@ cfg = get_config("ViT-B/32")
 sd = W.synthetic_state_dict(cfg, 0)
 B, NB = 256, int(sys.argv[1]) if len(sys.argv) > 1 else 120
 A = PlipModel(cfg, sd, device=dev, dtype="bf16", max_batch=B)
-Bm = PlipModel(cfg, sd, device=dev, dtype="bf16", max_batch=B)
 ids, _ = W.synthetic_ids(cfg, 10, seed=7)
 cls = A.engine.encode_text(torch.from_numpy(ids), None, normalize=True)
 tiles = W.synthetic_tiles(cfg, 4 * B, 11)
 pool = [torch.from_numpy(tiles[k * B:(k + 1) * B]).to(dev) for k in range(4)]
 main = torch.cuda.current_stream(dev)
-side = A.engine.pair_stream(main)
+engines = [A.engine] + [A.engine.clone() for _ in range(3)]            # plipmi_clone: the same packed weights, a workspace each
+streams = [main, A.engine.pair_stream(main)]
+for _ in range(16):                                                    # two more streams that overlap with main and with each other
+    if len(streams) == 4:
+        break
+    c = torch.cuda.Stream(device=dev)
+    if all(A.engine.streams_overlap(s, c) < 1.5 for s in streams):
+        streams.append(c)
+print("streams found:", len(streams))
 
 
 def classify(eng, t):
@@ -37,21 +44,18 @@ def classify(eng, t):
     return eng.logits(img, cls, scale=1.0, want_text=False, want_argmax=True)[2]
 
 
-def one():
-    return [classify(A.engine, pool[k % 4]) for k in range(NB)]
-
-
-def two():
-    out = [None] * NB
-    side.wait_stream(main)
-    for k in range(NB):
-        if k & 1:
-            with torch.cuda.stream(side):
-                out[k] = classify(Bm.engine, pool[k % 4])
-        else:
-            out[k] = classify(A.engine, pool[k % 4])
-    main.wait_stream(side)
-    return out
+def lanes(n):
+    def fn():
+        out = [None] * NB
+        for st in streams[1:n]:
+            st.wait_stream(main)
+        for k in range(NB):
+            with torch.cuda.stream(streams[k % n]):
+                out[k] = classify(engines[k % n], pool[k % 4])
+        for st in streams[1:n]:
+            main.wait_stream(st)
+        return out
+    return fn
 
 
 def timed(fn):
@@ -62,12 +66,13 @@ def timed(fn):
     return time.perf_counter() - t0, out
 
 
-ref = torch.cat(timed(one)[1])
-got = torch.cat(timed(two)[1])
-print("same predictions:", bool(torch.equal(ref, got)))
-res = {"one": [], "two": []}
+arms = {f"{n} lane(s)": lanes(n) for n in range(1, len(streams) + 1)}
+ref = torch.cat(timed(arms["1 lane(s)"])[1])
+for name, fn in arms.items():
+    print(name, "same predictions:", bool(torch.equal(ref, torch.cat(timed(fn)[1]))))
+res = {k: [] for k in arms}
 for rnd in range(4):
-    for name, fn in (("one", one), ("two", two)):
+    for name, fn in arms.items():
         res[name].append(timed(fn)[0])
 for name, ts in res.items():
     t = sorted(ts)[len(ts) // 2]
