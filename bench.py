@@ -780,6 +780,37 @@ def _run(args, world, rank, world_size_env, model_factory, emit):
             res["h2d_inclusive"] = h2d_inclusive(model, cfg, px, ids, mask, args.steps, args.warmup, bool(args.overlap))
         except Exception as e:  # pragma: no cover
             res["h2d_inclusive"] = {"error": repr(e)}
+        # ONE tower over many batches (the image side of BASELINE.json configs[3]; PLIP.encode_images, plip.py:41-52): a handle runs one
+        # batch per tower at a time, so the product's host loops give consecutive batches to the engine and to a plipmi_clone of it (same
+        # packed weights, a workspace of its own) on two streams (Engine.lane_loop) -- one batch's launch boundaries, epilogues and pooled
+        # tail run under the next batch's GEMMs.  `one_lane` = the plain loop; arms interleaved, median of three rounds of 40 batches.
+        try:
+            eng = model.engine
+            tiles_c = [torch.randint(0, 256, (B, cfg.image_size, cfg.image_size, 3), dtype=torch.uint8, device=dev) for _ in range(2)]
+
+            def corpus(two_lanes, nb=40):
+                eng.use_lanes = two_lanes
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                with eng.lane_loop() as run:
+                    outs = [run(lambda e, k=k: e.encode_image_u8(tiles_c[k & 1], True)) for k in range(nb)]
+                torch.cuda.synchronize(dev)
+                return (time.perf_counter() - t0) / nb, outs
+
+            same_bits = all(torch.equal(a, b) for a, b in zip(corpus(False, 4)[1], corpus(True, 4)[1]))
+            rounds = {False: [], True: []}
+            for _ in range(3):
+                for arm in (False, True):
+                    rounds[arm].append(corpus(arm)[0])
+            eng.use_lanes = True
+            t1, t2 = sorted(rounds[False])[1], sorted(rounds[True])[1]
+            res["image_corpus_lanes"] = {
+                "workload": f"image tower only, uint8 {cfg.image_size}px tiles resident in HBM, 40 consecutive batches of {B}",
+                "two_lanes": {"images_per_s": round(B / t2, 1), "ms_per_batch": round(t2 * 1e3, 3), "rounds_ms": [round(t * 1e3, 3) for t in rounds[True]]},
+                "one_lane": {"images_per_s": round(B / t1, 1), "ms_per_batch": round(t1 * 1e3, 3), "rounds_ms": [round(t * 1e3, 3) for t in rounds[False]]},
+                "bit_identical": same_bits}
+        except Exception as e:  # pragma: no cover
+            res["image_corpus_lanes"] = {"error": repr(e)}
         # one GPU's share of BASELINE.json configs[4] (ViT-L/14@336, bs=512 over 8 GPUs = 64 pairs per GPU), same dtype
         try:
             cl = get_config("ViT-L/14@336px")
