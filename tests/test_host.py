@@ -431,3 +431,7 @@ def test_named_test_hooks_reject_values_outside_their_range():
     finally:
         lib.plipmi_test_reset_hooks()
     assert lib.plipmi_get_pass_batch(None) == 0
+    import ctypes as C
+    out, ratio = C.c_void_p(1), C.c_float(0)
+    assert lib.plipmi_clone(None, C.byref(out)) != 0 and "null" in _lib.last_error()          # no source handle: an error, no crash
+    assert lib.plipmi_streams_overlap(None, None, None, C.byref(ratio)) != 0
