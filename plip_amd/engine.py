@@ -314,6 +314,11 @@ class Engine:
             self._no_lanes -= 1
 
     def _encode_pair(self, pixels, input_ids, attention_mask, normalize, overlap):
+        cfg = self.cfg          # the image side's shape error comes first, as in CLIPModel.forward, and before anything is enqueued
+        ok = (tuple(pixels.shape[1:]) == (cfg.image_size, cfg.image_size, 3)) if pixels.dtype == torch.uint8 else \
+            (pixels.dim() == 4 and tuple(pixels.shape[1:]) == (3, cfg.image_size, cfg.image_size))
+        if not ok:
+            self._encode_image_any(pixels, normalize)       # raises the tower's own ValueError
         n = pixels.shape[0]
         if overlap and self.pass_batch > 0 and n >= 2 * self.pass_batch and input_ids.shape[0] == n:
             # plipmi_config.pass_batch at the level that owns BOTH streams: equal passes, the two towers of a pass joined before the next

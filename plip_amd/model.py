@@ -111,8 +111,9 @@ class PlipModel:
             input_ids, pixel_values = pixel_values, input_ids
         if input_ids is None or pixel_values is None:
             raise ValueError("You have to specify input_ids and pixel_values")
-        img = self.engine.encode_image(pixel_values, normalize=True)           # modeling_clip.py:810
-        txt = self.engine.encode_text(input_ids, attention_mask, normalize=True)  # :811
+        # modeling_clip.py:793-811: the two towers, here side by side on two HIP streams (Engine.encode_pair: the bits of the
+        # one-stream order, the bench's step -- 4.4 -> 4.2 ms at bs = 256)
+        img, txt = self.engine.encode_pair(pixel_values, input_ids, attention_mask, normalize=True)
         lpi, lpt, _ = self.engine.logits(img, txt, scale=float(np.exp(float(self.logit_scale))))  # :814-817
         if openai_style:
             return lpi, lpt
