@@ -166,7 +166,7 @@ void plipmi_destroy(plipmi_handle h);
  * reproducibility/evaluation/zero_shot/zero_shot.py) gives consecutive batches to two handles on two HIP streams: the launch
  * boundaries, prologues / epilogues and the pooled tail of one batch then run under the GEMMs of the next, as the two towers of a
  * pair do for each other -- configs[3]'s shard 99.1 -> 107.5 k img/s (tools/exp/r06_two_batches.py); same bits per row.  Costs the
- * workspace again (ViT-B/32, max_batch 256: 1.4 GB), no second copy of the weights and no packing time. */
+ * workspace again (ViT-B/32, max_batch 256: 0.56 GB), no second copy of the weights and no packing time. */
 int  plipmi_clone(plipmi_handle src, plipmi_handle* out);
 int  plipmi_version(void);
 const char* plipmi_last_error(void);
