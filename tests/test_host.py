@@ -223,6 +223,17 @@ def test_host_pipeline_order_and_errors():
     with pytest.raises(OSError):
         run_batches(items, 5, bad, lambda t: t, device=None, num_workers=2)
 
+    # lanes (Engine.lanes(): consecutive batches alternate between an engine and its clone): batch k is consumed with lane k % n's
+    # engine as the last argument, the order of the outputs is the order of the batches -- with and without a batch tag
+    seen = []
+    outs = run_batches(items, 5, prep, lambda t, e: (seen.append(e), t.sum(dim=(1, 2)))[1], device=None, num_workers=2,
+                       lanes=[("engine", None), ("clone", None)])
+    assert seen == ["engine", "clone", "engine", "clone", "engine"] and torch.cat(outs).tolist() == [4.0 * i for i in items]
+    seen = []
+    outs = run_batches(items, 5, None, lambda tag, t, e: (seen.append((tag, e)), t.sum(dim=(1, 2)))[1], device=None, num_workers=0,
+                       prepare_batch=lambda chunk, pool: ("tiles", np.stack([prep(i) for i in chunk])), lanes=[("engine", None), ("clone", None)])
+    assert seen == [("tiles", "engine"), ("tiles", "clone")] * 2 + [("tiles", "engine")] and torch.cat(outs).tolist() == [4.0 * i for i in items]
+
 
 @pytest.mark.parametrize("h,w,n", [(300, 500, 224), (512, 512, 224), (256, 256, 224), (224, 300, 224), (1000, 700, 224),
                                    (100, 130, 64), (64, 200, 64), (233, 224, 224), (225, 225, 224), (96, 96, 224)])
