@@ -60,22 +60,25 @@ def run_batches(items: Sequence, batch_size: int, prepare_item: Optional[Callabl
             # high priority: a queue class of its own -- an ordinary stream may share its hardware queue with the stream the towers run
             # on, and its copies then run in order with the kernels instead of beside them (profiles/r06_h2d_copy_stream.txt)
             copy_stream = torch.cuda.Stream(device=device, priority=-1)
-            staging = [None, None]
-            copied = [torch.cuda.Event(), torch.cuda.Event()]
-            consumed = [None, None]
-            pinned_src = [False, False]
+            # device-side slots: two for one lane (batch k+1 is copied while batch k runs); with lanes two batches run at once, so the
+            # copy of batch k+2 needs a third slot to start before batch k has finished -- two per lane
+            ns = 2 * len(lanes) if lanes else 2
+            staging = [None] * ns
+            copied = [torch.cuda.Event() for _ in range(ns)]
+            consumed = [None] * ns
+            pinned_src = [False] * ns
         for k, (lo, hi) in enumerate(bounds):
             prepared = fut.result()
             host = arr(prepared)
-            if use_gpu and k >= 1 and pinned_src[(k - 1) & 1]:
-                copied[(k - 1) & 1].synchronize()       # batch k-1 has left its producer-owned pinned buffer: it may be refilled
+            if use_gpu and k >= 1 and pinned_src[(k - 1) % ns]:
+                copied[(k - 1) % ns].synchronize()      # batch k-1 has left its producer-owned pinned buffer: it may be refilled
             if k + 1 < len(bounds):
                 nlo, nhi = bounds[k + 1]
                 fut = ahead.submit(prep, items[nlo:nhi])
             if not use_gpu:
                 outs.append(eat(prepared, host if torch.is_tensor(host) else torch.from_numpy(host), *([lanes[k % len(lanes)][0]] if lanes else [])))
                 continue
-            slot = k & 1
+            slot = k % ns
             if consumed[slot] is not None:
                 consumed[slot].synchronize()            # the tower that read this slot's device copy has finished
             if torch.is_tensor(host) and host.is_pinned():
