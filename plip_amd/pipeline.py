@@ -9,7 +9,10 @@ tower and copies the features back -- every step waits for the previous one; ``C
 * the prepared batch goes through one of two pinned staging buffers and an H2D copy on a dedicated copy stream, so
   the transfer of batch k+1 overlaps the towers of batch k (uint8 tiles: 38.5 MB per 256 images, ~0.6 ms on PCIe
   Gen5; fp32 pixels are 4x that);
-* features stay on the GPU until the end (one D2H copy), instead of one synchronising ``.cpu()`` per batch.
+* features stay on the GPU until the end (one D2H copy), instead of one synchronising ``.cpu()`` per batch;
+* with ``lanes`` (``Engine.lanes()``: the engine + a ``plipmi_clone`` of it on a second stream) consecutive batches run side by side on
+  the GPU -- one batch's launch boundaries, epilogues and pooled tail under the next batch's GEMMs -- and there are two staging slots
+  per lane, so that the copy of batch k+2 does not wait for batch k (configs[3]'s shard H2D-inclusive: 96 -> 106 k img/s).
 """
 from __future__ import annotations
 
